@@ -1,0 +1,226 @@
+"""Parameter surface of the InsMOS inference path in the *reference's* checkpoint layout.
+
+A Lightning checkpoint of the reference stores `state_dict` with keys prefixed `model.`
+(models/models.py:52) in the layouts of its dependencies:
+  * MinkowskiEngine kernels  `...kernel`  (K_vol, Cin, Cout), x-fastest tap order; (Cin, Cout) for
+    1x1 convs; bias (1, Cout)                                 [minkunet.py:55-137, resnet.py:96-126]
+  * spconv 2.3.6 weights     `...weight`  (Cout, kz, ky, kx, Cin)        [spconv_unet.py:120-207]
+  * torch Conv2d (Cout,Cin,kh,kw), ConvTranspose2d (Cin,Cout,kh,kw), BatchNorm1d/2d, Linear
+This module enumerates every tensor on the inference path (`param_spec`), draws a seeded random
+checkpoint in exactly that layout (`random_state_dict` -- there are no published weights in this
+environment), and converts layouts into the (K, Cin, Cout) tap-major form the HIP kernels consume.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+ME_PREFIX = "model.motion_encoder.MinkUNet."
+UNET_PREFIX = "model.unet."
+
+
+def default_cfg():
+    """config/config.yaml of the reference, restricted to the keys the inference path reads
+    (SURVEY.md section 8b)."""
+    return {
+        "EXPERIMENT": {"ID": "InsMOS"},
+        "DATA": {
+            "POINT_CLOUD_RANGE": [-60, -50, -3, 60, 50, 1],
+            "VOXEL_SIZE": [0.1, 0.1, 0.1],
+            "TRANSFORM": True,
+            "POSES": "poses.txt",
+            "SEMANTIC_CONFIG_FILE": "./config/semantic-kitti-mos.yaml",
+            "CLASE_NAME": ["Car", "Pedestrian", "Cyclist"],
+        },
+        "TRAIN": {"LR": 0.0001, "LR_EPOCH": 1, "LR_DECAY": 0.99, "WEIGHT_DECAY": 0.0001, "BATCH_SIZE": 1},
+        "MODEL": {
+            "DELTA_T_PREDICTION": 0.1,
+            "N_PAST_STEPS": 10,
+            "USE_MOTION_LOSS": True,
+            "POINT_FEATURE_ENCODING": {"src_feature_list": ["x", "y", "z", "intensity"]},
+            "VFE": {"NAME": "MeanVFE"},
+            "MAP_TO_BEV": {"NAME": "HeightCompression", "NUM_BEV_FEATURES": 256},
+            "BACKBONE_2D": {"NAME": "BaseBEVBackbone", "LAYER_NUMS": [5], "LAYER_STRIDES": [1],
+                            "NUM_FILTERS": [128], "UPSAMPLE_STRIDES": [2], "NUM_UPSAMPLE_FILTERS": [256]},
+            "DENSE_HEAD": {"NAME": "CenterHead", "CLASS_AGNOSTIC": False, "NUM_CLASS": 3,
+                           "CLASE_NAME": ["Car", "Pedestrian", "Cyclist"],
+                           "TARGET_ASSIGNER_CONFIG": {"VOXEL_SIZE": [0.1, 0.1, 0.1], "OUT_SIZE_FACTOR": 4}},
+            "POST_PROCESSING": {"RECALL_THRESH_LIST": [0.3, 0.5, 0.7], "SCORE_THRESH": 0.1,
+                                "OUTPUT_RAW_SCORE": False,
+                                "NMS_CONFIG": {"MULTI_CLASSES_NMS": False, "NMS_TYPE": "nms_gpu", "NMS_THRESH": 0.01,
+                                               "NMS_PRE_MAXSIZE": 4096, "NMS_POST_MAXSIZE": 500}},
+        },
+    }
+
+
+# ---- MinkUNet14 / CustomMinkUNet: PLANES (8,16,32,64,64,32,16,8), INIT_DIM 8 (customminkunet.py:10-12)
+ME_BLOCKS = [  # (name, cin, cout)
+    ("block1.0", 8, 8), ("block2.0", 8, 16), ("block3.0", 16, 32),
+    ("block6.0", 48, 32), ("block7.0", 24, 16), ("block8.0", 16, 8),
+]
+ME_CONVS = [  # (conv name, bn name, kernel volume, cin, cout)
+    ("conv0p1s1", "bn0", 125, 1, 8), ("conv1p1s2", "bn1", 8, 8, 8), ("conv2p2s2", "bn2", 8, 8, 8),
+    ("conv3p4s2", "bn3", 8, 16, 16), ("convtr5p8s2", "bntr5", 8, 32, 32), ("convtr6p4s2", "bntr6", 8, 32, 16),
+    ("convtr7p2s2", "bntr7", 8, 16, 8),
+]
+
+# ---- UNetV2 (spconv_unet.py:111-209): (state_dict stem of conv, stem of bn or None, ksize, cin, cout)
+def unet_convs(in_ch=7, ncls=3):
+    L = [("conv_input.0", "conv_input.1", (3, 3, 3), in_ch, 16),
+         ("conv1.0.0", "conv1.0.1", (3, 3, 3), 16, 16)]
+    c = 16
+    for i, co in zip((2, 3, 4), (32, 64, 128)):
+        L.append((f"conv{i}.0.0", f"conv{i}.0.1", (3, 3, 3), c, co))
+        L.append((f"conv{i}.1.0", f"conv{i}.1.1", (3, 3, 3), co, co))
+        L.append((f"conv{i}.2.0", f"conv{i}.2.1", (3, 3, 3), co, co))
+        c = co
+    L.append(("conv_out.0", "conv_out.1", (3, 1, 1), 128, 128))
+    L.append(("inv_conv_out", None, (3, 1, 1), 128, 128))
+    L.append(("conv_up_instance_block.0", "conv_up_instance_block.1", (3, 3, 3), 128 + ncls, 128))
+    L.append(("conv_up_instance_block_up4.0", "conv_up_instance_block_up4.1", (3, 3, 3), 64 + ncls, 64))
+    L.append(("conv_up_instance_block_up3.0", "conv_up_instance_block_up3.1", (3, 3, 3), 32 + ncls, 32))
+    L.append(("conv_up_instance_block_up2.0", "conv_up_instance_block_up2.1", (3, 3, 3), 16 + ncls, 16))
+    L.append(("conv_up_instance_block_up1.0", "conv_up_instance_block_up1.1", (3, 3, 3), 16 + ncls, 16))
+    for lvl, C in ((4, 128), (3, 64), (2, 32), (1, 16)):
+        L.append((f"conv_up_t{lvl}.conv1", f"conv_up_t{lvl}.bn1", (3, 3, 3), C, C))
+        L.append((f"conv_up_t{lvl}.conv2", f"conv_up_t{lvl}.bn2", (3, 3, 3), C, C))
+        L.append((f"conv_up_m{lvl}.0", f"conv_up_m{lvl}.1", (3, 3, 3), 2 * C, C))
+        if lvl > 1:
+            L.append((f"inv_conv{lvl}.0", f"inv_conv{lvl}.1", (3, 3, 3), C, C // 2))
+    L.append(("conv_up_out.0.0", "conv_up_out.0.1", (3, 3, 3), 16, 16))
+    return L
+
+
+def param_spec(cfg=None):
+    """OrderedDict name -> (shape, kind) for every tensor the inference path reads."""
+    cfg = cfg or default_cfg()
+    ncls = cfg["MODEL"]["DENSE_HEAD"]["NUM_CLASS"]
+    in_ch = len(cfg["MODEL"]["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
+    nbev = cfg["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"]
+    b2d = cfg["MODEL"]["BACKBONE_2D"]
+    S = OrderedDict()
+
+    def bn(stem, c):
+        S[stem + ".weight"] = ((c,), "bn_w")
+        S[stem + ".bias"] = ((c,), "bn_b")
+        S[stem + ".running_mean"] = ((c,), "bn_m")
+        S[stem + ".running_var"] = ((c,), "bn_v")
+
+    P = ME_PREFIX
+    for conv, bnn, kv, ci, co in ME_CONVS:
+        S[P + conv + ".kernel"] = ((kv, ci, co), "me")
+        bn(P + bnn + ".bn", co)
+    for name, ci, co in ME_BLOCKS:
+        S[P + name + ".conv1.kernel"] = ((81, ci, co), "me")
+        bn(P + name + ".norm1.bn", co)
+        S[P + name + ".conv2.kernel"] = ((81, co, co), "me")
+        bn(P + name + ".norm2.bn", co)
+        if ci != co:
+            S[P + name + ".downsample.0.kernel"] = ((ci, co), "me")
+            bn(P + name + ".downsample.1.bn", co)
+    S[P + "final.kernel"] = ((8, 3), "me")
+    S[P + "final.bias"] = ((1, 3), "bias")
+
+    U = UNET_PREFIX
+    for conv, bnn, ks, ci, co in unet_convs(in_ch, ncls):
+        S[U + conv + ".weight"] = ((co, ks[0], ks[1], ks[2], ci), "spconv")
+        if bnn:
+            bn(U + bnn, co)
+    nf = b2d["NUM_FILTERS"][0]
+    S[U + "bev_backbone.blocks.0.1.weight"] = ((nf, nbev, 3, 3), "conv2d")
+    bn(U + "bev_backbone.blocks.0.2", nf)
+    for k in range(b2d["LAYER_NUMS"][0]):
+        S[U + f"bev_backbone.blocks.0.{4 + 3 * k}.weight"] = ((nf, nf, 3, 3), "conv2d")
+        bn(U + f"bev_backbone.blocks.0.{5 + 3 * k}", nf)
+    nu = b2d["NUM_UPSAMPLE_FILTERS"][0]
+    us = b2d["UPSAMPLE_STRIDES"][0]
+    S[U + "bev_backbone.deblocks.0.0.weight"] = ((nf, nu, us, us), "convT2d")
+    bn(U + "bev_backbone.deblocks.0.1", nu)
+    S[U + "center_head.conv_cls.weight"] = ((ncls, nu, 1, 1), "conv2d")
+    S[U + "center_head.conv_cls.bias"] = ((ncls,), "cls_bias")
+    S[U + "center_head.conv_box.weight"] = ((8, nu, 1, 1), "box_w")
+    S[U + "center_head.conv_box.bias"] = ((8,), "bias")
+    S[U + "mos_seg_layer.weight"] = ((3, 16), "linear")
+    S[U + "mos_seg_layer.bias"] = ((3,), "bias")
+    return S
+
+
+def random_state_dict(cfg=None, seed=0, cls_bias=None, box_w_std=0.001):
+    """Seeded random checkpoint in the reference's layout (numpy fp32 arrays).
+
+    Inits follow the reference modules' defaults in spirit (kaiming fan-out normal for ME kernels,
+    resnet.py:87-94; fan-in uniform for spconv/torch convs; BN weight 1 / bias 0) with BN running
+    statistics randomised to non-trivial values.  `cls_bias` overrides the
+    CenterHead classification bias (-log(99), center_head.py:60-63) so tests can force detections.
+    """
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for name, (shape, kind) in param_spec(cfg).items():
+        if kind == "me":
+            kv = shape[0] if len(shape) == 3 else 1
+            co = shape[-1]
+            a = rng.normal(0, math.sqrt(2.0 / (kv * co)), shape)
+        elif kind == "spconv":
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            b = math.sqrt(6.0 / ((1 + 5) * fan_in))  # kaiming_uniform(a=sqrt(5))
+            a = rng.uniform(-b, b, shape)
+        elif kind in ("conv2d", "convT2d", "linear"):
+            fan_in = int(np.prod(shape[1:])) if kind != "convT2d" else shape[1] * shape[2] * shape[3]
+            b = math.sqrt(1.0 / fan_in)
+            a = rng.uniform(-b, b, shape)
+        elif kind == "box_w":
+            a = rng.normal(0, box_w_std, shape)
+        elif kind == "bn_w":
+            a = rng.uniform(0.8, 1.2, shape)
+        elif kind == "bn_b":
+            a = rng.normal(0, 0.05, shape)
+        elif kind == "bn_m":
+            a = rng.normal(0, 0.1, shape)
+        elif kind == "bn_v":
+            a = rng.uniform(0.5, 1.5, shape)
+        elif kind == "cls_bias":
+            a = np.full(shape, -math.log(99.0) if cls_bias is None else cls_bias)
+        elif kind == "bias":
+            a = rng.uniform(-0.1, 0.1, shape)
+        else:
+            raise KeyError(kind)
+        sd[name] = np.asarray(a, dtype=np.float32)
+    return sd
+
+
+# ---- layout conversion (the only place that knows the dependency layouts) ------------------------
+def me_kernel_to_taps(kernel):
+    """ME kernel (K,Cin,Cout) or (Cin,Cout) -> (K,Cin,Cout)."""
+    k = np.asarray(kernel, dtype=np.float32)
+    return k[None] if k.ndim == 2 else k
+
+
+def spconv_weight_to_taps(weight):
+    """spconv 2.3.6 (Cout,kz,ky,kx,Cin) -> (K,Cin,Cout), K = (kz*KH+ky)*KW+kx."""
+    w = np.asarray(weight, dtype=np.float32)
+    co, kz, ky, kx, ci = w.shape
+    return np.ascontiguousarray(w.reshape(co, kz * ky * kx, ci).transpose(1, 2, 0))
+
+
+def conv2d_weight_to_taps(weight):
+    """torch Conv2d (Cout,Cin,kh,kw) -> (kh*kw, Cin, Cout), tap = ky*kw + kx (cross-correlation)."""
+    w = np.asarray(weight, dtype=np.float32)
+    co, ci, kh, kw = w.shape
+    return np.ascontiguousarray(w.reshape(co, ci, kh * kw).transpose(2, 1, 0))
+
+
+def convT2d_weight_to_taps(weight):
+    """torch ConvTranspose2d (Cin,Cout,kh,kw), stride == kernel -> (kh*kw, Cin, Cout):
+    out[s*y+ky, s*x+kx] = in[y,x] @ W[:, :, ky, kx]."""
+    w = np.asarray(weight, dtype=np.float32)
+    ci, co, kh, kw = w.shape
+    return np.ascontiguousarray(w.reshape(ci, co, kh * kw).transpose(2, 0, 1))
+
+
+def fold_bn(taps, bn_w, bn_b, bn_m, bn_v, eps, bias=None):
+    """Fold eval-mode BatchNorm into the taps: returns (taps * scale[co], shift[co])."""
+    scale = (np.asarray(bn_w, np.float64) / np.sqrt(np.asarray(bn_v, np.float64) + eps))
+    shift = np.asarray(bn_b, np.float64) - np.asarray(bn_m, np.float64) * scale
+    if bias is not None:
+        shift = shift + np.asarray(bias, np.float64).reshape(-1) * scale
+    return (np.asarray(taps, np.float64) * scale[None, None, :]).astype(np.float32), shift.astype(np.float32)

@@ -1,0 +1,99 @@
+"""The oracle (oracle/ref_ops.py + coracle.c) against golden vectors produced by the reference's own
+importable / compiled code (tests/golden/make_golden.py).  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_ops as R
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_center_decode(golden_dir):
+    g = G(golden_dir, "center_head.npz")
+    cls, boxes = R.center_decode(g["cls"][0], g["box"][0], 4, [0.1, 0.1, 0.1], [-60, -50])
+    np.testing.assert_array_equal(cls, g["out_cls"][0])
+    np.testing.assert_array_equal(boxes, g["out_boxes"][0])
+
+
+def test_metrics(golden_dir):
+    g = G(golden_dir, "metrics.npz")
+    cm = R.confusion_matrix(g["logits"], g["gt"])
+    np.testing.assert_array_equal(cm, g["cm"])
+    np.testing.assert_allclose(R.iou_from_confusion(cm), g["iou"], rtol=1e-6)
+
+
+def test_mean_vfe(golden_dir):
+    g = G(golden_dir, "mean_vfe.npz")
+    np.testing.assert_allclose(R.mean_vfe(g["voxels"], g["num"]), g["out"], rtol=0, atol=1e-6)
+
+
+def test_height_compression(golden_dir):
+    g = G(golden_dir, "height_compression.npz")
+    d = g["dense5"][0]  # (C, D, H, W)
+    C, D, H, W = d.shape
+    zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    coords = np.stack([zz.ravel(), yy.ravel(), xx.ravel()], 1)
+    feat = d[:, coords[:, 0], coords[:, 1], coords[:, 2]].T
+    np.testing.assert_array_equal(R.sparse_to_dense_bev(feat, coords, (D, H, W)), g["out"])
+
+
+@pytest.mark.parametrize("order", ["sorted", "perm1", "perm2"])
+def test_array_index_orders(golden_dir, order):
+    g = G(golden_dir, "array_index.npz")
+    out = R.boxes_to_onehot(g["coords_" + order], g["boxes"], 3)
+    np.testing.assert_array_equal(out, g["out_" + order])
+
+
+def test_array_index_quirk_demo(golden_dir):
+    g = G(golden_dir, "array_index.npz")
+    np.testing.assert_array_equal(R.boxes_to_onehot(g["demo_coords"], g["demo_box"], 3), g["demo_out"])
+    np.testing.assert_array_equal(R.boxes_to_onehot(g["demo_coords_b"], g["demo_box"], 3), g["demo_out_b"])
+    # the order dependence is real: the two orders give different answers for the same voxel set
+    a = g["demo_out"][np.lexsort(g["demo_coords"].T)]
+    b = g["demo_out_b"][np.lexsort(g["demo_coords_b"].T)]
+    assert not np.array_equal(a, b)
+    np.testing.assert_array_equal(R.boxes_to_onehot(g["coords_C"], g["boxes_C"], 3), g["out_C"])
+
+
+def test_iou_bev_matrices(golden_dir):
+    g = G(golden_dir, "iou_bev.npz")
+    np.testing.assert_array_equal(R.iou_bev_matrix(g["a"], g["b"]), g["iou_ab"])
+    np.testing.assert_array_equal(R.iou_bev_matrix(g["special"], g["special"]), g["iou_special"])
+    # survey's known answer: two 4x2 boxes offset 1 m, yaw 0.3 -> 0.5037
+    assert abs(float(R.iou_bev_matrix(g["special"][0:1], g["special"][2:3])[0, 0]) - 0.5037) < 5e-4
+
+
+def test_nms_keep_lists(golden_dir):
+    g = G(golden_dir, "iou_bev.npz")
+    np.testing.assert_array_equal(R.nms_bev(g["dense"], 0.01), g["keep_001"])
+    np.testing.assert_array_equal(R.nms_bev(g["dense"], 0.5), g["keep_05"])
+
+
+def test_post_process_end_to_end(golden_dir):
+    g = G(golden_dir, "post_process.npz")
+    boxes, scores, labels, _ = R.post_process(g["cls"], g["boxes"], 0.1, 0.01, int(g["pre_max"]), int(g["post_max"]))
+    np.testing.assert_array_equal(labels, g["pred_labels"])
+    np.testing.assert_array_equal(boxes, g["pred_boxes"])
+    np.testing.assert_allclose(scores, g["pred_scores"], rtol=0, atol=1e-7)
+
+
+def test_bev_backbone_torch_reference(golden_dir):
+    """oracle.ref_model.bev_forward (torch CPU functional) == the reference nn.Modules."""
+    from oracle import ref_model as M
+    g = G(golden_dir, "bev_backbone.npz")
+    sd = {}
+    for k in g.files:
+        if k.startswith("bev."):
+            sd[M.UN_P + "bev_backbone." + k[4:]] = g[k]
+        elif k.startswith("head."):
+            sd[M.UN_P + "center_head." + k[5:]] = g[k]
+    cfg = {"MODEL": {"BACKBONE_2D": {"LAYER_NUMS": [5], "UPSAMPLE_STRIDES": [2]}}}
+    f2d, cls, box = M.bev_forward(sd, cfg, g["x"])
+    np.testing.assert_allclose(f2d, g["f2d"][0].transpose(1, 2, 0), rtol=1e-5, atol=1e-5)
+    c, b = R.center_decode(cls, box, 4, [0.1, 0.1, 0.1], [-60, -50])
+    np.testing.assert_allclose(c, g["cls"][0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b, g["boxes"][0], rtol=1e-4, atol=1e-4)
