@@ -1,0 +1,238 @@
+/*
+ * include/insmos_hip.h -- C ABI of libinsmos_hip.so: the MI355X (gfx950) kernels behind the InsMOS
+ * sparse-voxel inference hot path.  Plain pointers and sizes only; every pointer is DEVICE memory
+ * unless its name ends in _host; every call is asynchronous on `stream` (a hipStream_t passed as
+ * void*) and returns 0 or a negative INSMOS_E* code -- never exit() like the reference's extensions
+ * (iou3d_nms.cpp:14-38).  Counts are produced in device memory (int32 slots of `counts`); the caller
+ * reads them when it needs them.  Scratch comes from a caller-provided workspace (`ws`, `ws_bytes`);
+ * there is no hidden allocation and no global state except the optional profiler.
+ *
+ * Each entry point names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Coordinate conventions
+ *   4D (MotionNet / MinkowskiEngine side): coords int32 (n,4) [x,y,z,t] in units of the finest
+ *     voxel, rows in ascending key order, key = (t+32768)<<48 | morton3(x+32768,y+32768,z+32768).
+ *   3D (UNetV2 / spconv side): coords int32 (n,4) [b=0,z,y,x] (spconv's indices layout), keys are
+ *     linear (z*H + y)*W + x in the level's spatial shape [D,H,W].
+ * Feature matrices are row-major fp32 with an explicit leading dimension (`ld_*`, in floats) so that
+ * channel concatenation is free: producers write into column slices of a wider row.
+ */
+#ifndef INSMOS_HIP_H
+#define INSMOS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INSMOS_OK 0
+#define INSMOS_EINVAL (-1)    /* bad argument */
+#define INSMOS_EHIP (-2)      /* a HIP runtime call failed; see insmos_last_hip_error() */
+#define INSMOS_EWORKSPACE (-3) /* workspace too small */
+
+int insmos_version(void);
+int insmos_last_hip_error(void);
+
+/* ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ---- */
+int insmos_prof_enable(int on);
+int insmos_prof_reset(void);
+/* Synchronises, then writes up to `max` entries; returns the number of kernel kinds. */
+int insmos_prof_read(int max, int* kind_ids_host, double* total_ms_host, int64_t* launches_host);
+const char* insmos_prof_name(int kind_id);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_quantize4d -- replaces ME.utils.sparse_collate + ME.TensorField(...).sparse() as called
+ * at models/backbones_3d/motionnet.py:22-36, plus the t==0 row selection of :42-45.
+ *   points (n,ld_pts) fp32 rows [x,y,z,intensity,t]; quant[4] = [ds,ds,ds,dt] (host values).
+ *   coords = floor(fp32 [x,y,z,t] / fp32 quant) (IEEE division), unique, canonical key order.
+ * Outputs: keys (cap n) u64, coords (cap n,4) i32, inverse (n) i32 point->voxel row,
+ *          cur_index (cap n) i32: ascending point indices whose quantised t == 0,
+ *          counts[0] = #voxels, counts[1] = #current points, counts[2] = #points outside the
+ *          +-32768-voxel key window (must be 0).
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_quantize4d_ws_bytes(int64_t n);
+int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
+                      int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_level_down4d -- the coordinate map MinkowskiConvolution(kernel [2,2,2,1], stride [2,2,2,1])
+ * creates (models/MinkowskiEngine/minkunet.py:63-89): floor(c / 2s) * 2s in x,y,z, t untouched.
+ * Because keys are Morton-in-space this is a prefix de-duplication of the sorted key array.
+ *   shift = log2 of the OUTPUT tensor stride (1,2,3).  parent (n) i32 = fine row -> coarse row.
+ *   counts[0] = #coarse voxels.
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_level_down4d_ws_bytes(int64_t n);
+int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,
+                        int32_t* parent, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_build_nbr -- the kernel map / indice pairs ("rulebook") in output-stationary form:
+ *   nbr[k*n_out + o] = input row read by output o through tap k, or -1.
+ * Query coordinate per (o,k):  q = out_coords[o]*mul + delta[k];  if div>1: require q % div == 0,
+ * q /= div  (component-wise over the 4 coordinate slots; slot meaning per key_mode).
+ * Replaces: ME kernel maps behind MinkowskiConvolution / MinkowskiConvolutionTranspose
+ * (minkunet.py:55-124) and spconv's indice-pair generation behind SubMConv3d / SparseConv3d /
+ * SparseInverseConv3d (models/backbones_3d/spconv_unet.py:120-207).
+ *   key_mode 0: 4D Morton keys, coords [x,y,z,t];  key_mode 1: 3D linear keys, coords [b,z,y,x],
+ *   in_shape_host = [D,H,W] of the INPUT level.
+ *   in_keys ascending (n_in); in_perm (n_in) maps sorted position -> input row (NULL = identity;
+ *   an entry of -1 marks a voxel dropped by the max-voxel cap).
+ *   delta_host (K,4) i32, mul_host[4], div_host[4] are HOST arrays (tiny, copied by value).
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_perm,
+                     int64_t n_in, int key_mode, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                     const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_voxelize_mean -- replaces spconv PointToVoxel.generate_voxel_with_id
+ * (models/backbones_3d/voxel_generate.py:19-28) fused with MeanVFE (models/backbones_2d/mean_vfe.py:47-52).
+ * Deterministic restatement of the CPU semantics: first-come voxel ids (cap max_voxels), first
+ * max_pts points of each voxel averaged, pc_voxel_id = -1 for dropped / out-of-range points.
+ *   points (n,ld_pts) fp32, first 3 columns x,y,z, first n_feat columns are the features (<= 8).
+ *   range_host[6] = [x0,y0,z0,x1,y1,z1], vsize_host[3].  Grid = round((hi-lo)/vsize) per axis.
+ * Outputs: feat (cap,ld_feat) fp32 (columns >= n_feat zeroed), coords (cap,4) [0,z,y,x],
+ *          num_points (cap) i32, pc_voxel_id (n) i64, and the level-1 search structure
+ *          ukeys (cap_seg) u64 ascending linear keys + uperm (cap_seg) i32 (voxel row or -1).
+ *          counts[0] = #voxels kept, counts[1] = #distinct occupied cells (= len of ukeys),
+ *          counts[2] = #points in range.     cap = max_voxels rows, cap_seg = n rows.
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_voxelize_mean_ws_bytes(int64_t n);
+int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, int n_feat, const float* range_host,
+                         const float* vsize_host, int max_voxels, int max_pts, float* feat, int ld_feat,
+                         int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
+                         int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_down_coords3d -- output coordinate set of spconv.SparseConv3d(kernel, stride, padding)
+ * (spconv_unet.py:135-160: k3 s2 p1 x3, (3,1,1) s(2,1,1) p0): o active iff some tap reads an active
+ * input (i = o*stride - pad + k), 0 <= o < out_shape.  Canonical order: ascending linear index.
+ *   out_keys/out_coords capacity = min(n_in*K, prod(out_shape)) rows; counts[0] = #outputs.
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_down_coords3d_ws_bytes(int64_t n_in, int K);
+int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
+                         const int32_t* stride_host, const int32_t* pad_host, const int32_t* out_shape_host,
+                         uint64_t* out_keys, int32_t* out_coords, int32_t* counts, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_sparse_conv -- gather -> MFMA (v_mfma_f32_16x16x4_f32, exact fp32) -> fused epilogue.
+ *   out[o, 0:cout] = epi( sum_k in[nbr[k][o], 0:cin] @ W[k] + bias )
+ *   epi(v): if relu_pre v=max(v,0); if res_mode==1 v+=res[o,c]; if res_mode==2 v+=res[o,2c]+res[o,2c+1];
+ *           if relu_post v=max(v,0)
+ * Replaces the gather-GEMM-scatter inside MinkowskiConvolution(+Transpose) (minkunet.py:139-181),
+ * spconv SubMConv3d/SparseConv3d/SparseInverseConv3d (spconv_unet.py:297-402) with eval-mode
+ * BatchNorm folded into W/bias, ReLU, the residual adds of BasicBlock / SparseBasicBlock
+ * (spconv_unet.py:86-106) and UR_block's channel_reduction add (spconv_unet.py:213-238); with a
+ * full-grid nbr table it also serves the dense BEV convs (base_bev_backbone.py:33-61) and the 1x1
+ * heads (center_head.py:47-54) in NHWC.
+ *   nbr == NULL  -> K must be 1, identity map (1x1 conv / Linear).
+ *   cin must be a multiple of 4 (pad with zero columns); ld_in % 4 == 0 and `in` 16-byte aligned.
+ *   wpacked: tap-major MFMA-fragment layout produced by insmos_pack_weights_host (below).
+ *   bias: (cout_pad16) fp32.
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_packed_weight_floats(int K, int cin, int cout);
+/* Host helper: taps (K,cin_real,cout_real) fp32 row-major -> packed layout for (cin,cout) padded. */
+int insmos_pack_weights_host(const float* taps_host, int K, int cin_real, int cout_real, int cin, int cout,
+                             float* packed_host);
+int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, int K, int64_t n_out,
+                       const float* wpacked, const float* bias, float* out, int ld_out, int cout,
+                       const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_dense_nbr2d -- full-grid 3x3 (pad 1) neighbour table for an H x W NHWC map, so that the
+ * BEV Conv2d layers (base_bev_backbone.py:33-47; ZeroPad2d(1)+pad 0 == pad 1) run on insmos_sparse_conv.
+ *   nbr (9, H*W) i32, tap = ky*3 + kx reads (y+ky-1, x+kx-1).
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_dense_nbr2d(int H, int W, int32_t* nbr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_sparse_to_bev -- replaces SparseConvTensor.dense() + HeightCompression view
+ * (models/backbones_2d/height_compression.py:24-31) in NHWC: bev[(y*W+x), c*D+d] = feat[i,c] for
+ * coords[i] = [0,d,y,x]; bev (H*W, C*D) is zero-filled first.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_sparse_to_bev(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D, int H, int W,
+                         float* bev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_center_decode_select -- CenterHead.generate_predicted_boxes (center_head.py:251-276) +
+ * the class-agnostic candidate selection of post_processing (models/post_process.py:182-192, :5-15):
+ * sigmoid, max over classes (first max wins), score >= thresh, descending-score order (ties: ascending
+ * cell index), at most pre_max candidates.
+ *   head (n_cells, ld_head) fp32 rows [cls(ncls) | box(8)] in the deconv's [y][x][ky][kx] sub-site
+ *   order: row r -> map row 2*(r/4/W0)+((r%4)/2), col 2*((r/4)%W0)+(r%2), W0 = half-resolution width.
+ *   (up == 1: rows are already [row][col] over H x W.)
+ * Outputs: cand_boxes (pre_max,7), cand_scores (pre_max), cand_labels (pre_max) i32 in {1..ncls},
+ *          cand_cell (pre_max) i32 canonical cell index row*W+col; counts[0] = #candidates.
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_center_decode_select_ws_bytes(int64_t n_cells);
+int insmos_center_decode_select(const float* head, int ld_head, int ncls, int H, int W, int up, float out_factor,
+                                float vx, float vy, float x0, float y0, float score_thresh, int pre_max,
+                                float* cand_boxes, float* cand_scores, int32_t* cand_labels, int32_t* cand_cell,
+                                int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_nms_rotated_bev -- replaces iou3d_nms_cuda.nms_gpu (models/bbox_post_process/src/
+ * iou3d_nms.cpp:90-136 + nms_kernel iou3d_nms_kernel.cu:267-311): 64x64-block bitmask of
+ * rotated-BEV IoU > thresh, then the greedy reduce ON DEVICE (no D2H of the mask).
+ *   boxes (n_dev[0],7) sorted by descending score, n_dev: device count (<= max_n).
+ *   keep (post_max) i32 ascending indices; counts[0] = #kept (<= post_max).
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_nms_ws_bytes(int max_n);
+int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, int max_n, float thresh, int post_max,
+                           int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* pairwise rotated BEV IoU (a: na x 7, b: nb x 7) -> out (na, nb); parity probe for the predicate. */
+int insmos_iou_bev(const float* a, int na, const float* b, int nb, float* out, void* stream);
+
+/* Gather the kept candidates into the final prediction arrays (post_process.py:204-216):
+ * pred_boxes (post_max,7) fp32, pred_scores (post_max) fp32, pred_labels (post_max) i64. */
+int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                        const int32_t* keep, const int32_t* n_keep_dev, int post_max, float* pred_boxes,
+                        float* pred_scores, int64_t* pred_labels, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_boxes_to_onehot -- replaces Array_Index.find_features_by_bbox_with_yaw
+ * (models/utils/src/Array_Index.cpp:14-79) and the box rescaling at its 4 call sites
+ * (spconv_unet.py:322-331,358,373,388), without the 4 host round trips.
+ *   pred_boxes (m,7) metric boxes, pred_labels (m) i64, n_boxes_dev device count.
+ *   Box in voxel units of this level: centre = (c - range_lo) * (1/vsize) * (1/stride) * mult, size
+ *   likewise (fp32, same operation order as the reference's torch ops; mult = 1,2,4,8).
+ *   coords (n,4) [b,z,y,x] int voxel indices of the level; the test uses the integer index (no +0.5).
+ *   quirk_exact != 0 reproduces the order-dependent early-skip of Array_Index.cpp:48-51.
+ *   onehot: fp32 written into out[i*ld_out + c], c < ncls (+ zero pad up to pad_to columns).
+ *   scratch: (16*max_boxes) i32 device scratch (per-box first-hit voxel + box in voxel units).
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                           int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
+                           float mult, const int32_t* coords, int64_t n, int ncls, int pad_to, int quirk_exact,
+                           float* out, int ld_out, int32_t* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row gathers.
+ * insmos_gather_rows: out[i,0:c] = idx[i] >= 0 ? src[idx[i],0:c] : 0   (idx i64)  -- replaces
+ *   spconv gather_features_by_pc_voxel_id (spconv_unet.py:410).
+ * insmos_build_current_points: cur[j] = [x,y,z,r | motion[inverse[p],0:3]] for p = cur_index[j]
+ *   -- replaces predicted_sparse_tensor.slice(tensor_field) + the hstack of motionnet.py:38-48.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_gather_rows(const float* src, int ld_src, int c, const int64_t* idx, int64_t n, float* out, int ld_out,
+                       void* stream);
+int insmos_build_current_points(const float* points, int ld_pts, const float* motion, int ld_motion,
+                                const int32_t* inverse, const int32_t* cur_index, int64_t n_cur, float* cur,
+                                int ld_cur, void* stream);
+/* fill rows: dst[i*ld + c0 .. c0+c) = value  (constant input features 0.5, motionnet.py:29-32) */
+int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, float value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * insmos_confusion3 -- ClassificationMetrics.compute_confusion_matrix (models/metrics.py:16-30):
+ * ignored class columns of the logits are treated as -inf, argmax (first max), cm[pred, gt] += 1.
+ *   cm (ncls*ncls) i64 is ACCUMULATED into (zero it once per evaluation).  ignore_mask bit c set =>
+ *   class c ignored.  gt i64.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_confusion3(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
+                      int64_t* cm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

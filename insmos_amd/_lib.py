@@ -1,0 +1,84 @@
+"""ctypes binding of libinsmos_hip.so (include/insmos_hip.h).  There is NO fallback: if the HIP library
+is missing or a call fails, this raises -- the product path never routes through oracle/ or any CPU
+implementation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinsmos_hip.so")
+
+c_vp, c_i64, c_int, c_f32, c_sz, c_u32 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                          ctypes.c_size_t, ctypes.c_uint)
+
+# name -> (restype, argtypes); mirrors include/insmos_hip.h exactly
+SIGNATURES = {
+    "insmos_version": (c_int, []),
+    "insmos_last_hip_error": (c_int, []),
+    "insmos_prof_enable": (c_int, [c_int]),
+    "insmos_prof_reset": (c_int, []),
+    "insmos_prof_read": (c_int, [c_int, c_vp, c_vp, c_vp]),
+    "insmos_prof_name": (ctypes.c_char_p, [c_int]),
+    "insmos_quantize4d_ws_bytes": (c_sz, [c_i64]),
+    "insmos_quantize4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_level_down4d_ws_bytes": (c_sz, [c_i64]),
+    "insmos_level_down4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_build_nbr": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_voxelize_mean_ws_bytes": (c_sz, [c_i64]),
+    "insmos_voxelize_mean": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp,
+                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_down_coords3d_ws_bytes": (c_sz, [c_i64, c_int]),
+    "insmos_down_coords3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_packed_weight_floats": (c_sz, [c_int, c_int, c_int]),
+    "insmos_pack_weights_host": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "insmos_sparse_conv": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
+                                   c_int, c_int, c_int, c_int, c_vp]),
+    "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),
+    "insmos_sparse_to_bev": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
+    "insmos_center_decode_select_ws_bytes": (c_sz, [c_i64]),
+    "insmos_center_decode_select": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32,
+                                            c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_nms_ws_bytes": (c_sz, [c_int]),
+    "insmos_nms_rotated_bev": (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_iou_bev": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_gather_preds": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_boxes_to_onehot": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
+                                       c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_gather_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "insmos_build_current_points": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "insmos_fill_cols": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_f32, c_vp]),
+    "insmos_confusion3": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class InsmosHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libinsmos_hip.so (built by __graft_entry__.build()).  Raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise InsmosHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  insmos_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+_ERR = {-1: "INSMOS_EINVAL (bad argument)", -2: "INSMOS_EHIP (HIP runtime error)", -3: "INSMOS_EWORKSPACE"}
+
+
+def check(rc, what):
+    if rc != 0:
+        extra = ""
+        if rc == -2:
+            extra = f", hipError={load().insmos_last_hip_error()}"
+        raise InsmosHipError(f"{what} failed: {_ERR.get(rc, rc)}{extra}")

@@ -1,0 +1,116 @@
+// insmos_amd/csrc/common.h -- shared host/device helpers of libinsmos_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/insmos_hip.h"
+
+namespace insmos {
+
+// ---- error plumbing -------------------------------------------------------------------------------
+extern int g_last_hip_error;
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) {                         \
+            insmos::g_last_hip_error = (int)_e;         \
+            return INSMOS_EHIP;                         \
+        }                                               \
+    } while (0)
+
+// ---- per-kernel profiler (HIP events on the launch stream) ----------------------------------------
+enum KernelKind : int {
+    KK_QUANT_KEYS = 0, KK_SORT, KK_SCAN, KK_QUANT_SCATTER, KK_LEVEL_DOWN, KK_BUILD_NBR, KK_VOX_KEYS,
+    KK_VOX_SEGMENTS, KK_VOX_MEAN, KK_DOWN_CAND, KK_DOWN_UNIQUE, KK_SPARSE_CONV, KK_DENSE_NBR, KK_TO_BEV,
+    KK_DECODE, KK_SELECT, KK_NMS_MASK, KK_NMS_REDUCE, KK_IOU, KK_GATHER_PREDS, KK_ONEHOT, KK_GATHER_ROWS,
+    KK_CUR_POINTS, KK_FILL, KK_CONFUSION, KK_MEMSET, KK_COUNT
+};
+struct ProfScope {
+    int kind;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(int kind, hipStream_t s);
+    ~ProfScope();
+};
+bool prof_on();
+
+// ---- workspace bump allocator ------------------------------------------------------------------------
+struct Bump {
+    char* base;
+    size_t cap, off = 0;
+    bool ok = true;
+    Bump(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+    template <class T>
+    T* take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) { ok = false; return nullptr; }
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// rocPRIM wrappers (coords.hip): sizes in bytes of the temp storage they need
+size_t sort_pairs_u64_u32_temp(size_t n);
+size_t sort_keys_u64_temp(size_t n);
+size_t scan_i32_temp(size_t n);
+int sort_pairs_u64_u32(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                       uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+int sort_keys_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit,
+                  int end_bit, hipStream_t s);
+int inclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t s);
+
+// ---- keys -------------------------------------------------------------------------------------------
+#define INSMOS_KEY_BIAS 32768
+#define INSMOS_INVALID_KEY 0xFFFFFFFFFFFFFFFFull
+
+__host__ __device__ __forceinline__ uint64_t spread3(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__host__ __device__ __forceinline__ uint32_t compact3(uint64_t v) {
+    v &= 0x1249249249249249ull;
+    v = (v ^ (v >> 2)) & 0x10C30C30C30C30C3ull;
+    v = (v ^ (v >> 4)) & 0x100F00F00F00F00Full;
+    v = (v ^ (v >> 8)) & 0x1F0000FF0000FFull;
+    v = (v ^ (v >> 16)) & 0x1F00000000FFFFull;
+    v = (v ^ (v >> 32)) & 0x1FFFFFull;
+    return (uint32_t)v;
+}
+// coords [x,y,z,t] (finest-voxel units) -> key; INVALID if outside the +-32768 window
+__host__ __device__ __forceinline__ uint64_t key4_encode(int x, int y, int z, int t) {
+    int bx = x + INSMOS_KEY_BIAS, by = y + INSMOS_KEY_BIAS, bz = z + INSMOS_KEY_BIAS, bt = t + INSMOS_KEY_BIAS;
+    if (((unsigned)bx | (unsigned)by | (unsigned)bz | (unsigned)bt) & 0xFFFF0000u) return INSMOS_INVALID_KEY;
+    return ((uint64_t)bt << 48) | spread3((uint64_t)bx) | (spread3((uint64_t)by) << 1) | (spread3((uint64_t)bz) << 2);
+}
+__host__ __device__ __forceinline__ void key4_decode(uint64_t k, int& x, int& y, int& z, int& t) {
+    t = (int)(k >> 48) - INSMOS_KEY_BIAS;
+    uint64_t m = k & 0xFFFFFFFFFFFFull;
+    x = (int)compact3(m) - INSMOS_KEY_BIAS;
+    y = (int)compact3(m >> 1) - INSMOS_KEY_BIAS;
+    z = (int)compact3(m >> 2) - INSMOS_KEY_BIAS;
+}
+__host__ __device__ __forceinline__ uint64_t key3_encode(int z, int y, int x, int D, int H, int W) {
+    if ((unsigned)z >= (unsigned)D || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return INSMOS_INVALID_KEY;
+    return ((uint64_t)z * (uint64_t)H + (uint64_t)y) * (uint64_t)W + (uint64_t)x;
+}
+
+// lower-bound binary search; returns position or -1
+__device__ __forceinline__ int64_t find_key(const uint64_t* __restrict__ keys, int64_t n, uint64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && keys[lo] == key) ? lo : -1;
+}
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace insmos

@@ -1,0 +1,541 @@
+// insmos_amd/csrc/coords.hip -- coordinate-set kernels: 4D quantise/de-dup, strided levels, 3D hard
+// voxelisation + mean VFE, strided-conv output sets, and the output-stationary neighbour tables.
+//
+// Design (MI355X-first): no hash tables.  Every coordinate set is a radix-sorted array
+// of 64-bit keys; de-duplication is an adjacent-difference + prefix sum over the sorted array (wide
+// coalesced streams), strided 4D levels fall out of the Morton key by a shift, and kernel maps are
+// binary searches over the sorted keys whose upper levels stay in L2.  Radix sort and prefix scan are
+// rocPRIM device primitives (commodity building blocks); everything domain-specific is hand-written.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include "common.h"
+
+namespace insmos {
+
+// ---------------------------------------------------------------------------------------------------
+// rocPRIM wrappers
+// ---------------------------------------------------------------------------------------------------
+size_t sort_pairs_u64_u32_temp(size_t n) {
+    size_t b = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0);
+    return pad256(b);
+}
+size_t sort_keys_u64_temp(size_t n) {
+    size_t b = 0;
+    (void)rocprim::radix_sort_keys(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, n, 0, 64, (hipStream_t)0);
+    return pad256(b);
+}
+size_t scan_i32_temp(size_t n) {
+    size_t b = 0;
+    (void)rocprim::inclusive_scan(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, n, rocprim::plus<int32_t>(),
+                                  (hipStream_t)0);
+    return pad256(b);
+}
+int sort_pairs_u64_u32(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                       uint32_t* vout, size_t n, int b0, int b1, hipStream_t s) {
+    ProfScope ps(KK_SORT, s);
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, (unsigned)b0, (unsigned)b1, s));
+    return INSMOS_OK;
+}
+int sort_keys_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, int b0, int b1,
+                  hipStream_t s) {
+    ProfScope ps(KK_SORT, s);
+    HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, (unsigned)b0, (unsigned)b1, s));
+    return INSMOS_OK;
+}
+int inclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t s) {
+    ProfScope ps(KK_SCAN, s);
+    HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::plus<int32_t>(), s));
+    return INSMOS_OK;
+}
+
+static inline int bits_for(uint64_t maxval) {
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 4D quantise (motionnet.py:22-36)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_quant_keys(const float* __restrict__ pts, int64_t n, int ld, float q0, float q1, float q2, float q3,
+                             uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int32_t* __restrict__ tflag,
+                             int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + i * ld;
+    // IEEE fp32 division then floor -- exactly torch.div(point_cloud, quantization) + ME's floor
+    float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;
+    uint64_t k = key4_encode((int)floorf(fx), (int)floorf(fy), (int)floorf(fz), (int)floorf(ft));
+    if (k == INSMOS_INVALID_KEY) atomicAdd(&counts[2], 1);
+    keys[i] = k;
+    idx[i] = (uint32_t)i;
+    tflag[i] = (ft == 0.0f) ? 1 : 0;
+}
+
+__global__ void k_head_flags(const uint64_t* __restrict__ keys, int64_t n, int shift_bits, int32_t* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys[i];
+    int f = 0;
+    if (k != INSMOS_INVALID_KEY) f = (i == 0) || ((k >> shift_bits) != (keys[i - 1] >> shift_bits));
+    flag[i] = f;
+}
+
+__global__ void k_quant_scatter(const uint64_t* __restrict__ keys_s, const uint32_t* __restrict__ idx_s,
+                                const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, int64_t n,
+                                uint64_t* __restrict__ vkeys, int32_t* __restrict__ vcoords,
+                                int32_t* __restrict__ inverse, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys_s[i];
+    int vid = scan[i] - 1;
+    if (k != INSMOS_INVALID_KEY) {
+        if (flag[i]) {
+            vkeys[vid] = k;
+            int x, y, z, t;
+            key4_decode(k, x, y, z, t);
+            *(int4*)(vcoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
+        }
+        inverse[idx_s[i]] = vid;
+    } else {
+        inverse[idx_s[i]] = -1;
+    }
+    if (i == n - 1) counts[0] = scan[i];
+}
+
+__global__ void k_compact_index(const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, int64_t n,
+                                int32_t* __restrict__ out_idx, int32_t* __restrict__ count_slot) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) out_idx[scan[i] - 1] = (int32_t)i;
+    if (i == n - 1) *count_slot = scan[i];
+}
+
+__global__ void k_level_down_scatter(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flag,
+                                     const int32_t* __restrict__ scan, int64_t n, int shift_bits,
+                                     uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                                     int32_t* __restrict__ parent, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int vid = scan[i] - 1;
+    if (flag[i]) {
+        uint64_t k = (keys[i] >> shift_bits) << shift_bits;
+        okeys[vid] = k;
+        int x, y, z, t;
+        key4_decode(k, x, y, z, t);
+        *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
+    }
+    parent[i] = vid;
+    if (i == n - 1) counts[0] = scan[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// neighbour tables
+// ---------------------------------------------------------------------------------------------------
+struct NbrParams {
+    int delta[128][4];
+    int mul[4];
+    int dv[4];
+    int shape[3];
+    int K;
+};
+
+template <int KEY_MODE>
+__global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                   const uint64_t* __restrict__ in_keys,
+                                                   const int32_t* __restrict__ in_perm, int64_t n_in, NbrParams P,
+                                                   int32_t* __restrict__ nbr) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (o >= n_out) return;
+    int4 c = *(const int4*)(out_coords + o * 4);
+    int q[4] = {c.x * P.mul[0] + P.delta[k][0], c.y * P.mul[1] + P.delta[k][1], c.z * P.mul[2] + P.delta[k][2],
+                c.w * P.mul[3] + P.delta[k][3]};
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int dv = P.dv[d];
+        if (dv > 1) {
+            // exact divisibility (floor semantics irrelevant once divisible)
+            if (q[d] % dv != 0) ok = false;
+            q[d] = q[d] / dv;
+        }
+    }
+    int32_t r = -1;
+    if (ok) {
+        uint64_t key = (KEY_MODE == 0) ? key4_encode(q[0], q[1], q[2], q[3])
+                                       : key3_encode(q[1], q[2], q[3], P.shape[0], P.shape[1], P.shape[2]);
+        if (key != INSMOS_INVALID_KEY) {
+            int64_t pos = find_key(in_keys, n_in, key);
+            if (pos >= 0) r = in_perm ? in_perm[pos] : (int32_t)pos;
+        }
+    }
+    nbr[(int64_t)k * n_out + o] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3D hard voxelisation + mean VFE (voxel_generate.py:19-28, mean_vfe.py:47-52)
+// ---------------------------------------------------------------------------------------------------
+#define VOX_IDX_BITS 21
+
+__global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, float lx, float ly, float lz, float vx,
+                           float vy, float vz, int gx, int gy, int gz, uint64_t* __restrict__ keys,
+                           int64_t* __restrict__ pcid, int32_t* __restrict__ mark, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + i * ld;
+    // spconv point-to-voxel: c = floor((p - lo) / vsize) in fp32, keep iff 0 <= c < grid
+    float cx = floorf((p[0] - lx) / vx), cy = floorf((p[1] - ly) / vy), cz = floorf((p[2] - lz) / vz);
+    bool in = cx >= 0.f && cx < (float)gx && cy >= 0.f && cy < (float)gy && cz >= 0.f && cz < (float)gz;
+    uint64_t k = INSMOS_INVALID_KEY;
+    if (in) {
+        uint64_t lin = ((uint64_t)(int)cz * (uint64_t)gy + (uint64_t)(int)cy) * (uint64_t)gx + (uint64_t)(int)cx;
+        k = (lin << VOX_IDX_BITS) | (uint64_t)i;
+        atomicAdd(&counts[2], 1);
+    }
+    keys[i] = k;
+    pcid[i] = -1;
+    mark[i] = 0;
+}
+
+__global__ void k_vox_heads(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ flag,
+                            const int32_t* __restrict__ scan, int64_t n, int32_t* __restrict__ seg_start,
+                            int32_t* __restrict__ seg_first, int32_t* __restrict__ mark) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        int sid = scan[i] - 1;
+        int p = (int)(keys_s[i] & ((1ull << VOX_IDX_BITS) - 1));
+        seg_start[sid] = (int32_t)i;
+        seg_first[sid] = p;
+        mark[p] = 1;
+    }
+}
+
+__global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat, const uint64_t* __restrict__ keys_s,
+                               const int32_t* __restrict__ sid_scan, int64_t n, const int32_t* __restrict__ seg_start,
+                               const int32_t* __restrict__ seg_first, const int32_t* __restrict__ rank_scan,
+                               int gx, int gy, int max_voxels, int max_pts, float* __restrict__ feat, int ld_feat,
+                               int32_t* __restrict__ coords, int32_t* __restrict__ num_points,
+                               int64_t* __restrict__ pcid, uint64_t* __restrict__ ukeys, int32_t* __restrict__ uperm,
+                               int32_t* __restrict__ counts) {
+    int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int S = sid_scan[n - 1];
+    int n_valid = counts[2];
+    if (sid == 0) {
+        counts[0] = S < max_voxels ? S : max_voxels;
+        counts[1] = S;
+    }
+    if (sid >= S) return;
+    int start = seg_start[sid];
+    int end = (sid + 1 < S) ? seg_start[sid + 1] : n_valid;
+    int vid = rank_scan[seg_first[sid]] - 1;  // first-come order
+    uint64_t lin = keys_s[start] >> VOX_IDX_BITS;
+    ukeys[sid] = lin;
+    bool kept = vid < max_voxels;
+    uperm[sid] = kept ? vid : -1;
+    if (kept) {
+        int x = (int)(lin % (uint64_t)gx);
+        int y = (int)((lin / (uint64_t)gx) % (uint64_t)gy);
+        int z = (int)(lin / ((uint64_t)gx * (uint64_t)gy));
+        *(int4*)(coords + (int64_t)vid * 4) = make_int4(0, z, y, x);
+        int cnt = end - start;
+        int m = cnt < max_pts ? cnt : max_pts;
+        num_points[vid] = m;
+        float acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[f] = 0.f;
+        for (int j = 0; j < m; ++j) {  // first max_pts points in point order (keys sort by point index inside a cell)
+            int p = (int)(keys_s[start + j] & ((1ull << VOX_IDX_BITS) - 1));
+            const float* pp = pts + (int64_t)p * ld;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+                if (f < n_feat) acc[f] += pp[f];
+        }
+        float norm = (float)(m < 1 ? 1 : m);
+        float* fo = feat + (int64_t)vid * ld_feat;
+        for (int f = 0; f < ld_feat; ++f) fo[f] = (f < n_feat && f < 8) ? acc[f] / norm : 0.f;
+    }
+    for (int j = start; j < end; ++j) {
+        int p = (int)(keys_s[j] & ((1ull << VOX_IDX_BITS) - 1));
+        pcid[p] = kept ? (int64_t)vid : (int64_t)-1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// strided SparseConv3d output coordinate set
+// ---------------------------------------------------------------------------------------------------
+struct DownParams { int ks[3], st[3], pd[3], oshape[3]; };
+
+__global__ void k_down_candidates(const int32_t* __restrict__ in_coords, int64_t n_in, int K, DownParams P,
+                                  uint64_t* __restrict__ cand) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_in * K) return;
+    int64_t i = t / K;
+    int k = (int)(t % K);
+    int kx = k % P.ks[2], ky = (k / P.ks[2]) % P.ks[1], kz = k / (P.ks[2] * P.ks[1]);
+    int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
+    int nz = c.y + P.pd[0] - kz, ny = c.z + P.pd[1] - ky, nx = c.w + P.pd[2] - kx;
+    uint64_t key = INSMOS_INVALID_KEY;
+    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % P.st[0] == 0 && ny % P.st[1] == 0 && nx % P.st[2] == 0)
+        key = key3_encode(nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
+    cand[t] = key;
+}
+
+__global__ void k_down_scatter(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ flag,
+                               const int32_t* __restrict__ scan, int64_t n, int H, int W, int64_t cap,
+                               uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                               int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        int vid = scan[i] - 1;
+        if (vid < cap) {
+            uint64_t k = keys_s[i];
+            okeys[vid] = k;
+            int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(k / ((uint64_t)W * H));
+            *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(0, z, y, x);
+        }
+    }
+    if (i == n - 1) counts[0] = scan[i];
+}
+
+}  // namespace insmos
+
+using namespace insmos;
+static const int TPB = 256;
+
+// ===================================================================================================
+extern "C" size_t insmos_quantize4d_ws_bytes(int64_t n) {
+    size_t N = (size_t)n;
+    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N);
+    return pad256(N * 8) * 2 + pad256(N * 4) * 6 + (st > sc ? st : sc) + 1024;
+}
+
+extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
+                                 int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (n <= 0 || ld_pts < 5 || !points || !quant_host) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    size_t N = (size_t)n;
+    uint64_t* k_in = b.take<uint64_t>(N);
+    uint64_t* k_s = b.take<uint64_t>(N);
+    uint32_t* i_in = b.take<uint32_t>(N);
+    uint32_t* i_s = b.take<uint32_t>(N);
+    int32_t* flag = b.take<int32_t>(N);
+    int32_t* scan = b.take<int32_t>(N);
+    int32_t* tflag = b.take<int32_t>(N);
+    int32_t* tscan = b.take<int32_t>(N);
+    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N);
+    size_t tb = st > sc ? st : sc;
+    char* tmp = b.take<char>(tb);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+    unsigned g = cdiv(n, TPB);
+    {
+        ProfScope ps(KK_QUANT_KEYS, s);
+        hipLaunchKernelGGL(k_quant_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+                           quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
+    }
+    int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, 64, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
+    }
+    rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        hipLaunchKernelGGL(k_quant_scatter, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
+                           counts);
+    }
+    rc = inclusive_scan_i32(tmp, sc, tflag, tscan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        hipLaunchKernelGGL(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_level_down4d_ws_bytes(int64_t n) {
+    return pad256((size_t)n * 4) * 2 + scan_i32_temp((size_t)n) + 1024;
+}
+
+extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,
+                                   int32_t* parent, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (n <= 0 || shift < 1 || shift > 15) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    int32_t* flag = b.take<int32_t>((size_t)n);
+    int32_t* scan = b.take<int32_t>((size_t)n);
+    size_t sc = scan_i32_temp((size_t)n);
+    char* tmp = b.take<char>(sc);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    unsigned g = cdiv(n, TPB);
+    {
+        ProfScope ps(KK_LEVEL_DOWN, s);
+        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, keys, n, 3 * shift, flag);
+    }
+    int rc = inclusive_scan_i32(tmp, sc, flag, scan, (size_t)n, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_LEVEL_DOWN, s);
+        hipLaunchKernelGGL(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
+                           out_coords, parent, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys,
+                                const int32_t* in_perm, int64_t n_in, int key_mode, const int32_t* in_shape_host,
+                                const int32_t* delta_host, int K, const int32_t* mul_host, const int32_t* div_host,
+                                int32_t* nbr, void* stream) {
+    if (n_out <= 0 || K <= 0 || K > 128 || n_in < 0 || (key_mode != 0 && key_mode != 1)) return INSMOS_EINVAL;
+    if (key_mode == 1 && !in_shape_host) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    NbrParams P;
+    memset(&P, 0, sizeof(P));
+    for (int k = 0; k < K; ++k)
+        for (int d = 0; d < 4; ++d) P.delta[k][d] = delta_host[k * 4 + d];
+    for (int d = 0; d < 4; ++d) {
+        P.mul[d] = mul_host ? mul_host[d] : 1;
+        P.dv[d] = div_host ? div_host[d] : 1;
+    }
+    if (in_shape_host)
+        for (int d = 0; d < 3; ++d) P.shape[d] = in_shape_host[d];
+    P.K = K;
+    dim3 grid(cdiv(n_out, TPB), (unsigned)K);
+    ProfScope ps(KK_BUILD_NBR, s);
+    if (key_mode == 0)
+        hipLaunchKernelGGL(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr);
+    else
+        hipLaunchKernelGGL(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_voxelize_mean_ws_bytes(int64_t n) {
+    size_t N = (size_t)n;
+    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    return pad256(N * 8) * 2 + pad256((N + 1) * 4) * 6 + (st > sc ? st : sc) + 1024;
+}
+
+extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, int n_feat, const float* range_host,
+                                    const float* vsize_host, int max_voxels, int max_pts, float* feat, int ld_feat,
+                                    int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
+                                    int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (n <= 0 || n >= (1ll << VOX_IDX_BITS) || n_feat < 3 || n_feat > 8 || ld_pts < n_feat || ld_feat < n_feat ||
+        max_voxels <= 0 || max_pts <= 0)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // grid = round((hi - lo) / vsize), as models.py:281-282 / spconv compute it (float64 on the host)
+    int g3[3];
+    for (int d = 0; d < 3; ++d)
+        g3[d] = (int)llround(((double)range_host[3 + d] - (double)range_host[d]) / (double)vsize_host[d]);
+    uint64_t max_lin = (uint64_t)g3[0] * g3[1] * g3[2];
+    int end_bit = VOX_IDX_BITS + bits_for(max_lin);
+    if (end_bit > 63) return INSMOS_EINVAL;
+    Bump b(ws, ws_bytes);
+    size_t N = (size_t)n;
+    uint64_t* k_in = b.take<uint64_t>(N);
+    uint64_t* k_s = b.take<uint64_t>(N);
+    int32_t* flag = b.take<int32_t>(N + 1);
+    int32_t* sid_scan = b.take<int32_t>(N + 1);
+    int32_t* mark = b.take<int32_t>(N + 1);
+    int32_t* rank_scan = b.take<int32_t>(N + 1);
+    int32_t* seg_start = b.take<int32_t>(N + 1);
+    int32_t* seg_first = b.take<int32_t>(N + 1);
+    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    char* tmp = b.take<char>(st > sc ? st : sc);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+    unsigned g = cdiv(n, TPB);
+    {
+        ProfScope ps(KK_VOX_KEYS, s);
+        hipLaunchKernelGGL(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, range_host[0], range_host[1],
+                           range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1], g3[2], k_in,
+                           pc_voxel_id, mark, counts);
+    }
+    // invalid keys are all-ones; they must sort last, so sort the full 64 bits when any may exist
+    int rc = sort_keys_u64(tmp, st, k_in, k_s, N, 0, 64, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_VOX_SEGMENTS, s);
+        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, VOX_IDX_BITS, flag);
+    }
+    rc = inclusive_scan_i32(tmp, sc, flag, sid_scan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_VOX_SEGMENTS, s);
+        hipLaunchKernelGGL(k_vox_heads, dim3(g), dim3(TPB), 0, s, k_s, flag, sid_scan, n, seg_start, seg_first, mark);
+    }
+    rc = inclusive_scan_i32(tmp, sc, mark, rank_scan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_VOX_MEAN, s);
+        hipLaunchKernelGGL(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
+                           seg_first, rank_scan, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords, num_points,
+                           pc_voxel_id, ukeys, uperm, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_down_coords3d_ws_bytes(int64_t n_in, int K) {
+    size_t N = (size_t)n_in * (size_t)K;
+    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    return pad256(N * 8) * 2 + pad256(N * 4) * 2 + (st > sc ? st : sc) + 1024;
+}
+
+extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
+                                    const int32_t* stride_host, const int32_t* pad_host,
+                                    const int32_t* out_shape_host, uint64_t* out_keys, int32_t* out_coords,
+                                    int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (n_in <= 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DownParams P;
+    int K = 1;
+    for (int d = 0; d < 3; ++d) {
+        P.ks[d] = ksize_host[d]; P.st[d] = stride_host[d]; P.pd[d] = pad_host[d]; P.oshape[d] = out_shape_host[d];
+        K *= ksize_host[d];
+    }
+    size_t N = (size_t)n_in * (size_t)K;
+    int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2];
+    int64_t cap = (int64_t)N < cells ? (int64_t)N : cells;
+    Bump b(ws, ws_bytes);
+    uint64_t* cand = b.take<uint64_t>(N);
+    uint64_t* cand_s = b.take<uint64_t>(N);
+    int32_t* flag = b.take<int32_t>(N);
+    int32_t* scan = b.take<int32_t>(N);
+    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    char* tmp = b.take<char>(st > sc ? st : sc);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    unsigned g = cdiv((int64_t)N, TPB);
+    {
+        ProfScope ps(KK_DOWN_CAND, s);
+        hipLaunchKernelGGL(k_down_candidates, dim3(g), dim3(TPB), 0, s, in_coords, n_in, K, P, cand);
+    }
+    int rc = sort_keys_u64(tmp, st, cand, cand_s, N, 0, 64, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_DOWN_UNIQUE, s);
+        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, cand_s, (int64_t)N, 0, flag);
+    }
+    rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_DOWN_UNIQUE, s);
+        hipLaunchKernelGGL(k_down_scatter, dim3(g), dim3(TPB), 0, s, cand_s, flag, scan, (int64_t)N, P.oshape[1],
+                           P.oshape[2], cap, out_keys, out_coords, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}

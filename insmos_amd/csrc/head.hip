@@ -1,0 +1,477 @@
+// insmos_amd/csrc/head.hip -- detection head post-processing on device: CenterHead box decode +
+// candidate selection, rotated-BEV NMS with an on-device greedy reduce, final gathers, and the
+// point-in-rotated-box instance features.  The whole library is compiled with -ffp-contract=off so
+// the fp32 expressions below evaluate exactly like the reference's separately-rounded torch / C ops.
+#include <cstring>
+#include "common.h"
+
+namespace insmos {
+
+// ---------------------------------------------------------------------------------------------------
+// CenterHead decode + class-agnostic candidate selection
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cell_of_row(int64_t r, int W, int up, int& row, int& col) {
+    if (up == 2) {
+        int W0 = W >> 1;
+        int64_t site = r >> 2;
+        int sub = (int)(r & 3);
+        row = 2 * (int)(site / W0) + (sub >> 1);
+        col = 2 * (int)(site % W0) + (sub & 1);
+    } else {
+        row = (int)(r / W);
+        col = (int)(r % W);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void k_score_keys(const float* __restrict__ head, int ld, int ncls, int64_t n_cells, int W, int up,
+                             float thresh, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                             int32_t* __restrict__ counts) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_cells) return;
+    const float* h = head + r * ld;
+    float best = sigmoidf_(h[0]);
+    for (int c = 1; c < ncls; ++c) {
+        float p = sigmoidf_(h[c]);
+        if (p > best) best = p;  // first max wins
+    }
+    uint64_t key = INSMOS_INVALID_KEY;
+    if (best >= thresh) {
+        int row, col;
+        cell_of_row(r, W, up, row, col);
+        uint32_t cell = (uint32_t)(row * W + col);
+        key = ((uint64_t)(0xFFFFFFFFu - __float_as_uint(best)) << 32) | cell;  // score desc, cell asc
+        atomicAdd(&counts[1], 1);
+    }
+    keys[r] = key;
+    vals[r] = (uint32_t)r;
+}
+
+__global__ void k_select_decode(const float* __restrict__ head, int ld, int ncls, int W, int up, float out_factor,
+                                float vx, float vy, float x0, float y0, const uint64_t* __restrict__ keys_s,
+                                const uint32_t* __restrict__ vals_s, int64_t n_cells, int pre_max,
+                                float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ labels,
+                                int32_t* __restrict__ cells, int32_t* __restrict__ counts) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) counts[0] = counts[1] < pre_max ? counts[1] : pre_max;
+    if (t >= pre_max) return;
+    bool valid = t < n_cells && keys_s[t] != INSMOS_INVALID_KEY;
+    float b7[7] = {0, 0, 0, 0, 0, 0, 0};
+    float sc = 0.f;
+    int lab = 0, cell = -1;
+    if (valid) {
+        int64_t r = vals_s[t];
+        const float* h = head + r * ld;
+        float best = sigmoidf_(h[0]);
+        int arg = 0;
+        for (int c = 1; c < ncls; ++c) {
+            float p = sigmoidf_(h[c]);
+            if (p > best) { best = p; arg = c; }
+        }
+        int row, col;
+        cell_of_row(r, W, up, row, col);
+        const float* bx = h + ncls;
+        // center_head.py:263-267: (idx + reg) * OUT_SIZE_FACTOR * VOXEL_SIZE + range, left to right in fp32
+        float xs = ((float)col + bx[0]) * out_factor * vx + x0;
+        float ys = ((float)row + bx[1]) * out_factor * vy + y0;
+        b7[0] = xs; b7[1] = ys; b7[2] = bx[2];
+        b7[3] = expf(bx[3]); b7[4] = expf(bx[4]); b7[5] = expf(bx[5]);
+        b7[6] = atan2f(bx[6], bx[7]);
+        sc = best; lab = arg + 1; cell = row * W + col;
+    }
+    for (int d = 0; d < 7; ++d) boxes[(int64_t)t * 7 + d] = b7[d];
+    scores[t] = sc;
+    labels[t] = lab;
+    cells[t] = cell;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rotated BEV IoU (restates iou3d_nms_kernel.cu:35-234; float trig overloads as in the CUDA device code)
+// ---------------------------------------------------------------------------------------------------
+struct P2 { float x, y; };
+__device__ __forceinline__ float crs3(P2 p1, P2 p2, P2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+__device__ __forceinline__ float fmin2(float a, float b) { return a > b ? b : a; }
+__device__ __forceinline__ float fmax2(float a, float b) { return a > b ? a : b; }
+
+__device__ __forceinline__ int corner_in_box(const float* box, P2 p) {
+    const float MARGIN = 1e-2f;
+    float ac = cosf(-box[6]), as = sinf(-box[6]);
+    float rx = (p.x - box[0]) * ac + (p.y - box[1]) * (-as);
+    float ry = (p.x - box[0]) * as + (p.y - box[1]) * ac;
+    return (fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN);
+}
+
+__device__ __forceinline__ int seg_x(P2 p1, P2 p0, P2 q1, P2 q0, P2& ans) {
+    int ov = fmin2(p0.x, p1.x) <= fmax2(q0.x, q1.x) && fmin2(q0.x, q1.x) <= fmax2(p0.x, p1.x) &&
+             fmin2(p0.y, p1.y) <= fmax2(q0.y, q1.y) && fmin2(q0.y, q1.y) <= fmax2(p0.y, p1.y);
+    if (!ov) return 0;
+    float s1 = crs3(q0, p1, p0), s2 = crs3(p1, q1, p0), s3 = crs3(p0, q1, q0), s4 = crs3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    float s5 = crs3(q1, p1, p0);
+    if (fabsf(s5 - s1) > 1e-8f) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+__device__ float box_overlap_bev(const float* A, const float* B) {
+    float adx = A[3] / 2, bdx = B[3] / 2, ady = A[4] / 2, bdy = B[4] / 2;
+    P2 pa[5] = {{A[0] - adx, A[1] - ady}, {A[0] + adx, A[1] - ady}, {A[0] + adx, A[1] + ady}, {A[0] - adx, A[1] + ady}, {0, 0}};
+    P2 pb[5] = {{B[0] - bdx, B[1] - bdy}, {B[0] + bdx, B[1] - bdy}, {B[0] + bdx, B[1] + bdy}, {B[0] - bdx, B[1] + bdy}, {0, 0}};
+    float aac = cosf(A[6]), aas = sinf(A[6]), bac = cosf(B[6]), bas = sinf(B[6]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        P2 p = pa[k];
+        pa[k].x = (p.x - A[0]) * aac + (p.y - A[1]) * (-aas) + A[0];
+        pa[k].y = (p.x - A[0]) * aas + (p.y - A[1]) * aac + A[1];
+        P2 q = pb[k];
+        pb[k].x = (q.x - B[0]) * bac + (q.y - B[1]) * (-bas) + B[0];
+        pb[k].y = (q.x - B[0]) * bas + (q.y - B[1]) * bac + B[1];
+    }
+    pa[4] = pa[0];
+    pb[4] = pb[0];
+    P2 poly[16];
+    P2 ctr = {0.f, 0.f};
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            P2 x;
+            if (seg_x(pa[i + 1], pa[i], pb[j + 1], pb[j], x)) {
+                poly[cnt] = x;
+                ctr.x = ctr.x + x.x;
+                ctr.y = ctr.y + x.y;
+                cnt++;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (corner_in_box(A, pb[k])) { ctr.x += pb[k].x; ctr.y += pb[k].y; poly[cnt++] = pb[k]; }
+        if (corner_in_box(B, pa[k])) { ctr.x += pa[k].x; ctr.y += pa[k].y; poly[cnt++] = pa[k]; }
+    }
+    ctr.x /= cnt;
+    ctr.y /= cnt;
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            if (atan2f(poly[i].y - ctr.y, poly[i].x - ctr.x) > atan2f(poly[i + 1].y - ctr.y, poly[i + 1].x - ctr.x)) {
+                P2 t = poly[i]; poly[i] = poly[i + 1]; poly[i + 1] = t;
+            }
+        }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; ++k) {
+        float ux = poly[k].x - poly[0].x, uy = poly[k].y - poly[0].y;
+        float vx = poly[k + 1].x - poly[0].x, vy = poly[k + 1].y - poly[0].y;
+        area += ux * vy - uy * vx;
+    }
+    return (float)(fabsf(area) / 2.0);
+}
+
+__device__ __forceinline__ float iou_bev_dev(const float* A, const float* B) {
+    float sa = A[3] * A[4], sb = B[3] * B[4];
+    float so = box_overlap_bev(A, B);
+    return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+__global__ void k_iou_bev(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                          float* __restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)na * nb) return;
+    int i = (int)(t / nb), j = (int)(t % nb);
+    float A[7], B[7];
+    for (int d = 0; d < 7; ++d) { A[d] = a[i * 7 + d]; B[d] = b[j * 7 + d]; }
+    out[t] = iou_bev_dev(A, B);
+}
+
+// 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed)
+__global__ void __launch_bounds__(64) k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ n_dev,
+                                                 int max_n, float thresh, uint64_t* __restrict__ mask) {
+    const int n = min(n_dev[0], max_n);
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    const int cbs = (max_n + 63) / 64;
+    __shared__ float col[64 * 7];
+    const int csize = min(n - cb * 64, 64), rsize = min(n - rb * 64, 64);
+    if ((int)threadIdx.x < csize)
+        for (int d = 0; d < 7; ++d) col[threadIdx.x * 7 + d] = boxes[(int64_t)(cb * 64 + threadIdx.x) * 7 + d];
+    __syncthreads();
+    if ((int)threadIdx.x < rsize) {
+        const int i = rb * 64 + threadIdx.x;
+        float A[7];
+        for (int d = 0; d < 7; ++d) A[d] = boxes[(int64_t)i * 7 + d];
+        uint64_t t = 0;
+        int start = (rb == cb) ? threadIdx.x + 1 : 0;
+        for (int j = start; j < csize; ++j)
+            if (iou_bev_dev(A, col + j * 7) > thresh) t |= 1ull << j;
+        mask[(int64_t)i * cbs + cb] = t;
+    }
+}
+
+// greedy reduce of iou3d_nms.cpp:116-132 by ONE wave: lane l owns word l of the removed-set
+__global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ n_dev,
+                                                   int max_n, int post_max, int32_t* __restrict__ keep,
+                                                   int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x;
+    const int n = min(n_dev[0], max_n);
+    const int cbs = (max_n + 63) / 64;
+    const int nb = (n + 63) / 64;
+    uint64_t remv = 0;  // word `lane`
+    int nk = 0;
+    for (int blk = 0; blk < nb && nk < post_max; ++blk) {
+        const int i_l = blk * 64 + lane;
+        uint64_t diag = (i_l < n) ? mask[(int64_t)i_l * cbs + blk] : 0ull;
+        uint64_t rb = __shfl(remv, blk);  // this block's removed word, wave-uniform
+        uint64_t kept = 0;
+        const int lim = min(64, n - blk * 64);
+        for (int i = 0; i < lim; ++i) {
+            if (!((rb >> i) & 1ull)) {
+                kept |= 1ull << i;
+                rb |= __shfl(diag, i);
+            }
+        }
+        // emit kept indices in ascending order
+        if ((kept >> lane) & 1ull) {
+            int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < post_max) keep[pos] = i_l;
+        }
+        nk += __popcll(kept);
+        // fold the kept rows into the later words, 4 independent row loads in flight
+        uint64_t kb = kept;
+        while (kb) {
+            int i0 = __ffsll((unsigned long long)kb) - 1; kb &= kb - 1;
+            int i1 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i1 >= 0) kb &= kb - 1;
+            int i2 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i2 >= 0) kb &= kb - 1;
+            int i3 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i3 >= 0) kb &= kb - 1;
+            uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+            if (lane > blk && lane < nb) {
+                m0 = mask[(int64_t)(blk * 64 + i0) * cbs + lane];
+                if (i1 >= 0) m1 = mask[(int64_t)(blk * 64 + i1) * cbs + lane];
+                if (i2 >= 0) m2 = mask[(int64_t)(blk * 64 + i2) * cbs + lane];
+                if (i3 >= 0) m3 = mask[(int64_t)(blk * 64 + i3) * cbs + lane];
+            }
+            remv |= m0 | m1 | m2 | m3;
+        }
+    }
+    if (lane == 0) counts[0] = nk < post_max ? nk : post_max;
+}
+
+__global__ void k_gather_preds(const float* __restrict__ cb, const float* __restrict__ cs, const int32_t* __restrict__ cl,
+                               const int32_t* __restrict__ keep, const int32_t* __restrict__ nk_dev, int post_max,
+                               float* __restrict__ pb, float* __restrict__ psc, int64_t* __restrict__ pl) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= post_max) return;
+    int nk = nk_dev[0];
+    if (t < nk) {
+        int s = keep[t];
+        for (int d = 0; d < 7; ++d) pb[t * 7 + d] = cb[(int64_t)s * 7 + d];
+        psc[t] = cs[s];
+        pl[t] = cl[s];
+    } else {
+        for (int d = 0; d < 7; ++d) pb[t * 7 + d] = 0.f;
+        psc[t] = 0.f;
+        pl[t] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// point-in-rotated-box one-hot features (Array_Index.cpp:14-79), exact incl. the first-hit early skip
+// ---------------------------------------------------------------------------------------------------
+struct BoxVox { float c[3], e[3], cs, sn; int label; int pad[3]; };  // 12 x 4 bytes
+
+__device__ __forceinline__ bool inside_box(const BoxVox& b, int x, int y, int z) {
+    float c0 = x - b.c[0], c1 = y - b.c[1], c2 = z - b.c[2];
+    float r0 = c0 * b.cs + c1 * b.sn;
+    float r1 = -c0 * b.sn + c1 * b.cs;
+    return (r0 <= b.e[0] / 2) && (r0 >= -b.e[0] / 2) && (r1 <= b.e[1] / 2) && (r1 >= -b.e[1] / 2) &&
+           (c2 <= b.e[2] / 2) && (c2 >= -b.e[2] / 2);
+}
+
+struct OneHotP { float lo[3], iv[3]; float istr, mult; };
+
+// one block per box: box -> voxel units, first hit (min voxel row inside) by block reduction
+__global__ void __launch_bounds__(256) k_onehot_first(const float* __restrict__ boxes, const int64_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ m_dev, int max_boxes, OneHotP P,
+                                                      const int32_t* __restrict__ coords, int64_t n,
+                                                      int32_t* __restrict__ first, BoxVox* __restrict__ bv) {
+    const int b = blockIdx.x;
+    const int m = min(m_dev[0], max_boxes);
+    if (b >= m) return;
+    __shared__ BoxVox sb;
+    __shared__ int smin;
+    if (threadIdx.x == 0) {
+        const float* bx = boxes + (int64_t)b * 7;
+        for (int d = 0; d < 3; ++d) {
+            // spconv_unet.py:324-329 on the CUDA path: (x - lo) * (1/v) * (1/stride), then *2 per level
+            sb.c[d] = (((bx[d] - P.lo[d]) * P.iv[d]) * P.istr) * P.mult;
+            sb.e[d] = ((bx[3 + d] * P.iv[d]) * P.istr) * P.mult;
+        }
+        double th = (double)bx[6];
+        sb.cs = (float)cos(th);
+        sb.sn = (float)sin(th);
+        sb.label = (int)(float)labels[b];
+        smin = 0x7fffffff;
+        bv[b] = sb;
+    }
+    __syncthreads();
+    BoxVox lb = sb;
+    int mine = 0x7fffffff;
+    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
+        int4 q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
+        if (inside_box(lb, q.w, q.z, q.y)) { mine = (int)j; break; }  // ascending j per thread: first hit is its min
+    }
+    atomicMin(&smin, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) first[b] = smin;
+}
+
+__global__ void __launch_bounds__(256) k_onehot_mark(const int32_t* __restrict__ m_dev, int max_boxes,
+                                                     const int32_t* __restrict__ coords, int64_t n,
+                                                     const int32_t* __restrict__ first, const BoxVox* __restrict__ bv,
+                                                     int ncls, int pad_to, int quirk, float* __restrict__ out, int ld_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = min(m_dev[0], max_boxes);
+    if (j >= n) return;
+    int4 q = *(const int4*)(coords + j * 4);
+    const int x = q.w, y = q.z, z = q.y;
+    unsigned bits = 0;
+    for (int b = 0; b < m; ++b) {
+        const int f = first[b];
+        if (f == 0x7fffffff) continue;  // box contains no voxel at all
+        const BoxVox bb = bv[b];
+        if (quirk && j != f) {
+            // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
+            // extend[d] from the first-hit voxel.  Rows before the first hit are not inside by definition.
+            if (j < f) continue;
+            int4 fq = *(const int4*)(coords + (int64_t)f * 4);
+            const int fx = fq.w, fy = fq.z, fz = fq.y;
+            if (x > (fx + bb.e[0]) || x < (fx - bb.e[0]) || y > (fy + bb.e[1]) || y < (fy - bb.e[1]) ||
+                z > (fz + bb.e[2]) || z < (fz - bb.e[2]))
+                continue;
+        }
+        if (bb.label > 0 && bb.label <= ncls && inside_box(bb, x, y, z)) bits |= 1u << (bb.label - 1);
+    }
+    float* o = out + j * ld_out;
+    for (int c = 0; c < pad_to; ++c) o[c] = (c < ncls && ((bits >> c) & 1u)) ? 1.0f : 0.0f;
+}
+
+}  // namespace insmos
+
+using namespace insmos;
+
+extern "C" size_t insmos_center_decode_select_ws_bytes(int64_t n_cells) {
+    size_t N = (size_t)n_cells;
+    return pad256(N * 8) * 2 + pad256(N * 4) * 2 + sort_pairs_u64_u32_temp(N) + 1024;
+}
+
+extern "C" int insmos_center_decode_select(const float* head, int ld_head, int ncls, int H, int W, int up,
+                                           float out_factor, float vx, float vy, float x0, float y0,
+                                           float score_thresh, int pre_max, float* cand_boxes, float* cand_scores,
+                                           int32_t* cand_labels, int32_t* cand_cell, int32_t* counts, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    if (!head || ncls <= 0 || ld_head < ncls + 8 || H <= 0 || W <= 0 || (up != 1 && up != 2) || pre_max <= 0)
+        return INSMOS_EINVAL;
+    if (up == 2 && ((H & 1) || (W & 1))) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)H * W;
+    Bump b(ws, ws_bytes);
+    uint64_t* keys = b.take<uint64_t>((size_t)n);
+    uint64_t* keys_s = b.take<uint64_t>((size_t)n);
+    uint32_t* vals = b.take<uint32_t>((size_t)n);
+    uint32_t* vals_s = b.take<uint32_t>((size_t)n);
+    size_t st = sort_pairs_u64_u32_temp((size_t)n);
+    char* tmp = b.take<char>(st);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+    {
+        ProfScope ps(KK_DECODE, s);
+        hipLaunchKernelGGL(k_score_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, head, ld_head, ncls, n, W, up, score_thresh,
+                           keys, vals, counts);
+    }
+    int rc = sort_pairs_u64_u32(tmp, st, keys, keys_s, vals, vals_s, (size_t)n, 0, 64, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_SELECT, s);
+        hipLaunchKernelGGL(k_select_decode, dim3(cdiv(pre_max, 256)), dim3(256), 0, s, head, ld_head, ncls, W, up,
+                           out_factor, vx, vy, x0, y0, keys_s, vals_s, n, pre_max, cand_boxes, cand_scores, cand_labels,
+                           cand_cell, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_nms_ws_bytes(int max_n) {
+    size_t cbs = ((size_t)max_n + 63) / 64;
+    return pad256((size_t)max_n * cbs * 8) + 1024;
+}
+
+extern "C" int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, int max_n, float thresh, int post_max,
+                                      int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (!boxes || !n_dev || max_n <= 0 || max_n > 4096 || post_max <= 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    const int cbs = (max_n + 63) / 64;
+    uint64_t* mask = b.take<uint64_t>((size_t)max_n * cbs);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    {
+        ProfScope ps(KK_NMS_MASK, s);
+        hipLaunchKernelGGL(k_nms_mask, dim3(cbs, cbs), dim3(64), 0, s, boxes, n_dev, max_n, thresh, mask);
+    }
+    {
+        ProfScope ps(KK_NMS_REDUCE, s);
+        hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(64), 0, s, mask, n_dev, max_n, post_max, keep, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_iou_bev(const float* a, int na, const float* b, int nb, float* out, void* stream) {
+    if (na <= 0 || nb <= 0) return INSMOS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_IOU, s);
+    hipLaunchKernelGGL(k_iou_bev, dim3(cdiv((int64_t)na * nb, 128)), dim3(128), 0, s, a, na, b, nb, out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                                   const int32_t* keep, const int32_t* n_keep_dev, int post_max, float* pred_boxes,
+                                   float* pred_scores, int64_t* pred_labels, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_GATHER_PREDS, s);
+    hipLaunchKernelGGL(k_gather_preds, dim3(cdiv(post_max, 256)), dim3(256), 0, s, cand_boxes, cand_scores, cand_labels,
+                       keep, n_keep_dev, post_max, pred_boxes, pred_scores, pred_labels);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                                      int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
+                                      float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
+                                      int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!pred_boxes || !pred_labels || !n_boxes_dev || max_boxes <= 0 || !coords || !out || !scratch || ncls <= 0 ||
+        ncls > 31 || pad_to < ncls || ld_out < pad_to)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    OneHotP P;
+    for (int d = 0; d < 3; ++d) {
+        P.lo[d] = range_lo_host[d];
+        P.iv[d] = 1.0f / vsize_host[d];
+    }
+    P.istr = 1.0f / stride;
+    P.mult = mult;
+    int32_t* first = scratch;
+    BoxVox* bv = (BoxVox*)(scratch + ((max_boxes + 3) & ~3));
+    ProfScope ps(KK_ONEHOT, s);
+    hipLaunchKernelGGL(k_onehot_first, dim3(max_boxes), dim3(256), 0, s, pred_boxes, pred_labels, n_boxes_dev, max_boxes,
+                       P, coords, n, first, bv);
+    hipLaunchKernelGGL(k_onehot_mark, dim3(cdiv(n, 256)), dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv,
+                       ncls, pad_to, quirk_exact, out, ld_out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}

@@ -1,0 +1,109 @@
+// insmos_amd/csrc/misc.hip -- row gathers, constant fills and the confusion-matrix histogram.
+#include "common.h"
+
+namespace insmos {
+
+__global__ void k_gather_rows(const float* __restrict__ src, int ld_src, int c, const int64_t* __restrict__ idx,
+                              int64_t n, float* __restrict__ out, int ld_out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    int64_t i = t / c;
+    int ch = (int)(t % c);
+    int64_t s = idx[i];
+    out[i * ld_out + ch] = s >= 0 ? src[s * ld_src + ch] : 0.f;
+}
+
+__global__ void k_current_points(const float* __restrict__ pts, int ld_pts, const float* __restrict__ motion,
+                                 int ld_motion, const int32_t* __restrict__ inverse,
+                                 const int32_t* __restrict__ cur_index, int64_t n_cur, float* __restrict__ cur,
+                                 int ld_cur) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cur) return;
+    int p = cur_index[j];
+    const float* pp = pts + (int64_t)p * ld_pts;
+    const float* mm = motion + (int64_t)inverse[p] * ld_motion;
+    float* o = cur + j * ld_cur;
+    o[0] = pp[0]; o[1] = pp[1]; o[2] = pp[2]; o[3] = pp[3];
+    o[4] = mm[0]; o[5] = mm[1]; o[6] = mm[2];
+    for (int c = 7; c < ld_cur; ++c) o[c] = 0.f;
+}
+
+__global__ void k_fill_cols(float* __restrict__ dst, int64_t n, int ld, int c0, int c, float v) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    dst[(t / c) * ld + c0 + (t % c)] = v;
+}
+
+__global__ void __launch_bounds__(256) k_confusion(const float* __restrict__ logits, int ld, const int64_t* __restrict__ gt,
+                                                   int64_t n, int ncls, unsigned ignore_mask,
+                                                   unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* l = logits + i * ld;
+        int best = 0;
+        float bv = -INFINITY;
+        bool have = false;
+        for (int c = 0; c < ncls; ++c) {
+            float v = ((ignore_mask >> c) & 1u) ? -INFINITY : l[c];
+            if (!have || v > bv) { bv = v; best = c; have = true; }  // first max wins (torch.argmax)
+        }
+        int g = (int)gt[i];
+        if (g >= 0 && g < ncls) atomicAdd(&h[best * ncls + g], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncls * ncls && h[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+}  // namespace insmos
+
+using namespace insmos;
+
+extern "C" int insmos_gather_rows(const float* src, int ld_src, int c, const int64_t* idx, int64_t n, float* out,
+                                  int ld_out, void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!src || !idx || !out || c <= 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_GATHER_ROWS, s);
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(n * c, 256)), dim3(256), 0, s, src, ld_src, c, idx, n, out, ld_out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_build_current_points(const float* points, int ld_pts, const float* motion, int ld_motion,
+                                           const int32_t* inverse, const int32_t* cur_index, int64_t n_cur, float* cur,
+                                           int ld_cur, void* stream) {
+    if (n_cur <= 0) return INSMOS_OK;
+    if (!points || !motion || !inverse || !cur_index || !cur || ld_cur < 7 || ld_pts < 5 || ld_motion < 3)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_CUR_POINTS, s);
+    hipLaunchKernelGGL(k_current_points, dim3(cdiv(n_cur, 256)), dim3(256), 0, s, points, ld_pts, motion, ld_motion,
+                       inverse, cur_index, n_cur, cur, ld_cur);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, float value, void* stream) {
+    if (n <= 0 || c <= 0) return INSMOS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_FILL, s);
+    hipLaunchKernelGGL(k_fill_cols, dim3(cdiv(n * c, 256)), dim3(256), 0, s, dst, n, ld, c0, c, value);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_confusion3(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls,
+                                 unsigned ignore_mask, int64_t* cm, void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!logits || !gt || !cm || ncls <= 0 || ncls > 8) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_CONFUSION, s);
+    unsigned g = cdiv(n, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_confusion, dim3(g), dim3(256), 0, s, logits, ld, gt, n, ncls, ignore_mask,
+                       (unsigned long long*)cm);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}

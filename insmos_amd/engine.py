@@ -1,0 +1,549 @@
+"""MI355X execution engine for one InsMOS window: torch is used only for device memory, streams and
+(in bench/metrics) torch.distributed; all compute goes through libinsmos_hip.so (include/insmos_hip.h).
+
+Layer order, channel widths and parameter names follow the reference modules:
+  MotionNet / CustomMinkUNet   models/backbones_3d/motionnet.py:21-50, models/MinkowskiEngine/minkunet.py:139-181
+  VoxelGenerate + MeanVFE      models/backbones_3d/voxel_generate.py:17-31, models/backbones_2d/mean_vfe.py:36-55
+  UNetV2                       models/backbones_3d/spconv_unet.py:267-416
+  HeightCompression            models/backbones_2d/height_compression.py:14-33
+  BaseBEVBackbone, CenterHead  models/backbones_2d/base_bev_backbone.py:84-115, center_head.py:65-98,251-276
+  post_processing              models/post_process.py:112-224
+Eval-mode BatchNorm is folded into the conv taps; channel concatenations (ME.cat, torch.cat of the
+UR blocks and the instance one-hots) are free: producers write into column slices of shared rows.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import params as P
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _hp(a):  # host pointer of a numpy array
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def me_kernel_offsets(kernel_size, tensor_stride):
+    """ME kernel-region tap order: x fastest; odd sizes centred, even sizes {0,1}; scaled by tensor stride."""
+    ks, ts = list(kernel_size), list(tensor_stride)
+    offs = []
+    for it in range(ks[3]):
+        for iz in range(ks[2]):
+            for iy in range(ks[1]):
+                for ix in range(ks[0]):
+                    idx = (ix, iy, iz, it)
+                    offs.append([((idx[d] - (ks[d] - 1) // 2) if ks[d] % 2 == 1 else idx[d]) * ts[d] for d in range(4)])
+    return _np_i32(offs)
+
+
+def spconv_tap_offsets(ksize):
+    return [(kz, ky, kx) for kz in range(ksize[0]) for ky in range(ksize[1]) for kx in range(ksize[2])]
+
+
+class ConvLayer:
+    """Device-resident packed taps + folded bias of one convolution."""
+
+    def __init__(self, lib, taps, bias, cin_pad, cout_store, device):
+        K, cin_real, cout_real = taps.shape
+        self.K, self.cin, self.cout = K, cin_pad, cout_store
+        self.cout_real = cout_real
+        nfl = lib.insmos_packed_weight_floats(K, cin_pad, cout_store)
+        packed = np.empty(nfl, dtype=np.float32)
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        _lib.check(lib.insmos_pack_weights_host(_hp(taps), K, cin_real, cout_real, cin_pad, cout_store, _hp(packed)),
+                   "insmos_pack_weights_host")
+        ntile = (cout_store + 15) // 16
+        b = np.zeros(ntile * 16, dtype=np.float32)
+        if bias is not None:
+            b[:cout_real] = np.asarray(bias, np.float32).reshape(-1)
+        self.w = torch.from_numpy(packed).to(device)
+        self.b = torch.from_numpy(b).to(device)
+        self.flops_per_pair = 2 * cin_real * cout_real
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class Engine:
+    def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.quirk_exact = quirk_exact
+        self.max_voxels, self.max_points = max_voxels, max_points
+        d, m = cfg["DATA"], cfg["MODEL"]
+        self.vs = [float(v) for v in d["VOXEL_SIZE"]]
+        self.range = [float(v) for v in d["POINT_CLOUD_RANGE"]]
+        self.dt = float(m["DELTA_T_PREDICTION"])
+        self.ncls = int(m["DENSE_HEAD"]["NUM_CLASS"])
+        self.in_ch = len(m["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
+        grid = np.round((np.array(self.range[3:6]) - np.array(self.range[0:3])) / np.array(self.vs)).astype(np.int64)
+        self.grid = [int(g) for g in grid]  # [nx, ny, nz]
+        self.shape = {1: [self.grid[2] + 1, self.grid[1], self.grid[0]]}  # spconv_unet.py:114
+        for l in (2, 3, 4):
+            self.shape[l] = [(s + 2 - 3) // 2 + 1 for s in self.shape[l - 1]]
+        s4 = self.shape[4]
+        self.shape[5] = [(s4[0] - 3) // 2 + 1, s4[1], s4[2]]
+        self.bevD, self.bevH, self.bevW = self.shape[5]
+        self.nbev = int(m["MAP_TO_BEV"]["NUM_BEV_FEATURES"])
+        if self.nbev != 128 * self.bevD:
+            raise ValueError(f"NUM_BEV_FEATURES={self.nbev} does not match 128*{self.bevD} (height_compression.py:28)")
+        pp = m["POST_PROCESSING"]
+        self.score_thresh = float(pp["SCORE_THRESH"])
+        self.nms_thresh = float(pp["NMS_CONFIG"]["NMS_THRESH"])
+        self.pre_max = int(pp["NMS_CONFIG"]["NMS_PRE_MAXSIZE"])
+        self.post_max = int(pp["NMS_CONFIG"]["NMS_POST_MAXSIZE"])
+        if pp["NMS_CONFIG"]["MULTI_CLASSES_NMS"] or pp["NMS_CONFIG"]["NMS_TYPE"] != "nms_gpu" or pp["OUTPUT_RAW_SCORE"]:
+            raise NotImplementedError("only the class-agnostic nms_gpu branch of post_processing is on the hot path")
+        tcfg = m["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]
+        self.out_factor = float(tcfg["OUT_SIZE_FACTOR"])
+        self.tvs = [float(v) for v in tcfg["VOXEL_SIZE"]]
+        self.up = int(m["BACKBONE_2D"]["UPSAMPLE_STRIDES"][0])
+        if self.up != 2:
+            raise NotImplementedError("BEV deconv stride 2 only (config.yaml:118)")
+        self._ws = None
+        self._load_weights(state_dict)
+        self._static_tables()
+        self.last_counts = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _sd(self, name):
+        v = self.sd[name]
+        return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+    def _bn(self, stem):
+        return (self._sd(stem + ".weight"), self._sd(stem + ".bias"), self._sd(stem + ".running_mean"),
+                self._sd(stem + ".running_var"))
+
+    def _load_weights(self, sd):
+        self.sd = sd
+        L, dev, lib = {}, self.device, self.lib
+        M = P.ME_PREFIX
+
+        def me(conv, bn, cin_pad, cout_store, bias=None):
+            taps = P.me_kernel_to_taps(self._sd(M + conv + ".kernel"))
+            b = None
+            if bn is not None:
+                taps, b = P.fold_bn(taps, *self._bn(M + bn + ".bn"), 1e-5)
+            elif bias is not None:
+                b = bias
+            return ConvLayer(lib, taps, b, cin_pad, cout_store, dev)
+
+        for conv, bn, kv, ci, co in P.ME_CONVS:
+            L[conv] = me(conv, bn, _pad4(ci), co)
+        for name, ci, co in P.ME_BLOCKS:
+            L[name + ".conv1"] = me(name + ".conv1", name + ".norm1", ci, co)
+            L[name + ".conv2"] = me(name + ".conv2", name + ".norm2", co, co)
+            if ci != co:
+                L[name + ".ds"] = me(name + ".downsample.0", name + ".downsample.1", ci, co)
+        L["final"] = me("final", None, 8, 3, bias=self._sd(M + "final.bias"))
+
+        U = P.UNET_PREFIX
+        for conv, bn, ks, ci, co in P.unet_convs(self.in_ch, self.ncls):
+            taps = P.spconv_weight_to_taps(self._sd(U + conv + ".weight"))
+            b = None
+            if bn:
+                taps, b = P.fold_bn(taps, *self._bn(U + bn), 1e-3)
+            L[conv] = ConvLayer(lib, taps, b, _pad4(ci), co, dev)
+        B = U + "bev_backbone."
+        taps, b = P.fold_bn(P.conv2d_weight_to_taps(self._sd(B + "blocks.0.1.weight")), *self._bn(B + "blocks.0.2"), 1e-3)
+        L["bev0"] = ConvLayer(lib, taps, b, taps.shape[1], taps.shape[2], dev)
+        self.n_bev_layers = int(self.cfg["MODEL"]["BACKBONE_2D"]["LAYER_NUMS"][0])
+        for k in range(self.n_bev_layers):
+            taps, b = P.fold_bn(P.conv2d_weight_to_taps(self._sd(B + f"blocks.0.{4 + 3 * k}.weight")),
+                                *self._bn(B + f"blocks.0.{5 + 3 * k}"), 1e-3)
+            L[f"bev{k + 1}"] = ConvLayer(lib, taps, b, taps.shape[1], taps.shape[2], dev)
+        # ConvTranspose2d(k=2,s=2) == a 1x1 conv with 4*Cout output channels laid out [ky][kx][co]
+        tt = P.convT2d_weight_to_taps(self._sd(B + "deblocks.0.0.weight"))  # (4, Cin, Cout)
+        tt, b = P.fold_bn(tt, *self._bn(B + "deblocks.0.1"), 1e-3)
+        K4, ci, co = tt.shape
+        wide = np.ascontiguousarray(tt.transpose(1, 0, 2).reshape(1, ci, K4 * co))
+        L["deconv"] = ConvLayer(lib, wide, np.tile(b, K4), ci, K4 * co, dev)
+        self.up_ch = co
+        Hd = U + "center_head."
+        wc = self._sd(Hd + "conv_cls.weight").reshape(self.ncls, -1)
+        wb = self._sd(Hd + "conv_box.weight").reshape(8, -1)
+        taps = np.concatenate([wc, wb], 0).T[None].astype(np.float32)  # (1, 256, ncls+8)
+        bias = np.concatenate([self._sd(Hd + "conv_cls.bias"), self._sd(Hd + "conv_box.bias")])
+        self.head_ld = _pad4(self.ncls + 8)
+        L["head"] = ConvLayer(lib, taps, bias, co, self.head_ld, dev)
+        wl = self._sd(U + "mos_seg_layer.weight")  # (3,16)
+        L["mos_seg"] = ConvLayer(lib, np.ascontiguousarray(wl.T[None]), self._sd(U + "mos_seg_layer.bias"), 16, 3, dev)
+        self.L = L
+
+    def _static_tables(self):
+        dev = self.device
+        self.nbr_bev = torch.empty((9, self.bevH * self.bevW), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.insmos_dense_nbr2d(self.bevH, self.bevW, self.nbr_bev.data_ptr(), self._stream()),
+                   "insmos_dense_nbr2d")
+        self.off125 = me_kernel_offsets([5, 5, 5, 1], [1, 1, 1, 1])
+        self.off81 = [me_kernel_offsets([3, 3, 3, 3], [1 << l, 1 << l, 1 << l, 1]) for l in range(4)]
+        self.off8 = [me_kernel_offsets([2, 2, 2, 1], [1 << l, 1 << l, 1 << l, 1]) for l in range(3)]
+        self.ones4 = _np_i32([1, 1, 1, 1])
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------
+    def conv(self, layer, x, ld_in, nbr, n_out, out, ld_out, col_out=0, col_in=0, res=None, ld_res=0, col_res=0,
+             res_mode=0, relu_pre=0, relu_post=0):
+        """out[:, col_out:col_out+cout] = epilogue(conv(x[:, col_in:col_in+cin]))."""
+        if n_out == 0:
+            return
+        K = layer.K
+        if nbr is not None:
+            assert nbr.shape[0] == K and nbr.shape[1] == n_out, (nbr.shape, K, n_out)
+        rc = self.lib.insmos_sparse_conv(
+            x.data_ptr() + 4 * col_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None, K, n_out,
+            layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr() + 4 * col_out, ld_out, layer.cout,
+            (res.data_ptr() + 4 * col_res) if res is not None else None, ld_res, res_mode, relu_pre, relu_post,
+            self._stream())
+        _lib.check(rc, "insmos_sparse_conv")
+        self._conv_log.append((nbr, n_out, layer))
+
+    def build_nbr(self, out_coords, n_out, in_keys, in_perm, n_in, mode, shape, delta, mul=None, div=None):
+        K = len(delta)
+        nbr = self._empty((K, n_out), torch.int32)
+        if n_out == 0:
+            return nbr
+        delta = _np_i32(delta)
+        mul = _np_i32(mul if mul is not None else [1, 1, 1, 1])
+        div = _np_i32(div if div is not None else [1, 1, 1, 1])
+        shp = _np_i32(shape) if shape is not None else None
+        rc = self.lib.insmos_build_nbr(out_coords.data_ptr(), n_out, in_keys.data_ptr(),
+                                       in_perm.data_ptr() if in_perm is not None else None, n_in, mode,
+                                       _hp(shp) if shp is not None else None, _hp(delta), K, _hp(mul), _hp(div),
+                                       nbr.data_ptr(), self._stream())
+        _lib.check(rc, "insmos_build_nbr")
+        return nbr
+
+    # ------------------------------------------------------------------------------------------------
+    def motionnet(self, pts):
+        """pts (N, ld>=5) fp32 device [x,y,z,r,t] -> current_point (Ncur, 8) [x,y,z,r,m0,m1,m2,0]."""
+        lib, st = self.lib, self._stream()
+        N, ld = pts.shape[0], pts.stride(0)
+        ws = self._workspace(lib.insmos_quantize4d_ws_bytes(N))
+        keys0 = self._empty((N,), torch.int64)
+        coords0 = self._empty((N, 4), torch.int32)
+        inverse = self._empty((N,), torch.int32)
+        cur_index = self._empty((N,), torch.int32)
+        counts = self._empty((4,), torch.int32)
+        quant = np.array([self.vs[0], self.vs[0], self.vs[0], self.dt], dtype=np.float32)
+        _lib.check(lib.insmos_quantize4d(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
+                                         inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), st), "insmos_quantize4d")
+        c = counts.cpu().numpy()
+        n0, ncur = int(c[0]), int(c[1])
+        if int(c[2]) != 0:
+            raise ValueError(f"{int(c[2])} points fall outside the +-32768-voxel key window")
+        keys = [keys0[:n0]]
+        coords = [coords0[:n0]]
+        n = [n0]
+        for l in (1, 2, 3):
+            kk = self._empty((n[-1],), torch.int64)
+            cc = self._empty((n[-1], 4), torch.int32)
+            par = self._empty((n[-1],), torch.int32)
+            ws = self._workspace(lib.insmos_level_down4d_ws_bytes(n[-1]))
+            # always derived from level 0 so each level's parent map is w.r.t. the finest voxels;
+            # cheaper: derive level l from level l-1 (its keys already have the lower bits cleared)
+            _lib.check(lib.insmos_level_down4d(keys[-1].data_ptr(), n[-1], l, kk.data_ptr(), cc.data_ptr(),
+                                               par.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       "insmos_level_down4d")
+            nl = int(counts[0].item())
+            keys.append(kk[:nl])
+            coords.append(cc[:nl])
+            n.append(nl)
+        self.last_counts["me_voxels"] = list(n)
+        self.last_counts["n_cur"] = ncur
+        nbr125 = self.build_nbr(coords[0], n[0], keys[0], None, n[0], 0, None, self.off125)
+        nbr81 = [self.build_nbr(coords[l], n[l], keys[l], None, n[l], 0, None, self.off81[l]) for l in range(4)]
+        dn = [self.build_nbr(coords[l + 1], n[l + 1], keys[l], None, n[l], 0, None, self.off8[l]) for l in range(3)]
+        up = [self.build_nbr(coords[l], n[l], keys[l + 1], None, n[l + 1], 0, None, -self.off8[l]) for l in range(3)]
+        self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse)
+
+        L, E = self.L, self._empty
+        x_in = E((n[0], 4))
+        x_in.zero_()
+        _lib.check(lib.insmos_fill_cols(x_in.data_ptr(), n[0], 4, 0, 1, 0.5, st), "insmos_fill_cols")
+        cat8 = E((n[0], 16))  # [convtr7 (8) | out_p1 (8)]
+        cat7 = E((n[1], 24))  # [convtr6 (16) | out_b1p2 (8)]
+        cat6 = E((n[2], 48))  # [convtr5 (32) | out_b2p4 (16)]
+        self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
+        x1 = E((n[1], 8))
+        self.conv(L["conv1p1s2"], cat8, 16, dn[0], n[1], x1, 8, col_in=8, relu_post=1)
+
+        def block(name, x, ld_x, col_x, nb, nn, cout, out, ld_out, col_out):
+            t = E((nn, cout))
+            self.conv(L[name + ".conv1"], x, ld_x, nb, nn, t, cout, col_in=col_x, relu_post=1)
+            if (name + ".ds") in L:
+                r = E((nn, cout))
+                self.conv(L[name + ".ds"], x, ld_x, None, nn, r, cout, col_in=col_x)
+                self.conv(L[name + ".conv2"], t, cout, nb, nn, out, ld_out, col_out=col_out, res=r, ld_res=cout,
+                          res_mode=1, relu_post=1)
+            else:
+                self.conv(L[name + ".conv2"], t, cout, nb, nn, out, ld_out, col_out=col_out, res=x, ld_res=ld_x,
+                          col_res=col_x, res_mode=1, relu_post=1)
+
+        block("block1.0", x1, 8, 0, nbr81[1], n[1], 8, cat7, 24, 16)
+        x2 = E((n[2], 8))
+        self.conv(L["conv2p2s2"], cat7, 24, dn[1], n[2], x2, 8, col_in=16, relu_post=1)
+        block("block2.0", x2, 8, 0, nbr81[2], n[2], 16, cat6, 48, 32)
+        x3 = E((n[3], 16))
+        self.conv(L["conv3p4s2"], cat6, 48, dn[2], n[3], x3, 16, col_in=32, relu_post=1)
+        b3 = E((n[3], 32))
+        block("block3.0", x3, 16, 0, nbr81[3], n[3], 32, b3, 32, 0)
+        self.conv(L["convtr5p8s2"], b3, 32, up[2], n[2], cat6, 48, col_out=0, relu_post=1)
+        b6 = E((n[2], 32))
+        block("block6.0", cat6, 48, 0, nbr81[2], n[2], 32, b6, 32, 0)
+        self.conv(L["convtr6p4s2"], b6, 32, up[1], n[1], cat7, 24, col_out=0, relu_post=1)
+        b7 = E((n[1], 16))
+        block("block7.0", cat7, 24, 0, nbr81[1], n[1], 16, b7, 16, 0)
+        self.conv(L["convtr7p2s2"], b7, 16, up[0], n[0], cat8, 16, col_out=0, relu_post=1)
+        b8 = E((n[0], 8))
+        block("block8.0", cat8, 16, 0, nbr81[0], n[0], 8, b8, 8, 0)
+        motion = E((n[0], 4))
+        self.conv(L["final"], b8, 8, None, n[0], motion, 4)
+        cur = E((ncur, 8))
+        _lib.check(lib.insmos_build_current_points(pts.data_ptr(), ld, motion.data_ptr(), 4, inverse.data_ptr(),
+                                                   cur_index.data_ptr(), ncur, cur.data_ptr(), 8, st),
+                   "insmos_build_current_points")
+        self._me_debug = dict(b3=b3, b8=b8, motion=motion)
+        return cur
+
+    # ------------------------------------------------------------------------------------------------
+    def unet(self, cur):
+        """cur (Ncur, 8) -> (point logits (Ncur,3), pred dict of device tensors)."""
+        lib, st, E, L = self.lib, self._stream(), self._empty, self.L
+        ncur = cur.shape[0]
+        ncls = self.ncls
+        counts = E((4,), torch.int32)
+        V_cap = self.max_voxels
+        feat = E((V_cap, 8))
+        coords1 = E((V_cap, 4), torch.int32)
+        num_points = E((V_cap,), torch.int32)
+        pcid = E((max(ncur, 1),), torch.int64)
+        ukeys = E((max(ncur, 1),), torch.int64)
+        uperm = E((max(ncur, 1),), torch.int32)
+        if ncur == 0:
+            raise ValueError("window has no current-scan points (t == 0)")
+        ws = self._workspace(lib.insmos_voxelize_mean_ws_bytes(ncur))
+        rng = np.array(self.range, dtype=np.float32)
+        vsz = np.array(self.vs, dtype=np.float32)
+        _lib.check(lib.insmos_voxelize_mean(cur.data_ptr(), ncur, 8, self.in_ch, _hp(rng), _hp(vsz), self.max_voxels,
+                                            self.max_points, feat.data_ptr(), 8, coords1.data_ptr(),
+                                            num_points.data_ptr(), pcid.data_ptr(), ukeys.data_ptr(), uperm.data_ptr(),
+                                            counts.data_ptr(), ws.data_ptr(), ws.numel(), st), "insmos_voxelize_mean")
+        c = counts.cpu().numpy()
+        V, S = int(c[0]), int(c[1])
+        nv = {1: V}
+        coords = {1: coords1[:V]}
+        keys = {1: ukeys[:S]}
+        perm = {1: uperm[:S]}
+        nkeys = {1: S}
+        k333, s222, p111 = _np_i32([3, 3, 3]), _np_i32([2, 2, 2]), _np_i32([1, 1, 1])
+
+        def down_coords(lvl_in, ks, stv, pd, oshape):
+            n_in = nv[lvl_in]
+            K = int(np.prod(ks))
+            cells = int(np.prod(oshape))
+            cap = max(min(n_in * K, cells), 1)
+            ok = E((cap,), torch.int64)
+            oc = E((cap, 4), torch.int32)
+            if n_in == 0:
+                return ok[:0], oc[:0], 0
+            w = self._workspace(lib.insmos_down_coords3d_ws_bytes(n_in, K))
+            _lib.check(lib.insmos_down_coords3d(coords[lvl_in].data_ptr(), n_in, _hp(ks), _hp(stv), _hp(pd),
+                                                _hp(_np_i32(oshape)), ok.data_ptr(), oc.data_ptr(), counts.data_ptr(),
+                                                w.data_ptr(), w.numel(), st), "insmos_down_coords3d")
+            no = int(counts[0].item())
+            return ok[:no], oc[:no], no
+
+        for l in (2, 3, 4):
+            keys[l], coords[l], nv[l] = down_coords(l - 1, k333, s222, p111, self.shape[l])
+            perm[l], nkeys[l] = None, nv[l]
+        k311, s211, p000 = _np_i32([3, 1, 1]), _np_i32([2, 1, 1]), _np_i32([0, 0, 0])
+        keys[5], coords[5], nv[5] = down_coords(4, k311, s211, p000, self.shape[5])
+        perm[5], nkeys[5] = None, nv[5]
+        self.last_counts["unet_voxels"] = [nv[l] for l in (1, 2, 3, 4, 5)]
+
+        t27 = spconv_tap_offsets((3, 3, 3))
+        t3 = spconv_tap_offsets((3, 1, 1))
+        d_subm = [[0, kz - 1, ky - 1, kx - 1] for kz, ky, kx in t27]
+        d_down = [[0, kz - 1, ky - 1, kx - 1] for kz, ky, kx in t27]  # i = 2*o - 1 + k
+        d_inv = [[0, 1 - kz, 1 - ky, 1 - kx] for kz, ky, kx in t27]  # o = (i + 1 - k) / 2
+        d_down5 = [[0, kz, 0, 0] for kz, ky, kx in t3]  # i = (2*oz + kz, oy, ox)
+        d_inv5 = [[0, -kz, 0, 0] for kz, ky, kx in t3]
+        subm = {l: self.build_nbr(coords[l], nv[l], keys[l], perm[l], nkeys[l], 1, self.shape[l], d_subm)
+                for l in (1, 2, 3, 4)}
+        down = {l: self.build_nbr(coords[l], nv[l], keys[l - 1], perm[l - 1], nkeys[l - 1], 1, self.shape[l - 1], d_down,
+                                  mul=[1, 2, 2, 2]) for l in (2, 3, 4)}
+        inv = {l: self.build_nbr(coords[l - 1], nv[l - 1], keys[l], perm[l], nkeys[l], 1, self.shape[l], d_inv,
+                                 div=[1, 2, 2, 2]) for l in (2, 3, 4)}
+        down5 = self.build_nbr(coords[5], nv[5], keys[4], None, nkeys[4], 1, self.shape[4], d_down5, mul=[1, 2, 1, 1])
+        inv5 = self.build_nbr(coords[4], nv[4], keys[5], None, nkeys[5], 1, self.shape[5], d_inv5, div=[1, 2, 1, 1])
+        self._un_tables = dict(subm=subm, down=down, inv=inv, down5=down5, inv5=inv5, coords=coords, pcid=pcid,
+                               feat=feat[:V], num_points=num_points[:V])
+
+        # ---- encoder (spconv_unet.py:297-306)
+        x0 = E((V, 16))
+        self.conv(L["conv_input.0"], feat, 8, subm[1], V, x0, 16, relu_post=1)
+        xc = {1: E((V, 16))}
+        self.conv(L["conv1.0.0"], x0, 16, subm[1], V, xc[1], 16, relu_post=1)
+        for l, C in ((2, 32), (3, 64), (4, 128)):
+            a, b = E((nv[l], C)), E((nv[l], C))
+            xc[l] = E((nv[l], C))
+            self.conv(L[f"conv{l}.0.0"], xc[l - 1], C // 2, down[l], nv[l], a, C, relu_post=1)
+            self.conv(L[f"conv{l}.1.0"], a, C, subm[l], nv[l], b, C, relu_post=1)
+            self.conv(L[f"conv{l}.2.0"], b, C, subm[l], nv[l], xc[l], C, relu_post=1)
+        enc = E((nv[5], 128))
+        self.conv(L["conv_out.0"], xc[4], 128, down5, nv[5], enc, 128, relu_post=1)
+
+        # ---- BEV detection head in NHWC (height_compression.py:24-31, base_bev_backbone.py:84-115)
+        nsite = self.bevH * self.bevW
+        bev = E((nsite, self.nbev))
+        _lib.check(lib.insmos_sparse_to_bev(enc.data_ptr(), 128, 128, coords[5].data_ptr(), nv[5], self.bevD, self.bevH,
+                                            self.bevW, bev.data_ptr(), st), "insmos_sparse_to_bev")
+        nf = L["bev0"].cout
+        fa, fb = E((nsite, nf)), E((nsite, nf))
+        self.conv(L["bev0"], bev, self.nbev, self.nbr_bev, nsite, fa, nf, relu_post=1)
+        for k in range(self.n_bev_layers):
+            self.conv(L[f"bev{k + 1}"], fa, nf, self.nbr_bev, nsite, fb, nf, relu_post=1)
+            fa, fb = fb, fa
+        upc = self.up_ch
+        upf = E((nsite, 4 * upc))  # rows [y][x], columns [ky][kx][co]  == (4*nsite, upc) sub-site rows
+        self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
+        ncell = 4 * nsite
+        head = E((ncell, self.head_ld))
+        self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld)
+        H2, W2 = 2 * self.bevH, 2 * self.bevW
+        cb, cs = E((self.pre_max, 7)), E((self.pre_max,))
+        cl, cc = E((self.pre_max,), torch.int32), E((self.pre_max,), torch.int32)
+        cnt_c = E((4,), torch.int32)
+        w = self._workspace(lib.insmos_center_decode_select_ws_bytes(ncell))
+        _lib.check(lib.insmos_center_decode_select(head.data_ptr(), self.head_ld, ncls, H2, W2, 2, self.out_factor,
+                                                   self.tvs[0], self.tvs[1], self.range[0], self.range[1],
+                                                   self.score_thresh, self.pre_max, cb.data_ptr(), cs.data_ptr(),
+                                                   cl.data_ptr(), cc.data_ptr(), cnt_c.data_ptr(), w.data_ptr(), w.numel(),
+                                                   st), "insmos_center_decode_select")
+        keep = E((self.post_max,), torch.int32)
+        cnt_k = E((4,), torch.int32)
+        w = self._workspace(lib.insmos_nms_ws_bytes(self.pre_max))
+        _lib.check(lib.insmos_nms_rotated_bev(cb.data_ptr(), cnt_c.data_ptr(), self.pre_max, self.nms_thresh,
+                                              self.post_max, keep.data_ptr(), cnt_k.data_ptr(), w.data_ptr(), w.numel(),
+                                              st), "insmos_nms_rotated_bev")
+        pb, psc = E((self.post_max, 7)), E((self.post_max,))
+        pl = E((self.post_max,), torch.int64)
+        _lib.check(lib.insmos_gather_preds(cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), keep.data_ptr(),
+                                           cnt_k.data_ptr(), self.post_max, pb.data_ptr(), psc.data_ptr(), pl.data_ptr(),
+                                           st), "insmos_gather_preds")
+        self._head_debug = dict(head=head, cand_boxes=cb, cand_scores=cs, cand_labels=cl, cand_cell=cc, n_cand=cnt_c,
+                                keep=keep, spatial_features_2d=upf, bev=bev)
+
+        # ---- upsample fusion (spconv_unet.py:319-402)
+        scratch = E((16 * self.post_max,), torch.int32)
+        lo = np.array(self.range[0:3], dtype=np.float32)
+
+        def onehot(level, mult, out, ld, col):
+            _lib.check(lib.insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), cnt_k.data_ptr(), self.post_max, _hp(lo),
+                                                  _hp(vsz), 8.0, float(mult), coords[level].data_ptr(), nv[level], ncls,
+                                                  4, 1 if self.quirk_exact else 0, out.data_ptr() + 4 * col, ld,
+                                                  scratch.data_ptr(), st), "insmos_boxes_to_onehot")
+
+        def ur_block(lvl, C, x_lat, ld_lat, catm):
+            """UR_block_forward up to (not including) conv_inv; catm[:, 0:C] already holds x_bottom."""
+            t = E((nv[lvl], C))
+            self.conv(L[f"conv_up_t{lvl}.conv1"], x_lat, ld_lat, subm[lvl], nv[lvl], t, C, relu_post=1)
+            self.conv(L[f"conv_up_t{lvl}.conv2"], t, C, subm[lvl], nv[lvl], catm, 2 * C, col_out=C, res=x_lat,
+                      ld_res=ld_lat, res_mode=1, relu_post=1)
+            m = E((nv[lvl], C))
+            self.conv(L[f"conv_up_m{lvl}.0"], catm, 2 * C, subm[lvl], nv[lvl], m, C, res=catm, ld_res=2 * C,
+                      res_mode=2, relu_pre=1)
+            return m
+
+        ci4 = E((nv[4], 132))
+        self.conv(L["inv_conv_out"], enc, 128, inv5, nv[4], ci4, 132)
+        onehot(4, 1.0, ci4, 132, 128)
+        catm4 = E((nv[4], 256))
+        self.conv(L["conv_up_instance_block.0"], ci4, 132, subm[4], nv[4], catm4, 256, relu_post=1)
+        m4 = ur_block(4, 128, catm4, 256, catm4)
+        ci3 = E((nv[3], 68))
+        self.conv(L["inv_conv4.0"], m4, 128, inv[4], nv[3], ci3, 68, relu_post=1)
+        onehot(3, 2.0, ci3, 68, 64)
+        catm3 = E((nv[3], 128))
+        self.conv(L["conv_up_instance_block_up4.0"], ci3, 68, subm[3], nv[3], catm3, 128, relu_post=1)
+        m3 = ur_block(3, 64, xc[3], 64, catm3)
+        ci2 = E((nv[2], 36))
+        self.conv(L["inv_conv3.0"], m3, 64, inv[3], nv[2], ci2, 36, relu_post=1)
+        onehot(2, 4.0, ci2, 36, 32)
+        catm2 = E((nv[2], 64))
+        self.conv(L["conv_up_instance_block_up3.0"], ci2, 36, subm[2], nv[2], catm2, 64, relu_post=1)
+        m2 = ur_block(2, 32, xc[2], 32, catm2)
+        ci1 = E((V, 20))
+        self.conv(L["inv_conv2.0"], m2, 32, inv[2], V, ci1, 20, relu_post=1)
+        onehot(1, 8.0, ci1, 20, 16)
+        catm1 = E((V, 32))
+        self.conv(L["conv_up_instance_block_up2.0"], ci1, 20, subm[1], V, catm1, 32, relu_post=1)
+        m1 = ur_block(1, 16, xc[1], 16, catm1)
+        ci0 = E((V, 20))
+        self.conv(L["conv_up_out.0.0"], m1, 16, subm[1], V, ci0, 20, relu_post=1)
+        onehot(1, 8.0, ci0, 20, 16)  # spconv_unet.py:401 re-uses the stride-1 instance features
+        seg = E((V, 16))
+        self.conv(L["conv_up_instance_block_up1.0"], ci0, 20, subm[1], V, seg, 16, relu_post=1)
+        vox_logits = E((V, 4))
+        self.conv(L["mos_seg"], seg, 16, None, V, vox_logits, 4)
+        logits = E((ncur, 3))
+        _lib.check(lib.insmos_gather_rows(vox_logits.data_ptr(), 4, 3, pcid.data_ptr(), ncur, logits.data_ptr(), 3, st),
+                   "insmos_gather_rows")
+        K = int(cnt_k[0].item())  # the one unavoidable read-back: output tensors are sized by it
+        self.last_counts["n_boxes"] = K
+        self.last_counts["n_candidates"] = int(cnt_c[0].item())
+        self._un_debug = dict(xc=xc, enc=enc, ci4=ci4, ci3=ci3, ci2=ci2, ci1=ci1, seg=seg, vox_logits=vox_logits,
+                              m=[m1, m2, m3, m4])
+        pred = {"pred_boxes": pb[:K], "pred_scores": psc[:K], "pred_labels": pl[:K]}
+        return logits, pred
+
+    # ------------------------------------------------------------------------------------------------
+    def forward_window(self, pts):
+        """One batch item of InsMOS_Model.forward(..., 'test') (models/models.py:313-364)."""
+        if pts.dtype != torch.float32 or pts.device.type != "cuda" or pts.dim() != 2 or pts.shape[1] < 5:
+            raise ValueError("past_point_clouds must be a float32 CUDA tensor of shape (N, 5) [x,y,z,intensity,t]")
+        if pts.stride(1) != 1:
+            pts = pts.contiguous()
+        self._conv_log = []
+        cur = self.motionnet(pts)
+        return self.unet(cur)
+
+    def algorithmic_work(self):
+        """Algorithmic work of the LAST forward_window over all sparse_conv launches:
+        flops = sum 2*pairs*Cin*Cout, gather bytes = sum 4*pairs*(Cin+Cout) + 8*pairs.  pairs = valid
+        entries of the layer's neighbour table (n_out for 1x1 layers).  Costs a device reduction per
+        distinct table: bench/profiling only."""
+        cache = {}
+        flops = gather = pairs_total = 0
+        for nbr, n_out, layer in self._conv_log:
+            if nbr is None:
+                pairs = n_out
+            else:
+                key = nbr.data_ptr()
+                if key not in cache:
+                    cache[key] = int((nbr >= 0).sum().item())
+                pairs = cache[key]
+            cin = layer.flops_per_pair // (2 * layer.cout_real)
+            flops += pairs * layer.flops_per_pair
+            gather += 4 * pairs * (cin + layer.cout_real) + 8 * pairs
+            pairs_total += pairs
+        return {"flops": flops, "gather_bytes": gather, "pairs": pairs_total, "launches": len(self._conv_log)}

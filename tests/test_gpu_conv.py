@@ -1,0 +1,89 @@
+"""-m gpu: the MFMA sparse-conv kernel against the oracle's C conv (same fp32 inputs; tolerance covers
+summation order only) and against torch conv2d / conv_transpose2d for the dense BEV use."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _rand_nbr(rng, K, n_out, n_in, density):
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    nbr[rng.uniform(size=(K, n_out)) > density] = -1
+    return nbr
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out,density", [
+    (8, 8, 81, 1000, 0.2), (1, 8, 125, 777, 0.15), (16, 8, 81, 513, 0.2), (24, 16, 81, 300, 0.3),
+    (48, 32, 81, 260, 0.3), (32, 32, 8, 4000, 0.13), (7, 16, 27, 2000, 0.3), (131, 128, 27, 500, 0.4),
+    (67, 64, 27, 300, 0.4), (35, 32, 27, 300, 0.4), (19, 16, 27, 129, 0.4), (256, 128, 27, 200, 0.5),
+    (128, 128, 3, 64, 0.7), (16, 3, 1, 1000, 1.0), (8, 3, 1, 70, 1.0), (64, 64, 27, 70000, 0.25)])
+def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
+    from gpu_util import dev, pack_layer, run_conv
+    rng = np.random.default_rng(cin * 1000 + cout)
+    identity = (K == 1)
+    n_in = n_out if identity else max(n_out // 2, 50)
+    cin_pad = (cin + 3) // 4 * 4
+    x = np.zeros((n_in, cin_pad), np.float32)
+    x[:, :cin] = rng.normal(size=(n_in, cin))
+    x[:, cin:] = 7.0  # padded columns must be neutral (their taps are zero)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * density + 1)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    nbr = None if identity else _rand_nbr(rng, K, n_out, n_in, density)
+    layer = pack_layer(taps, bias, cin_pad, cout)
+    y = run_conv(layer, dev(x), None if identity else dev(nbr), n_out).cpu().numpy()
+    ref = R.sparse_conv(x[:, :cin], nbr, taps) + bias
+    np.testing.assert_allclose(y[:, :cout], ref, **TOL)
+
+
+def test_epilogue_variants_and_column_slices():
+    from gpu_util import dev, pack_layer, run_conv
+    rng = np.random.default_rng(5)
+    n, cin, cout, K = 700, 32, 16, 27
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    nbr = _rand_nbr(rng, K, n, n, 0.3)
+    layer = pack_layer(taps, bias, cin, cout)
+    base = R.sparse_conv(x, nbr, taps) + bias
+    res = rng.normal(size=(n, cout)).astype(np.float32)
+    y = run_conv(layer, dev(x), dev(nbr), n, res=dev(res), res_mode=1, relu_post=1).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(base + res, 0), **TOL)
+    res2 = rng.normal(size=(n, 2 * cout)).astype(np.float32)
+    y = run_conv(layer, dev(x), dev(nbr), n, res=dev(res2), res_mode=2, relu_pre=1).cpu().numpy()
+    np.testing.assert_allclose(y, np.maximum(base, 0) + res2.reshape(n, cout, 2).sum(2), **TOL)
+    # write into a column slice of a wider row; the other columns must stay untouched
+    out = torch.full((n, 40), -5.0, device="cuda:0")
+    run_conv(layer, dev(x), dev(nbr), n, ld_out=40, col_out=20, relu_post=1, out=out)
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[:, 20:36], np.maximum(base, 0), **TOL)
+    assert np.all(o[:, :20] == -5.0) and np.all(o[:, 36:] == -5.0)
+
+
+def test_dense_bev_convs_match_torch():
+    """3x3 pad-1 Conv2d, ConvTranspose2d(2,2) and the 1x1 heads through the sparse-conv kernel (NHWC)."""
+    from gpu_util import dev, pack_layer, run_conv, lib, stream
+    from insmos_amd import params as P, _lib
+    rng = np.random.default_rng(9)
+    H, W, ci, co = 13, 17, 32, 48
+    x = rng.normal(size=(1, ci, H, W)).astype(np.float32)
+    w = (rng.normal(size=(co, ci, 3, 3)) * 0.1).astype(np.float32)
+    nbr = torch.empty((9, H * W), dtype=torch.int32, device="cuda:0")
+    _lib.check(lib().insmos_dense_nbr2d(H, W, nbr.data_ptr(), stream()), "dense_nbr2d")
+    layer = pack_layer(P.conv2d_weight_to_taps(w), None, ci, co)
+    xs = np.ascontiguousarray(x[0].transpose(1, 2, 0).reshape(H * W, ci))
+    y = run_conv(layer, dev(xs), nbr, H * W).cpu().numpy()
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1)[0].permute(1, 2, 0).reshape(H * W, co).numpy()
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4)
+    wt = (rng.normal(size=(ci, co, 2, 2)) * 0.1).astype(np.float32)
+    tt = P.convT2d_weight_to_taps(wt)
+    wide = np.ascontiguousarray(tt.transpose(1, 0, 2).reshape(1, ci, 4 * co))
+    lt = pack_layer(wide, None, ci, 4 * co)
+    yt = run_conv(lt, dev(xs), None, H * W).cpu().numpy().reshape(H, W, 2, 2, co)
+    reft = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), stride=2)[0].permute(1, 2, 0).numpy()
+    got = yt.transpose(0, 2, 1, 3, 4).reshape(2 * H, 2 * W, co)
+    np.testing.assert_allclose(got, reft, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,130 @@
+"""-m gpu: coordinate kernels (quantise / levels / voxelise / strided sets / neighbour tables) against
+the oracle, bit-exact (integer work)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def window():
+    from insmos_amd.synth import make_window
+    return make_window(seed=3, n_scans=10, n_az=256)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from insmos_amd import params as P
+    from insmos_amd.engine import Engine
+    cfg = P.default_cfg()
+    return Engine(cfg, P.random_state_dict(cfg, 0))
+
+
+def test_quantize_levels_and_tables(window, engine):
+    from gpu_util import dev, u64
+    pts = dev(window)
+    cur = engine.motionnet(pts)
+    torch.cuda.synchronize()
+    T = engine._me_tables
+    pts4 = np.concatenate([window[:, :3], window[:, 4:5]], 1)
+    c, k, inv = R.me_quantize(pts4, [0.1, 0.1, 0.1, 0.1])
+    np.testing.assert_array_equal(T["coords"][0].cpu().numpy(), c)
+    np.testing.assert_array_equal(u64(T["keys"][0]), k)
+    np.testing.assert_array_equal(T["inverse"].cpu().numpy(), inv)
+    lv = [(c, k)]
+    for L in (1, 2, 3):
+        pc, pk, _ = R.me_stride_down(c, k, L)
+        np.testing.assert_array_equal(T["coords"][L].cpu().numpy(), pc)
+        np.testing.assert_array_equal(u64(T["keys"][L]), pk)
+        lv.append((pc, pk))
+    np.testing.assert_array_equal(T["nbr125"].cpu().numpy(), R.me_nbr(c, k, R.me_kernel_offsets([5, 5, 5, 1], [1] * 4)))
+    for L in range(4):
+        s = 1 << L
+        np.testing.assert_array_equal(T["nbr81"][L].cpu().numpy(),
+                                      R.me_nbr(lv[L][0], lv[L][1], R.me_kernel_offsets([3, 3, 3, 3], [s, s, s, 1])))
+    for L in range(3):
+        s = 1 << L
+        off = R.me_kernel_offsets([2, 2, 2, 1], [s, s, s, 1])
+        np.testing.assert_array_equal(T["dn"][L].cpu().numpy(), R.me_nbr(lv[L + 1][0], lv[L][1], off, +1))
+        np.testing.assert_array_equal(T["up"][L].cpu().numpy(), R.me_nbr(lv[L][0], lv[L + 1][1], off, -1))
+    ncur = int((window[:, 4] == 0).sum())
+    assert cur.shape == (ncur, 8)
+    np.testing.assert_array_equal(cur[:, :4].cpu().numpy(), window[window[:, 4] == 0][:, :4])
+
+
+@pytest.mark.parametrize("max_voxels", [100000, 1500])
+def test_voxelize_and_3d_tables(window, engine, max_voxels):
+    from gpu_util import dev
+    rng = np.random.default_rng(0)
+    curp = window[window[:, 4] == 0]
+    cur8 = np.concatenate([curp[:, :4], rng.normal(size=(len(curp), 3)).astype(np.float32),
+                           np.zeros((len(curp), 1), np.float32)], 1)
+    old = engine.max_voxels
+    engine.max_voxels = max_voxels
+    try:
+        engine._conv_log = []
+        engine.unet(dev(cur8))
+        torch.cuda.synchronize()
+    finally:
+        engine.max_voxels = old
+    T = engine._un_tables
+    vox, co, num, pid = R.voxelize_with_id(cur8[:, :7], [0.1] * 3, [-60, -50, -3, 60, 50, 1], max_voxels, 5)
+    np.testing.assert_array_equal(T["coords"][1].cpu().numpy()[:, 1:], co)
+    assert int(T["coords"][1][:, 0].abs().sum()) == 0
+    np.testing.assert_array_equal(T["pcid"].cpu().numpy(), pid)
+    np.testing.assert_array_equal(T["num_points"].cpu().numpy(), num)
+    np.testing.assert_allclose(T["feat"].cpu().numpy()[:, :7], R.mean_vfe(vox, num), rtol=0, atol=1e-6)
+    assert float(T["feat"][:, 7].abs().sum()) == 0.0
+    shape = engine.shape
+    ks, perm = R.sorted_index(R.key3(co, shape[1]))
+    S = {1: (co, ks, perm, shape[1])}
+    for l in (2, 3, 4):
+        oc, ok, osz = R.spconv_down_coords(S[l - 1][0], S[l - 1][3], (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        assert osz == shape[l]
+        S[l] = (oc, ok, None, osz)
+        np.testing.assert_array_equal(T["coords"][l].cpu().numpy()[:, 1:], oc)
+    c5, k5, s5 = R.spconv_down_coords(S[4][0], S[4][3], (3, 1, 1), (2, 1, 1), (0, 0, 0))
+    np.testing.assert_array_equal(T["coords"][5].cpu().numpy()[:, 1:], c5)
+    for l in (1, 2, 3, 4):
+        np.testing.assert_array_equal(T["subm"][l].cpu().numpy(), R.spconv_nbr_subm(*S[l]))
+    for l in (2, 3, 4):
+        np.testing.assert_array_equal(T["down"][l].cpu().numpy(),
+                                      R.spconv_nbr_down(S[l][0], S[l - 1][1], S[l - 1][2], S[l - 1][3], (3, 3, 3),
+                                                        (2, 2, 2), (1, 1, 1)))
+        np.testing.assert_array_equal(T["inv"][l].cpu().numpy(),
+                                      R.spconv_nbr_inverse(S[l - 1][0], S[l][1], None, S[l][3], (3, 3, 3), (2, 2, 2),
+                                                           (1, 1, 1)))
+    np.testing.assert_array_equal(T["down5"].cpu().numpy(),
+                                  R.spconv_nbr_down(c5, S[4][1], None, S[4][3], (3, 1, 1), (2, 1, 1), (0, 0, 0)))
+    np.testing.assert_array_equal(T["inv5"].cpu().numpy(),
+                                  R.spconv_nbr_inverse(S[4][0], k5, None, s5, (3, 1, 1), (2, 1, 1), (0, 0, 0)))
+
+
+def test_quantize_edge_cases():
+    """negative coordinates, exact voxel boundaries, duplicate points, t rounding (-0.3/0.1 etc.)."""
+    from gpu_util import dev, lib, stream, ws, hp, u64
+    from insmos_amd import _lib
+    pts = np.array([[0.0, 0.0, 0.0, 0.5, 0.0], [-0.0, -0.05, 0.1, 0.5, -0.3], [0.1, 0.2, 0.3, 0.1, -0.3],
+                    [0.1, 0.2, 0.3, 0.9, -0.3], [-12.34, 56.78, -1.0, 0.2, -0.9], [79.99, -79.99, 3.3, 0.3, -0.7],
+                    [0.30000001, 0.6, 0.7, 0.2, -0.1], [0.29999998, 0.6, 0.7, 0.2, -0.1], [1e-8, -1e-8, 0, 0, 0.0]],
+                   np.float32)
+    n = len(pts)
+    d = dev(pts)
+    keys = torch.empty(n, dtype=torch.int64, device="cuda:0")
+    coords = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
+    inv = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    cur = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    counts = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    w = ws(lib().insmos_quantize4d_ws_bytes(n))
+    q = np.array([0.1, 0.1, 0.1, 0.1], np.float32)
+    _lib.check(lib().insmos_quantize4d(d.data_ptr(), n, 5, hp(q), keys.data_ptr(), coords.data_ptr(), inv.data_ptr(),
+                                       cur.data_ptr(), counts.data_ptr(), w.data_ptr(), w.numel(), stream()), "quant")
+    c, k, i = R.me_quantize(np.concatenate([pts[:, :3], pts[:, 4:5]], 1), q)
+    V, ncur = int(counts[0]), int(counts[1])
+    assert V == len(c) and int(counts[2]) == 0
+    np.testing.assert_array_equal(coords[:V].cpu().numpy(), c)
+    np.testing.assert_array_equal(inv.cpu().numpy(), i)
+    np.testing.assert_array_equal(cur[:ncur].cpu().numpy(), np.nonzero((pts[:, 4] / q[3]) == 0)[0])

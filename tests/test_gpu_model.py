@@ -1,0 +1,107 @@
+"""-m gpu: end-to-end parity of the HIP path against the oracle on a seeded synthetic window, through
+the reference-shaped API (InsMOSNet.load_from_checkpoint(...).cuda().eval().forward(list, 'test')).
+Tolerances: logits 1e-3 abs fp32 (north star), labels exact after argmax, boxes 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as M
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(tmp_path_factory):
+    from insmos_amd import params as P
+    from insmos_amd.models import InsMOSNet, save_checkpoint
+    from insmos_amd.synth import make_window
+    from model_util import detecting_state_dict
+    cfg = P.default_cfg()
+    window = make_window(seed=5, n_scans=10, n_az=256)
+    sd = detecting_state_dict(cfg, window, seed=0)
+    path = os.path.join(tmp_path_factory.mktemp("ckpt"), "synthetic.ckpt")
+    save_checkpoint(path, cfg, sd)
+    hparams = torch.load(path, weights_only=False)["hyper_parameters"]  # predict_mos.py:288
+    model = InsMOSNet.load_from_checkpoint(path, hparams=hparams).cuda().eval()
+    ref_logits, ref_pred, dbg = M.forward_window(sd, cfg, window, want_debug=True)
+    return dict(cfg=cfg, window=window, sd=sd, model=model, ref_logits=ref_logits, ref_pred=ref_pred, dbg=dbg)
+
+
+def test_forward_signature_and_parity(setup):
+    model, window = setup["model"], setup["window"]
+    batch = [{"past_point_clouds": torch.from_numpy(window).cuda(), "meta": (8, 0, ["000009.bin"]),
+              "batch_size_npast": 10}]
+    with torch.no_grad():
+        pred_list, recall_list, logits_list = model.forward(batch, "test")
+    torch.cuda.synchronize()
+    assert len(pred_list) == len(recall_list) == len(logits_list) == 1
+    assert recall_list[0] == {}
+    pred = pred_list[0][0]
+    assert set(pred) == {"pred_boxes", "pred_scores", "pred_labels"}
+    assert pred["pred_labels"].dtype == torch.int64 and pred["pred_boxes"].shape[1] == 7
+    logits = logits_list[0].cpu().numpy()
+    ref_logits, ref_pred, dbg = setup["ref_logits"], setup["ref_pred"], setup["dbg"]
+    eng = model.model.engine
+    # --- stage checks (sharper diagnostics than the end result)
+    cur_ref = dbg["current_point"]
+    assert logits.shape == ref_logits.shape == (len(cur_ref), 3)
+    np.testing.assert_allclose(eng._me_debug["motion"].cpu().numpy()[:, :3], dbg["motion"]["voxel_motion"], atol=2e-4,
+                               rtol=1e-3)
+    np.testing.assert_allclose(eng._un_debug["enc"].cpu().numpy(), dbg["unet"]["encoded"], atol=2e-4, rtol=1e-3)
+    head = eng._head_debug["head"].cpu().numpy()
+    H2, W2 = 2 * eng.bevH, 2 * eng.bevW
+    hm = head.reshape(eng.bevH, eng.bevW, 2, 2, -1).transpose(0, 2, 1, 3, 4).reshape(H2 * W2, -1)
+    np.testing.assert_allclose(hm[:, :3], dbg["unet"]["cls"], atol=2e-3, rtol=1e-3)  # cls weights are x1000 here
+    K = len(ref_pred["pred_boxes"])
+    assert K > 5, "test checkpoint must produce detections"
+    assert pred["pred_boxes"].shape[0] == K
+    np.testing.assert_array_equal(pred["pred_labels"].cpu().numpy(), ref_pred["pred_labels"])
+    np.testing.assert_allclose(pred["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"], atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(pred["pred_scores"].cpu().numpy(), ref_pred["pred_scores"], atol=2e-3)
+    for lvl, name in ((4, "ci4"), (3, "ci3"), (2, "ci2"), (1, "ci1")):
+        oh = eng._un_debug[name].cpu().numpy()[:, -4:-1]
+        np.testing.assert_array_equal(oh, dbg["unet"]["onehots"][lvl])
+    assert sum(int(dbg["unet"]["onehots"][l].sum()) for l in (1, 2, 3, 4)) > 0, "instance features must be exercised"
+    # --- the north-star bar
+    np.testing.assert_allclose(logits, ref_logits, atol=1e-3, rtol=0)
+    lab, conf = R.output_stage(logits)
+    lab_ref, conf_ref = R.output_stage(ref_logits)
+    np.testing.assert_array_equal(lab, lab_ref)
+    # MOS IoU parity through the on-device confusion matrix
+    from insmos_amd.metrics import ClassificationMetrics
+    from insmos_amd.synth import make_labels
+    gt = make_labels(cur_ref, seed=5)
+    met = ClassificationMetrics(3, [0])
+    cm = met.compute_confusion_matrix(logits_list[0], torch.from_numpy(gt).cuda())
+    np.testing.assert_array_equal(cm.cpu().numpy(), R.confusion_matrix(ref_logits, gt))
+    np.testing.assert_allclose(met.getIoU(cm).cpu().numpy(), R.iou_from_confusion(R.confusion_matrix(ref_logits, gt)),
+                               rtol=1e-6)
+
+
+def test_idempotent_and_batch_of_two(setup):
+    """Same window twice in one list -> identical results (deterministic kernels, no atomics in the sums)."""
+    model, window = setup["model"], setup["window"]
+    t = torch.from_numpy(window).cuda()
+    a, _, la = model.forward([{"past_point_clouds": t}, {"past_point_clouds": t.clone()}], "test")
+    torch.cuda.synchronize()
+    assert torch.equal(la[0], la[1])
+    assert torch.equal(a[0][0]["pred_boxes"], a[1][0]["pred_boxes"])
+
+
+def test_n1_window_and_no_detection_checkpoint(setup):
+    """cfg-1 shape: a single scan (N=1, t==0 only) and the default head bias (no detections)."""
+    from insmos_amd import params as P
+    from insmos_amd.models import InsMOSNet
+    from insmos_amd.synth import make_window
+    cfg = setup["cfg"]
+    w1 = make_window(seed=2, n_scans=1, n_az=256)
+    sd = P.random_state_dict(cfg, 1)
+    model = InsMOSNet(cfg, state_dict=sd).cuda().eval()
+    pred, _, logits = model.forward([{"past_point_clouds": torch.from_numpy(w1).cuda()}], "test")
+    ref_logits, ref_pred = M.forward_window(sd, cfg, w1)
+    assert pred[0][0]["pred_boxes"].shape == (0, 7) and len(ref_pred["pred_boxes"]) == 0
+    np.testing.assert_allclose(logits[0].cpu().numpy(), ref_logits, atol=1e-3, rtol=0)
+    np.testing.assert_array_equal(R.output_stage(logits[0].cpu().numpy())[0], R.output_stage(ref_logits)[0])

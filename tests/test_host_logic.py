@@ -1,0 +1,159 @@
+"""CPU-only: the C-ABI library loads and exports every declared symbol; host-side weight packing matches
+the MFMA fragment convention the kernel assumes; checkpoint layout conversions; rank sharding and the
+confusion-counter all_gather on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from insmos_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from insmos_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "insmos_hip.h")).read()
+    declared = set(re.findall(r"\b(insmos_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.insmos_version() >= 100
+
+
+def _emulate_conv(packed, K, cin, cout, x, nbr):
+    """Numpy emulation of k_sparse_conv's contraction straight from the PACKED weights: one MFMA step s of a
+    block contracts, for lane group g, input channel c0 + width*g + s with A = packed[k][blk][tile][lane][s]."""
+    n16, rem = cin // 16, cin % 16
+    blocks = [(c * 16, 4) for c in range(n16)]
+    c0 = n16 * 16
+    if rem & 8:
+        blocks.append((c0, 2)); c0 += 8
+    if rem & 4:
+        blocks.append((c0, 1))
+    ntile = (cout + 15) // 16
+    pk = packed.reshape(K, len(blocks), ntile, 64, 4)
+    n_out = nbr.shape[1]
+    out = np.zeros((n_out, ntile * 16), np.float64)
+    for k in range(K):
+        valid = nbr[k] >= 0
+        rows = x[np.where(valid, nbr[k], 0)] * valid[:, None]
+        for b, (cb, width) in enumerate(blocks):
+            for s in range(width):
+                for g in range(4):
+                    ch = cb + width * g + s
+                    for t in range(ntile):
+                        a = pk[k, b, t, g * 16:(g + 1) * 16, s]  # A[i = lane&15] for this lane group
+                        out[:, t * 16:(t + 1) * 16] += rows[:, ch:ch + 1] * a[None, :]
+    return out[:, :cout]
+
+
+@pytest.mark.parametrize("cin_real,cout_real,K", [(8, 8, 5), (1, 8, 3), (7, 16, 4), (19, 16, 3), (35, 32, 2), (48, 32, 2),
+                                                  (24, 16, 3), (131, 24, 2), (16, 3, 1), (128, 11, 1)])
+def test_weight_packing_matches_fragment_convention(lib, cin_real, cout_real, K):
+    from oracle import ref_ops as R
+    rng = np.random.default_rng(cin_real * 7 + cout_real)
+    cin = (cin_real + 3) // 4 * 4
+    cout = cout_real if cout_real % 4 == 0 else (cout_real + 3) // 4 * 4
+    taps = rng.normal(size=(K, cin_real, cout_real)).astype(np.float32)
+    n = lib.insmos_packed_weight_floats(K, cin, cout)
+    packed = np.full(n, np.nan, np.float32)
+    assert lib.insmos_pack_weights_host(taps.ctypes.data, K, cin_real, cout_real, cin, cout, packed.ctypes.data) == 0
+    assert not np.isnan(packed).any()
+    n_in, n_out = 40, 33
+    x = np.zeros((n_in, cin), np.float32)
+    x[:, :cin_real] = rng.normal(size=(n_in, cin_real))
+    x[:, cin_real:] = 3.0  # padded channels carry junk; their taps must be zero
+    nbr = rng.integers(-1, n_in, size=(K, n_out)).astype(np.int32)
+    got = _emulate_conv(packed, K, cin, cout, x.astype(np.float64), nbr)
+    ref = R.sparse_conv(x[:, :cin_real], nbr, taps)
+    np.testing.assert_allclose(got[:, :cout_real], ref, rtol=1e-4, atol=1e-4)
+    assert np.all(got[:, cout_real:] == 0)
+    assert lib.insmos_pack_weights_host(taps.ctypes.data, K, cin_real, cout_real, cin + 1, cout, packed.ctypes.data) == -1
+
+
+def test_checkpoint_spec_and_layout_conversions():
+    from insmos_amd import params as P
+    cfg = P.default_cfg()
+    sd = P.random_state_dict(cfg, 3)
+    spec = P.param_spec(cfg)
+    assert list(sd) == list(spec)
+    for k, (shape, _) in spec.items():
+        assert sd[k].shape == tuple(shape) and sd[k].dtype == np.float32
+    assert sum(v.size for v in sd.values()) > 4_000_000  # ~4.8 M UNetV2 + BEV + MotionNet parameters
+    w = np.arange(2 * 3 * 1 * 2 * 5, dtype=np.float32).reshape(2, 3, 1, 2, 5)  # (Cout,kz,ky,kx,Cin)
+    t = P.spconv_weight_to_taps(w)
+    assert t.shape == (6, 5, 2)
+    assert t[3, 4, 1] == w[1, 1, 0, 1, 4]  # k = (kz*KH + ky)*KW + kx = (1*1+0)*2+1 = 3
+    w2 = np.arange(4 * 3 * 3 * 3, dtype=np.float32).reshape(4, 3, 3, 3)
+    assert P.conv2d_weight_to_taps(w2)[5, 2, 1] == w2[1, 2, 1, 2]  # tap = ky*3 + kx
+    wt = np.arange(3 * 4 * 2 * 2, dtype=np.float32).reshape(3, 4, 2, 2)
+    assert P.convT2d_weight_to_taps(wt)[2, 1, 3] == wt[1, 3, 1, 0]
+    taps, shift = P.fold_bn(np.ones((1, 2, 3), np.float32), [2, 2, 2], [1, 1, 1], [0.5, 0.5, 0.5], [3, 3, 3], 1.0)
+    np.testing.assert_allclose(taps, 1.0)  # 2/sqrt(3+1) = 1
+    np.testing.assert_allclose(shift, 0.5)
+
+
+def test_models_surface_fails_loudly_without_gpu(tmp_path):
+    import torch
+    from insmos_amd import params as P
+    from insmos_amd.models import InsMOSNet, save_checkpoint
+    cfg = P.default_cfg()
+    path = str(tmp_path / "x.ckpt")
+    save_checkpoint(path, cfg, P.random_state_dict(cfg, 0))
+    m = InsMOSNet.load_from_checkpoint(path, hparams=cfg)
+    assert m.n_mos_classes == 3 and m.ignore_index == [0]
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.cuda()
+    with pytest.raises(KeyError):
+        InsMOSNet(cfg, state_dict={})
+
+
+def test_shard_indices():
+    from insmos_amd.metrics import shard_indices
+    parts = [shard_indices(10, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(10))
+    assert parts[1] == [1, 5, 9]
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from insmos_amd.metrics import all_gather_confusion, shard_indices
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cm = torch.zeros((3, 3), dtype=torch.int64)
+for w in shard_indices(7, rank, world):          # windows owned by this rank
+    cm[w % 3, (w * 2) % 3] += w + 1
+tot = all_gather_confusion(cm)
+exp = torch.zeros((3, 3), dtype=torch.int64)
+for w in range(7):
+    exp[w % 3, (w * 2) % 3] += w + 1
+assert torch.equal(tot, exp), (tot, exp)
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_confusion_all_gather_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, ROOT], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o
