@@ -108,6 +108,7 @@ class Engine:
         if self.up != 2:
             raise NotImplementedError("BEV deconv stride 2 only (config.yaml:118)")
         self._ws = None
+        self._conv_log = []
         self._load_weights(state_dict)
         self._static_tables()
         self.last_counts = {}

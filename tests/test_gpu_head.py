@@ -20,7 +20,8 @@ def _iou(a, b):
     from gpu_util import dev, lib, stream
     from insmos_amd import _lib
     out = torch.empty((len(a), len(b)), device=D)
-    _lib.check(lib().insmos_iou_bev(dev(a).data_ptr(), len(a), dev(b).data_ptr(), len(b), out.data_ptr(), stream()), "iou")
+    da, db = dev(a), dev(b)  # keep both alive: temporaries would share one allocation
+    _lib.check(lib().insmos_iou_bev(da.data_ptr(), len(a), db.data_ptr(), len(b), out.data_ptr(), stream()), "iou")
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -92,7 +93,8 @@ def test_decode_select_nms_vs_reference_golden(golden_dir):
     cl = torch.empty(pre_max, dtype=torch.int32, device=D); cc = torch.empty(pre_max, dtype=torch.int32, device=D)
     cnt = torch.zeros(4, dtype=torch.int32, device=D)
     w = ws(lib().insmos_center_decode_select_ws_bytes(n))
-    _lib.check(lib().insmos_center_decode_select(dev(head).data_ptr(), 12, 3, H, W, 1, 1.0, 1.0, 1.0, 0.0, 0.0, 0.1,
+    dhead = dev(head)
+    _lib.check(lib().insmos_center_decode_select(dhead.data_ptr(), 12, 3, H, W, 1, 1.0, 1.0, 1.0, 0.0, 0.0, 0.1,
                                                  pre_max, cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), cc.data_ptr(),
                                                  cnt.data_ptr(), w.data_ptr(), w.numel(), stream()), "decode")
     keep = torch.empty(post_max, dtype=torch.int32, device=D)
@@ -127,8 +129,9 @@ def _onehot(coords_xyz, boxes8, quirk=True):
     out = torch.full((n, 4), -1.0, device=D)
     scratch = torch.empty(16 * mb, dtype=torch.int32, device=D)
     lo = np.zeros(3, np.float32); vs = np.ones(3, np.float32)
+    dc4 = dev(c4)
     _lib.check(lib().insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), nd.data_ptr(), mb, hp(lo), hp(vs), 1.0, 1.0,
-                                            dev(c4).data_ptr(), n, 3, 4, 1 if quirk else 0, out.data_ptr(), 4,
+                                            dc4.data_ptr(), n, 3, 4, 1 if quirk else 0, out.data_ptr(), 4,
                                             scratch.data_ptr(), stream()), "onehot")
     torch.cuda.synchronize()
     o = out.cpu().numpy()
@@ -154,8 +157,9 @@ def test_confusion_and_gather(golden_dir):
     g = G(golden_dir, "metrics.npz")
     cm = torch.zeros(9, dtype=torch.int64, device=D)
     lg = dev(g["logits"])
+    dgt = dev(g["gt"])
     for _ in range(2):  # accumulates
-        _lib.check(lib().insmos_confusion3(lg.data_ptr(), 3, dev(g["gt"]).data_ptr(), len(g["gt"]), 3, 1, cm.data_ptr(),
+        _lib.check(lib().insmos_confusion3(lg.data_ptr(), 3, dgt.data_ptr(), len(g["gt"]), 3, 1, cm.data_ptr(),
                                            stream()), "confusion")
     torch.cuda.synchronize()
     np.testing.assert_array_equal(cm.cpu().numpy().reshape(3, 3), 2 * g["cm"])
