@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-az", type=int, default=472)
+    ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,6 +177,16 @@ def main():
             if conv_ms_per_window else 0,
         }
         out["kernel_ms_per_window"] = {k: round(v[0] / nprof, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        if args.layer_times:
+            eng.layer_timing = []
+            model.forward(batch, "test")
+            torch.cuda.synchronize()
+            rows = [(nm, K, ci, co, n, e0.elapsed_time(e1) * 1000.0) for nm, K, ci, co, n, e0, e1 in eng.layer_timing]
+            eng.layer_timing = None
+            with open(args.layer_times, "w") as f:
+                f.write("layer,K,cin,cout,n_out,us\n")
+                for r in rows:
+                    f.write("%s,%d,%d,%d,%d,%.1f\n" % r)
         out["device_ms_per_window_sum"] = round(total_ms, 3)
 
         # ---- CPU baseline: the oracle (a port, not MinkowskiEngine) on a bounded sample of the same workload

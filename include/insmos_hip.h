@@ -80,10 +80,12 @@ int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* ou
  *   in_keys ascending (n_in); in_perm (n_in) maps sorted position -> input row (NULL = identity;
  *   an entry of -1 marks a voxel dropped by the max-voxel cap).
  *   delta_host (K,4) i32, mul_host[4], div_host[4] are HOST arrays (tiny, copied by value).
+ *   mask16 (optional, (ceil(n_out/16), 4) u32): bit k of group g is set iff some row of the 16-row
+ *   group g has a neighbour on tap k -- the active-tap sets insmos_sparse_conv iterates over.
  * ---------------------------------------------------------------------------------------------- */
 int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_perm,
                      int64_t n_in, int key_mode, const int32_t* in_shape_host, const int32_t* delta_host, int K,
-                     const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, void* stream);
+                     const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * insmos_voxelize_mean -- replaces spconv PointToVoxel.generate_voxel_with_id
@@ -128,7 +130,8 @@ int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* 
  * full-grid nbr table it also serves the dense BEV convs (base_bev_backbone.py:33-61) and the 1x1
  * heads (center_head.py:47-54) in NHWC.
  *   nbr == NULL  -> K must be 1, identity map (1x1 conv / Linear).
- *   cin must be a multiple of 4 (pad with zero columns); ld_in % 4 == 0 and `in` 16-byte aligned.
+ *   mask16: the table's active-tap sets from insmos_build_nbr, or NULL (every tap visited).
+ *   cin must be 4, 8 or a multiple of 16 (pad with ZERO columns); ld_in % 4 == 0, `in` 16-byte aligned.
  *   wpacked: tap-major MFMA-fragment layout produced by insmos_pack_weights_host (below).
  *   bias: (cout_pad16) fp32.
  * ---------------------------------------------------------------------------------------------- */
@@ -136,8 +139,8 @@ size_t insmos_packed_weight_floats(int K, int cin, int cout);
 /* Host helper: taps (K,cin_real,cout_real) fp32 row-major -> packed layout for (cin,cout) padded. */
 int insmos_pack_weights_host(const float* taps_host, int K, int cin_real, int cout_real, int cin, int cout,
                              float* packed_host);
-int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, int K, int64_t n_out,
-                       const float* wpacked, const float* bias, float* out, int ld_out, int cout,
+int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16, int K,
+                       int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
                        const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

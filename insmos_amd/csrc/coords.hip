@@ -147,7 +147,7 @@ template <int KEY_MODE>
 __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ out_coords, int64_t n_out,
                                                    const uint64_t* __restrict__ in_keys,
                                                    const int32_t* __restrict__ in_perm, int64_t n_in, NbrParams P,
-                                                   int32_t* __restrict__ nbr) {
+                                                   int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16) {
     int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int k = blockIdx.y;
     if (o >= n_out) return;
@@ -174,6 +174,12 @@ __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ o
         }
     }
     nbr[(int64_t)k * n_out + o] = r;
+    if (mask16) {
+        // active-tap bitmask per 16-row group (rows of a group are 16 consecutive lanes)
+        const unsigned long long bal = __ballot(r >= 0);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(o >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -397,7 +403,7 @@ extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, u
 extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys,
                                 const int32_t* in_perm, int64_t n_in, int key_mode, const int32_t* in_shape_host,
                                 const int32_t* delta_host, int K, const int32_t* mul_host, const int32_t* div_host,
-                                int32_t* nbr, void* stream) {
+                                int32_t* nbr, uint32_t* mask16, void* stream) {
     if (n_out <= 0 || K <= 0 || K > 128 || n_in < 0 || (key_mode != 0 && key_mode != 1)) return INSMOS_EINVAL;
     if (key_mode == 1 && !in_shape_host) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -414,10 +420,13 @@ extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const 
     P.K = K;
     dim3 grid(cdiv(n_out, TPB), (unsigned)K);
     ProfScope ps(KK_BUILD_NBR, s);
+    if (mask16) HIP_TRY(hipMemsetAsync(mask16, 0, (size_t)((n_out + 15) / 16) * 4 * sizeof(uint32_t), s));
     if (key_mode == 0)
-        hipLaunchKernelGGL(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr);
+        hipLaunchKernelGGL(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
+                           mask16);
     else
-        hipLaunchKernelGGL(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr);
+        hipLaunchKernelGGL(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
+                           mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

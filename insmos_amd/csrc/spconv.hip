@@ -2,21 +2,27 @@
 //
 //   out[o, :] = epilogue( sum_k  in[nbr[k][o], :] @ W[k]  + bias )
 //
-// One wave owns 64 consecutive output rows x (16*COT) output channels.  For every tap k the wave
-// reads its 64 neighbour indices (coalesced), skips the tap when none of its rows has that
-// neighbour (wave-uniform branch; outputs are Morton-/raster-ordered so taps are spatially
-// correlated), gathers the input rows straight into MFMA B-fragments (each lane one 16-byte
-// load per 16-channel chunk -- four 16-lane groups cover one 64-byte sector of a row) and streams the
-// pre-packed weight A-fragments (one coalesced 16-byte load per lane, L1/L2 resident).  The
-// contraction runs on v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain), i = output
-// channel, j = output row, so the accumulator of lane (g, j) holds 4 consecutive channels of row j
-// and the epilogue (folded-BN bias, ReLU, residual / channel-pair residual) stores one float4 per
-// tile.  No atomics, no scatter: results are deterministic.
+// One wave owns 16*JT consecutive output rows x 16*COT output channels (tile shape picked per layer
+// so that the launch keeps >= 2 waves per SIMD whenever the layer is big enough).  Taps are walked
+// through a per-16-row-group ACTIVE-TAP BITMASK produced when the neighbour table is built
+// (insmos_build_nbr): a tap none of the tile's rows uses is never touched, and inside a tile each
+// 16-row group skips its own empty taps (rows are Morton-/raster-ordered, so occupancy is spatially
+// coherent: ~50 % of (64-row tile, tap) slots and ~60 % of (16-row group, tap) slots are empty on
+// LiDAR data).  Because the active-tap list is known up front the loop is software-pipelined:
+// neighbour indices are fetched two taps ahead, the gathered rows (B fragments: one 16-byte load
+// per lane per 16-channel chunk; four 16-lane groups cover one 64-byte sector of a row) and the
+// pre-packed weight A fragments (one coalesced 16-byte load per lane, L1/L2 resident) one step
+// ahead of the MFMAs that consume them.  All offsets are 32-bit so loads use SGPR-base + VGPR-offset
+// addressing.  The contraction runs on v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain),
+// i = output channel, j = output row, so lane (g, j) ends up with 4 consecutive channels of row j and
+// the epilogue (folded-BN bias, ReLU, residual / channel-pair residual) is one float4 store per tile.
+// No atomics, no scatter: results are deterministic.
 //
-// Fragment maps used (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
-// B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4) + reg][j = lane&15].  The contraction index of one
-// MFMA step s inside a 16-channel chunk is channel c0 + 4*(lane>>4) + s (any assignment is legal as
-// long as A and B agree), which is what makes the gather a contiguous float4 per lane.
+// Fragment maps (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4) + reg][j = lane&15].  The contraction index of MFMA
+// step s inside a 16-channel chunk is channel c0 + 4*(lane>>4) + s (any assignment is legal as long
+// as A and B agree), which is what makes the gather a contiguous float4 per lane.
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
@@ -28,151 +34,232 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct ConvP {
     const float* in;
     const int32_t* nbr;
+    const uint32_t* mask16;  // [ceil(n_out/16)][4] active-tap bits per 16-row group, or null (all active)
     const float* w;
     const float* bias;
     float* out;
     const float* res;
-    int64_t n_out;
+    uint32_t n_out;
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
     int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
 };
 
-template <int COT>
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// next active tap of the 128-bit set, or `keep` when the set is exhausted (branch-free scalar code)
+__device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep) {
+    const bool use_lo = lo != 0;
+    const uint64_t w = use_lo ? lo : hi;
+    const int k = (w ? __builtin_ctzll(w) : 0) + (use_lo ? 0 : 64);
+    const uint64_t cleared = w & (w - 1);
+    const bool any = w != 0;
+    lo = use_lo ? cleared : lo;
+    hi = use_lo ? hi : cleared;
+    return any ? k : keep;
+}
+
+// CK == 0: Cin is a multiple of 16, a tap is Cin/16 chunks of 16 channels (4 MFMA steps each)
+// CK == 4 / 8: the whole contraction of a tap is ONE chunk of that width (small-C 4D layers)
+// IDENT: no neighbour table -- a 1x1 convolution / Linear (row o reads row o)
+//
+// The main loop is a COUNTED, branch-free two-stage software pipeline over work items (tap, chunk):
+// the operands of item i+1 are requested before the MFMAs of item i issue, and the neighbour indices
+// of the tap after next are already in flight.  Everything that could be a guard is a clamp instead:
+// rows past n_out re-read the last row, missing neighbours re-read row 0 and are zeroed by a select
+// right before the MFMA, and running off the end of the tap list re-requests the last item.  (Exec-
+// masked loads made hipcc wait vmcnt(0) inside each branch, and per-16-row-group skip branches made
+// it shuttle the accumulators between AGPRs and VGPRs every iteration; both cost far more than the
+// redundant work.)
+template <int COT, int JT, int CK, bool IDENT>
 __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-    const int n_cg = P.ntile_co / COT;
-    if (gw >= (int64_t)P.n_otiles * n_cg) return;  // wave-uniform
-    const int cg = (int)(gw / P.n_otiles);
-    const int64_t ot = gw % P.n_otiles;
+    // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
+    const uint32_t gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_cg = P.ntile_co / COT;
+    if (gw >= (uint32_t)P.n_otiles * n_cg) return;  // wave-uniform
+    const uint32_t cg = gw / P.n_otiles;
+    const uint32_t ot = gw % P.n_otiles;
     const int g = lane >> 4, j = lane & 15;
+    const float* __restrict__ in = P.in;
+    const int32_t* __restrict__ nbr = P.nbr;
+    const uint32_t n_out = P.n_out;
+    const uint32_t ld_in = P.ld_in;
 
-    int64_t orow[4];
+    uint32_t orow[JT], crow[JT];
+    bool rok[JT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) orow[jt] = ot * 64 + jt * 16 + j;
+    for (int jt = 0; jt < JT; ++jt) {
+        orow[jt] = ot * (16 * JT) + jt * 16 + j;
+        rok[jt] = orow[jt] < n_out;
+        crow[jt] = rok[jt] ? orow[jt] : n_out - 1;
+    }
 
-    f32x4 acc[COT][4];
+    // ---- active-tap set of the tile = union over its 16-row groups (SGPRs)
+    uint64_t tlo = 0, thi = 0;
+    if constexpr (IDENT) {
+        tlo = 1;
+    } else {
+        const int K = P.K;
+        const uint32_t ngrp = (n_out + 15) >> 4;
+        if (P.mask16) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const uint32_t grp = ot * JT + jt;
+                const uint32_t* mp = P.mask16 + (size_t)(grp < ngrp ? grp : ngrp - 1) * 4;
+                uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
+                uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
+                if (grp < ngrp) {
+                    tlo |= ((uint64_t)w1 << 32) | w0;
+                    thi |= ((uint64_t)w3 << 32) | w2;
+                }
+            }
+        } else {
+            tlo = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+            thi = K > 64 ? (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull)) : 0ull;
+        }
+    }
+    const int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
+
+    f32x4 acc[COT][JT];
 #pragma unroll
     for (int it = 0; it < COT; ++it)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < JT; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t tap_stride = (int64_t)P.nblk * P.ntile_co * 256;
-    for (int k = 0; k < P.K; ++k) {
-        int idx[4];
-        int anyv = 0;
+    const uint32_t blk_stride = (uint32_t)P.ntile_co * 256u;   // floats between chunk blocks of one tap
+    const uint32_t tap_stride = (uint32_t)P.nblk * blk_stride;  // floats between taps
+    const float* __restrict__ wbase = P.w + (cg * COT) * 256u + lane * 4u;
+    constexpr int NS = CK ? CK / 4 : 4;  // MFMA steps per chunk
+    const int nchunk = CK ? 1 : P.n16;
+
+    auto load_idx = [&](int k, int (&idx)[JT]) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            int v = -1;
-            if (orow[jt] < P.n_out) v = P.nbr ? P.nbr[(int64_t)k * P.n_out + orow[jt]] : (int)orow[jt];
-            idx[jt] = v;
-            anyv |= (v >= 0);
+        for (int jt = 0; jt < JT; ++jt) {
+            if constexpr (IDENT) idx[jt] = (int)crow[jt];
+            else idx[jt] = nbr[(uint32_t)k * n_out + crow[jt]];
         }
-        if (!__any(anyv)) continue;
-        const float* wk = P.w + (int64_t)k * tap_stride + ((int64_t)cg * COT) * 256 + lane * 4;
-        int blk = 0;
-        for (int c = 0; c < P.n16; ++c, ++blk) {
-            f32x4 b[4];
+    };
+    auto load_a = [&](int k, int c, f32x4 (&a)[COT]) {
+        const float* wb = wbase + (uint32_t)k * tap_stride + (uint32_t)c * blk_stride;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                b[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (idx[jt] >= 0) b[jt] = *(const f32x4*)(P.in + (int64_t)idx[jt] * P.ld_in + c * 16 + 4 * g);
+        for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
+    };
+    auto load_b = [&](const int (&idx)[JT], int c, f32x4 (&b)[JT]) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const uint32_t row = (uint32_t)(idx[jt] < 0 ? 0 : idx[jt]) * ld_in;
+            if constexpr (CK == 8) {
+                f32x2 t = *(const f32x2*)(in + row + 2u * g);
+                b[jt] = (f32x4){t[0], t[1], 0.f, 0.f};
+            } else if constexpr (CK == 4) {
+                b[jt] = (f32x4){in[row + g], 0.f, 0.f, 0.f};
+            } else {
+                b[jt] = *(const f32x4*)(in + row + (uint32_t)c * 16u + 4u * g);
             }
-            f32x4 a[COT];
-            const float* wb = wk + (int64_t)blk * P.ntile_co * 256;
-#pragma unroll
-            for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int it = 0; it < COT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it][s], b[jt][s], acc[it][jt], 0, 0, 0);
         }
-        int c0 = P.n16 * 16;
-        if (P.has8) {
-            f32x2 b[4];
+    };
+    auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT], const int (&idx)[JT]) {
+        f32x4 bb[JT];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                b[jt] = (f32x2){0.f, 0.f};
-                if (idx[jt] >= 0) b[jt] = *(const f32x2*)(P.in + (int64_t)idx[jt] * P.ld_in + c0 + 2 * g);
-            }
-            f32x4 a[COT];
-            const float* wb = wk + (int64_t)blk * P.ntile_co * 256;
+        for (int jt = 0; jt < JT; ++jt) {
+            const bool ok = rok[jt] && idx[jt] >= 0;
 #pragma unroll
-            for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int it = 0; it < COT; ++it)
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it][s], b[jt][s], acc[it][jt], 0, 0, 0);
-            ++blk;
-            c0 += 8;
+            for (int s = 0; s < NS; ++s) bb[jt][s] = ok ? b[jt][s] : 0.f;
         }
-        if (P.has4) {
-            float b[4];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                b[jt] = 0.f;
-                if (idx[jt] >= 0) b[jt] = P.in[(int64_t)idx[jt] * P.ld_in + c0 + g];
-            }
-            f32x4 a[COT];
-            const float* wb = wk + (int64_t)blk * P.ntile_co * 256;
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
+            for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-            for (int it = 0; it < COT; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it][0], b[jt], acc[it][jt], 0, 0, 0);
+                for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], bb[jt][s], acc[it][jt]);
+    };
+
+    if (nt > 0) {
+        // taps: k0 = current, k1 = next, k2 = the one after (clamped to the last tap at the end)
+        int k0 = pop_or_keep(tlo, thi, 0);
+        int k1 = pop_or_keep(tlo, thi, k0);
+        int k2 = pop_or_keep(tlo, thi, k1);
+        int i0[JT], i1[JT], i2[JT];
+        load_idx(k0, i0);
+        load_idx(k1, i1);
+        load_idx(k2, i2);
+        f32x4 bA[JT], bB[JT], aA[COT], aB[COT];
+        load_b(i0, 0, bA);
+        load_a(k0, 0, aA);
+        int c = 0;
+        const int nitems = nt * nchunk;
+        // one stage: request item i+1 into (bN,aN), run item i from (bC,aC), advance the tap ring
+#define STAGE(bC, aC, bN, aN)                                                              \
+    {                                                                                      \
+        const bool last = (c + 1 == nchunk);                                               \
+        int ir[JT], in1[JT];                                                               \
+        _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) {                                \
+            ir[jt] = i0[jt];                                                               \
+            in1[jt] = last ? i1[jt] : i0[jt];                                              \
+        }                                                                                  \
+        const int kk = last ? k1 : k0;                                                     \
+        const int cc = last ? 0 : c + 1;                                                   \
+        load_b(in1, cc, bN);                                                               \
+        load_a(kk, cc, aN);                                                                \
+        mma(aC, bC, ir);                                                                   \
+        c = cc;                                                                            \
+        if (last) {                                                                        \
+            k0 = k1; k1 = k2;                                                              \
+            _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) { i0[jt] = i1[jt]; i1[jt] = i2[jt]; } \
+            k2 = pop_or_keep(tlo, thi, k2);                                                \
+            load_idx(k2, i2);                                                              \
+        }                                                                                  \
+    }
+        int i = 0;
+        for (; i + 1 < nitems; i += 2) {
+            STAGE(bA, aA, bB, aB)
+            STAGE(bB, aB, bA, aA)
         }
+        if (i < nitems) STAGE(bA, aA, bB, aB)
+#undef STAGE
     }
 
     // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow[jt]
+    const uint32_t cout = P.cout;
 #pragma unroll
     for (int it = 0; it < COT; ++it) {
-        const int co0 = (cg * COT + it) * 16 + 4 * g;
+        const uint32_t co0 = (cg * COT + it) * 16 + 4 * g;
         const f32x4 bz = *(const f32x4*)(P.bias + co0);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int64_t o = orow[jt];
-            if (o >= P.n_out || co0 >= P.cout) continue;
+        for (int jt = 0; jt < JT; ++jt) {
+            const uint32_t o = orow[jt];
+            if (o >= n_out || co0 >= cout) continue;
             f32x4 v = acc[it][jt] + bz;
             if (P.relu_pre) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (P.res_mode == 1) {
-                if (P.vec_store && co0 + 3 < P.cout) {
-                    v += *(const f32x4*)(P.res + o * P.ld_res + co0);
+                const float* rp = P.res + (size_t)o * P.ld_res + co0;
+                if (P.vec_store && co0 + 3 < cout) {
+                    v += *(const f32x4*)rp;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (co0 + r < P.cout) v[r] += P.res[o * P.ld_res + co0 + r];
+                        if (co0 + r < cout) v[r] += rp[r];
                 }
             } else if (P.res_mode == 2) {
+                const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < P.cout) {
-                        const float* rp = P.res + o * P.ld_res + 2 * (co0 + r);
-                        v[r] += rp[0] + rp[1];
-                    }
+                    if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
             }
             if (P.relu_post) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            float* op = P.out + o * P.ld_out + co0;
-            if (P.vec_store && co0 + 3 < P.cout) {
+            float* op = P.out + (size_t)o * P.ld_out + co0;
+            if (P.vec_store && co0 + 3 < cout) {
                 *(f32x4*)op = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < P.cout) op[r] = v[r];
+                    if (co0 + r < cout) op[r] = v[r];
             }
         }
     }
@@ -244,40 +331,80 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
     return INSMOS_OK;
 }
 
-extern "C" int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, int K, int64_t n_out,
-                                  const float* wpacked, const float* bias, float* out, int ld_out, int cout,
-                                  const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
+namespace {
+typedef void (*ConvKernel)(ConvP);
+struct Cfg { int cot, jt; };
+
+template <int CK, bool IDENT>
+ConvKernel pick_kernel(int cot, int jt) {
+#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT>;
+    if constexpr (CK == 0) {
+        CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
+        CASE(8, 1) CASE(8, 2) CASE(8, 4)
+    } else {
+        CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4)
+    }
+#undef CASE
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16,
+                                  int K, int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out,
+                                  int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
                                   void* stream) {
     if (n_out <= 0) return INSMOS_OK;
     if (!in || !wpacked || !bias || !out || cin <= 0 || cin % 4 != 0 || ld_in % 4 != 0 || ld_in < cin || K <= 0 ||
-        (!nbr && K != 1) || cout <= 0 || ld_out < cout || (res_mode != 0 && !res) || ((uintptr_t)in & 15))
+        K > 128 || (!nbr && K != 1) || cout <= 0 || ld_out < cout || (res_mode != 0 && !res) || ((uintptr_t)in & 15) ||
+        n_out * (int64_t)K >= (1ll << 31) || n_out * (int64_t)ld_in >= (1ll << 31))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ConvP P;
-    P.in = in; P.nbr = nbr; P.w = wpacked; P.bias = bias; P.out = out; P.res = res; P.n_out = n_out;
+    P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
+    P.n_out = (uint32_t)n_out;
     P.ld_in = ld_in; P.cin = cin; P.K = K; P.ld_out = ld_out; P.cout = cout; P.ld_res = ld_res; P.res_mode = res_mode;
     P.relu_pre = relu_pre; P.relu_post = relu_post;
     chunking(cin, P.n16, P.has8, P.has4);
     P.nblk = P.n16 + P.has8 + P.has4;
     P.ntile_co = (cout + 15) / 16;
-    P.n_otiles = (int)((n_out + 63) / 64);
     P.vec_store = (cout % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
                    (res_mode != 1 || (ld_res % 4 == 0 && ((uintptr_t)res & 15) == 0)))
                       ? 1
                       : 0;
-    // channel tiles per wave: as many as possible while the grid still fills the 1024 SIMDs
-    int cot = 1;
-    for (int c = 8; c >= 2; c >>= 1)
-        if (P.ntile_co % c == 0 && (int64_t)P.n_otiles * (P.ntile_co / c) >= 1024) { cot = c; break; }
-    int64_t waves = (int64_t)P.n_otiles * (P.ntile_co / cot);
+    const int ck = (cin == 4 || cin == 8) ? cin : 0;
+    if (!ck && (cin % 16 != 0)) return INSMOS_EINVAL;  // supported widths: 4, 8, or a multiple of 16
+    // tile shape: the largest (COT x JT) tile (ties: squarest) that still gives >= 2 waves per SIMD;
+    // if the layer is too small for that, the shape with the most waves.
+    const int max_cot = ck ? 2 : 8;
+    Cfg best = {1, 1};
+    long best_waves = -1;
+    bool found = false;
+    int best_area = 0, best_skew = 99;
+    for (int cot = 1; cot <= max_cot; cot <<= 1) {
+        if (P.ntile_co % cot) continue;
+        for (int jt = 1; jt <= 4; jt <<= 1) {
+            long waves = (long)((n_out + 16 * jt - 1) / (16 * jt)) * (P.ntile_co / cot);
+            int area = cot * jt, skew = cot > jt ? cot / jt : jt / cot;
+            if (waves >= 2048) {
+                if (!found || area > best_area || (area == best_area && skew < best_skew)) {
+                    found = true; best = {cot, jt}; best_area = area; best_skew = skew; best_waves = waves;
+                }
+            } else if (!found && (waves > best_waves || (waves == best_waves && area > best_area))) {
+                best = {cot, jt}; best_waves = waves; best_area = area;
+            }
+        }
+    }
+    P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
+    const bool ident = (nbr == nullptr);
+    ConvKernel kern = nullptr;
+    if (ck == 4) kern = ident ? pick_kernel<4, true>(best.cot, best.jt) : pick_kernel<4, false>(best.cot, best.jt);
+    else if (ck == 8) kern = ident ? pick_kernel<8, true>(best.cot, best.jt) : pick_kernel<8, false>(best.cot, best.jt);
+    else kern = ident ? pick_kernel<0, true>(best.cot, best.jt) : pick_kernel<0, false>(best.cot, best.jt);
+    if (!kern) return INSMOS_EINVAL;
+    long waves = (long)P.n_otiles * (P.ntile_co / best.cot);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     ProfScope ps(KK_SPARSE_CONV, s);
-    switch (cot) {
-        case 8: hipLaunchKernelGGL(k_sparse_conv<8>, grid, block, 0, s, P); break;
-        case 4: hipLaunchKernelGGL(k_sparse_conv<4>, grid, block, 0, s, P); break;
-        case 2: hipLaunchKernelGGL(k_sparse_conv<2>, grid, block, 0, s, P); break;
-        default: hipLaunchKernelGGL(k_sparse_conv<1>, grid, block, 0, s, P); break;
-    }
+    hipLaunchKernelGGL(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -70,6 +70,28 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+def _padc(c):
+    """Channel widths insmos_sparse_conv accepts: 4, 8, or a multiple of 16 (zero-padded columns)."""
+    return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
+
+
+class NbrTable:
+    """Output-stationary neighbour table + its per-16-row-group active-tap bitmasks."""
+
+    def __init__(self, nbr, mask16):
+        self.nbr, self.mask16 = nbr, mask16
+        self.shape = nbr.shape
+
+    def data_ptr(self):
+        return self.nbr.data_ptr()
+
+    def cpu(self):
+        return self.nbr.cpu()
+
+    def __ge__(self, other):
+        return self.nbr >= other
+
+
 class Engine:
     def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5):
         self.lib = _lib.load()
@@ -109,6 +131,7 @@ class Engine:
             raise NotImplementedError("BEV deconv stride 2 only (config.yaml:118)")
         self._ws = None
         self._conv_log = []
+        self.layer_timing = None  # set to [] to record per-conv (name, K, cin, cout, n_out, ev0, ev1)
         self._load_weights(state_dict)
         self._static_tables()
         self.last_counts = {}
@@ -137,12 +160,12 @@ class Engine:
             return ConvLayer(lib, taps, b, cin_pad, cout_store, dev)
 
         for conv, bn, kv, ci, co in P.ME_CONVS:
-            L[conv] = me(conv, bn, _pad4(ci), co)
+            L[conv] = me(conv, bn, _padc(ci), co)
         for name, ci, co in P.ME_BLOCKS:
-            L[name + ".conv1"] = me(name + ".conv1", name + ".norm1", ci, co)
-            L[name + ".conv2"] = me(name + ".conv2", name + ".norm2", co, co)
+            L[name + ".conv1"] = me(name + ".conv1", name + ".norm1", _padc(ci), co)
+            L[name + ".conv2"] = me(name + ".conv2", name + ".norm2", _padc(co), co)
             if ci != co:
-                L[name + ".ds"] = me(name + ".downsample.0", name + ".downsample.1", ci, co)
+                L[name + ".ds"] = me(name + ".downsample.0", name + ".downsample.1", _padc(ci), co)
         L["final"] = me("final", None, 8, 3, bias=self._sd(M + "final.bias"))
 
         U = P.UNET_PREFIX
@@ -151,7 +174,7 @@ class Engine:
             b = None
             if bn:
                 taps, b = P.fold_bn(taps, *self._bn(U + bn), 1e-3)
-            L[conv] = ConvLayer(lib, taps, b, _pad4(ci), co, dev)
+            L[conv] = ConvLayer(lib, taps, b, _padc(ci), co, dev)
         B = U + "bev_backbone."
         taps, b = P.fold_bn(P.conv2d_weight_to_taps(self._sd(B + "blocks.0.1.weight")), *self._bn(B + "blocks.0.2"), 1e-3)
         L["bev0"] = ConvLayer(lib, taps, b, taps.shape[1], taps.shape[2], dev)
@@ -176,6 +199,8 @@ class Engine:
         L["head"] = ConvLayer(lib, taps, bias, co, self.head_ld, dev)
         wl = self._sd(U + "mos_seg_layer.weight")  # (3,16)
         L["mos_seg"] = ConvLayer(lib, np.ascontiguousarray(wl.T[None]), self._sd(U + "mos_seg_layer.bias"), 16, 3, dev)
+        for k, v in L.items():
+            v.name = k
         self.L = L
 
     def _static_tables(self):
@@ -206,21 +231,33 @@ class Engine:
         if n_out == 0:
             return
         K = layer.K
+        mask = None
         if nbr is not None:
             assert nbr.shape[0] == K and nbr.shape[1] == n_out, (nbr.shape, K, n_out)
+            if isinstance(nbr, NbrTable):
+                mask = nbr.mask16
+        if self.layer_timing is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(torch.cuda.current_stream(self.device))
         rc = self.lib.insmos_sparse_conv(
-            x.data_ptr() + 4 * col_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None, K, n_out,
+            x.data_ptr() + 4 * col_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None,
+            mask.data_ptr() if mask is not None else None, K, n_out,
             layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr() + 4 * col_out, ld_out, layer.cout,
             (res.data_ptr() + 4 * col_res) if res is not None else None, ld_res, res_mode, relu_pre, relu_post,
             self._stream())
         _lib.check(rc, "insmos_sparse_conv")
         self._conv_log.append((nbr, n_out, layer))
+        if self.layer_timing is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.layer_timing.append((layer.name, K, layer.cin, layer.cout, n_out, self._t0, e1))
 
     def build_nbr(self, out_coords, n_out, in_keys, in_perm, n_in, mode, shape, delta, mul=None, div=None):
         K = len(delta)
         nbr = self._empty((K, n_out), torch.int32)
+        mask = self._empty(((n_out + 15) // 16, 4), torch.int32)
         if n_out == 0:
-            return nbr
+            return NbrTable(nbr, mask)
         delta = _np_i32(delta)
         mul = _np_i32(mul if mul is not None else [1, 1, 1, 1])
         div = _np_i32(div if div is not None else [1, 1, 1, 1])
@@ -228,9 +265,9 @@ class Engine:
         rc = self.lib.insmos_build_nbr(out_coords.data_ptr(), n_out, in_keys.data_ptr(),
                                        in_perm.data_ptr() if in_perm is not None else None, n_in, mode,
                                        _hp(shp) if shp is not None else None, _hp(delta), K, _hp(mul), _hp(div),
-                                       nbr.data_ptr(), self._stream())
+                                       nbr.data_ptr(), mask.data_ptr(), self._stream())
         _lib.check(rc, "insmos_build_nbr")
-        return nbr
+        return NbrTable(nbr, mask)
 
     # ------------------------------------------------------------------------------------------------
     def motionnet(self, pts):
@@ -281,7 +318,8 @@ class Engine:
         x_in.zero_()
         _lib.check(lib.insmos_fill_cols(x_in.data_ptr(), n[0], 4, 0, 1, 0.5, st), "insmos_fill_cols")
         cat8 = E((n[0], 16))  # [convtr7 (8) | out_p1 (8)]
-        cat7 = E((n[1], 24))  # [convtr6 (16) | out_b1p2 (8)]
+        cat7 = E((n[1], 32))  # [convtr6 (16) | out_b1p2 (8) | zero pad (8)]
+        _lib.check(lib.insmos_fill_cols(cat7.data_ptr(), n[1], 32, 24, 8, 0.0, st), "insmos_fill_cols")
         cat6 = E((n[2], 48))  # [convtr5 (32) | out_b2p4 (16)]
         self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
         x1 = E((n[1], 8))
@@ -299,9 +337,9 @@ class Engine:
                 self.conv(L[name + ".conv2"], t, cout, nb, nn, out, ld_out, col_out=col_out, res=x, ld_res=ld_x,
                           col_res=col_x, res_mode=1, relu_post=1)
 
-        block("block1.0", x1, 8, 0, nbr81[1], n[1], 8, cat7, 24, 16)
+        block("block1.0", x1, 8, 0, nbr81[1], n[1], 8, cat7, 32, 16)
         x2 = E((n[2], 8))
-        self.conv(L["conv2p2s2"], cat7, 24, dn[1], n[2], x2, 8, col_in=16, relu_post=1)
+        self.conv(L["conv2p2s2"], cat7, 32, dn[1], n[2], x2, 8, col_in=16, relu_post=1)
         block("block2.0", x2, 8, 0, nbr81[2], n[2], 16, cat6, 48, 32)
         x3 = E((n[3], 16))
         self.conv(L["conv3p4s2"], cat6, 48, dn[2], n[3], x3, 16, col_in=32, relu_post=1)
@@ -310,9 +348,9 @@ class Engine:
         self.conv(L["convtr5p8s2"], b3, 32, up[2], n[2], cat6, 48, col_out=0, relu_post=1)
         b6 = E((n[2], 32))
         block("block6.0", cat6, 48, 0, nbr81[2], n[2], 32, b6, 32, 0)
-        self.conv(L["convtr6p4s2"], b6, 32, up[1], n[1], cat7, 24, col_out=0, relu_post=1)
+        self.conv(L["convtr6p4s2"], b6, 32, up[1], n[1], cat7, 32, col_out=0, relu_post=1)
         b7 = E((n[1], 16))
-        block("block7.0", cat7, 24, 0, nbr81[1], n[1], 16, b7, 16, 0)
+        block("block7.0", cat7, 32, 0, nbr81[1], n[1], 16, b7, 16, 0)
         self.conv(L["convtr7p2s2"], b7, 16, up[0], n[0], cat8, 16, col_out=0, relu_post=1)
         b8 = E((n[0], 8))
         block("block8.0", cat8, 16, 0, nbr81[0], n[0], 8, b8, 8, 0)
@@ -461,7 +499,7 @@ class Engine:
         def onehot(level, mult, out, ld, col):
             _lib.check(lib.insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), cnt_k.data_ptr(), self.post_max, _hp(lo),
                                                   _hp(vsz), 8.0, float(mult), coords[level].data_ptr(), nv[level], ncls,
-                                                  4, 1 if self.quirk_exact else 0, out.data_ptr() + 4 * col, ld,
+                                                  16, 1 if self.quirk_exact else 0, out.data_ptr() + 4 * col, ld,
                                                   scratch.data_ptr(), st), "insmos_boxes_to_onehot")
 
         def ur_block(lvl, C, x_lat, ld_lat, catm):
@@ -475,35 +513,35 @@ class Engine:
                       res_mode=2, relu_pre=1)
             return m
 
-        ci4 = E((nv[4], 132))
-        self.conv(L["inv_conv_out"], enc, 128, inv5, nv[4], ci4, 132)
-        onehot(4, 1.0, ci4, 132, 128)
+        ci4 = E((nv[4], 144))
+        self.conv(L["inv_conv_out"], enc, 128, inv5, nv[4], ci4, 144)
+        onehot(4, 1.0, ci4, 144, 128)
         catm4 = E((nv[4], 256))
-        self.conv(L["conv_up_instance_block.0"], ci4, 132, subm[4], nv[4], catm4, 256, relu_post=1)
+        self.conv(L["conv_up_instance_block.0"], ci4, 144, subm[4], nv[4], catm4, 256, relu_post=1)
         m4 = ur_block(4, 128, catm4, 256, catm4)
-        ci3 = E((nv[3], 68))
-        self.conv(L["inv_conv4.0"], m4, 128, inv[4], nv[3], ci3, 68, relu_post=1)
-        onehot(3, 2.0, ci3, 68, 64)
+        ci3 = E((nv[3], 80))
+        self.conv(L["inv_conv4.0"], m4, 128, inv[4], nv[3], ci3, 80, relu_post=1)
+        onehot(3, 2.0, ci3, 80, 64)
         catm3 = E((nv[3], 128))
-        self.conv(L["conv_up_instance_block_up4.0"], ci3, 68, subm[3], nv[3], catm3, 128, relu_post=1)
+        self.conv(L["conv_up_instance_block_up4.0"], ci3, 80, subm[3], nv[3], catm3, 128, relu_post=1)
         m3 = ur_block(3, 64, xc[3], 64, catm3)
-        ci2 = E((nv[2], 36))
-        self.conv(L["inv_conv3.0"], m3, 64, inv[3], nv[2], ci2, 36, relu_post=1)
-        onehot(2, 4.0, ci2, 36, 32)
+        ci2 = E((nv[2], 48))
+        self.conv(L["inv_conv3.0"], m3, 64, inv[3], nv[2], ci2, 48, relu_post=1)
+        onehot(2, 4.0, ci2, 48, 32)
         catm2 = E((nv[2], 64))
-        self.conv(L["conv_up_instance_block_up3.0"], ci2, 36, subm[2], nv[2], catm2, 64, relu_post=1)
+        self.conv(L["conv_up_instance_block_up3.0"], ci2, 48, subm[2], nv[2], catm2, 64, relu_post=1)
         m2 = ur_block(2, 32, xc[2], 32, catm2)
-        ci1 = E((V, 20))
-        self.conv(L["inv_conv2.0"], m2, 32, inv[2], V, ci1, 20, relu_post=1)
-        onehot(1, 8.0, ci1, 20, 16)
+        ci1 = E((V, 32))
+        self.conv(L["inv_conv2.0"], m2, 32, inv[2], V, ci1, 32, relu_post=1)
+        onehot(1, 8.0, ci1, 32, 16)
         catm1 = E((V, 32))
-        self.conv(L["conv_up_instance_block_up2.0"], ci1, 20, subm[1], V, catm1, 32, relu_post=1)
+        self.conv(L["conv_up_instance_block_up2.0"], ci1, 32, subm[1], V, catm1, 32, relu_post=1)
         m1 = ur_block(1, 16, xc[1], 16, catm1)
-        ci0 = E((V, 20))
-        self.conv(L["conv_up_out.0.0"], m1, 16, subm[1], V, ci0, 20, relu_post=1)
-        onehot(1, 8.0, ci0, 20, 16)  # spconv_unet.py:401 re-uses the stride-1 instance features
+        ci0 = E((V, 32))
+        self.conv(L["conv_up_out.0.0"], m1, 16, subm[1], V, ci0, 32, relu_post=1)
+        onehot(1, 8.0, ci0, 32, 16)  # spconv_unet.py:401 re-uses the stride-1 instance features
         seg = E((V, 16))
-        self.conv(L["conv_up_instance_block_up1.0"], ci0, 20, subm[1], V, seg, 16, relu_post=1)
+        self.conv(L["conv_up_instance_block_up1.0"], ci0, 32, subm[1], V, seg, 16, relu_post=1)
         vox_logits = E((V, 4))
         self.conv(L["mos_seg"], seg, 16, None, V, vox_logits, 4)
         logits = E((ncur, 3))

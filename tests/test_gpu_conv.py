@@ -27,7 +27,7 @@ def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
     rng = np.random.default_rng(cin * 1000 + cout)
     identity = (K == 1)
     n_in = n_out if identity else max(n_out // 2, 50)
-    cin_pad = (cin + 3) // 4 * 4
+    cin_pad = 4 if cin <= 4 else 8 if cin <= 8 else (cin + 15) // 16 * 16
     x = np.zeros((n_in, cin_pad), np.float32)
     x[:, :cin] = rng.normal(size=(n_in, cin))
     x[:, cin:] = 7.0  # padded columns must be neutral (their taps are zero)
@@ -38,6 +38,29 @@ def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
     y = run_conv(layer, dev(x), None if identity else dev(nbr), n_out).cpu().numpy()
     ref = R.sparse_conv(x[:, :cin], nbr, taps) + bias
     np.testing.assert_allclose(y[:, :cout], ref, **TOL)
+    if not identity:  # same result when the active-tap bitmasks drive the tap loop
+        from gpu_util import tap_masks
+        ym = run_conv(layer, dev(x), dev(nbr), n_out, mask=dev(tap_masks(nbr).view(np.int32))).cpu().numpy()
+        np.testing.assert_array_equal(ym, y)
+
+
+def test_clustered_occupancy_with_masks():
+    """Spatially coherent tables (whole 16-row groups / whole tiles without a tap) exercise the skip paths."""
+    from gpu_util import dev, pack_layer, run_conv, tap_masks
+    rng = np.random.default_rng(11)
+    for cin, cout, K, n in ((8, 8, 81, 5000), (16, 16, 27, 3000), (48, 32, 81, 2000), (128, 64, 27, 1500), (32, 16, 27, 900)):
+        n_in = n
+        nbr = rng.integers(0, n_in, size=(K, n)).astype(np.int32)
+        grp = rng.uniform(size=(K, (n + 15) // 16)) < 0.45     # whole groups empty
+        tile = rng.uniform(size=(K, (n + 63) // 64)) < 0.3     # whole 64-row tiles empty
+        keep = np.repeat(grp, 16, axis=1)[:, :n] & ~np.repeat(tile, 64, axis=1)[:, :n] & (rng.uniform(size=(K, n)) < 0.5)
+        nbr[~keep] = -1
+        x = rng.normal(size=(n_in, cin)).astype(np.float32)
+        taps = (rng.normal(size=(K, cin, cout)) * 0.1).astype(np.float32)
+        bias = rng.normal(size=cout).astype(np.float32)
+        layer = pack_layer(taps, bias, cin, cout)
+        y = run_conv(layer, dev(x), dev(nbr), n, mask=dev(tap_masks(nbr).view(np.int32))).cpu().numpy()
+        np.testing.assert_allclose(y, R.sparse_conv(x, nbr, taps) + bias, **TOL)
 
 
 def test_epilogue_variants_and_column_slices():

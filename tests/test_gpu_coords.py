@@ -40,7 +40,12 @@ def test_quantize_levels_and_tables(window, engine):
         np.testing.assert_array_equal(T["coords"][L].cpu().numpy(), pc)
         np.testing.assert_array_equal(u64(T["keys"][L]), pk)
         lv.append((pc, pk))
-    np.testing.assert_array_equal(T["nbr125"].cpu().numpy(), R.me_nbr(c, k, R.me_kernel_offsets([5, 5, 5, 1], [1] * 4)))
+    n125 = R.me_nbr(c, k, R.me_kernel_offsets([5, 5, 5, 1], [1] * 4))
+    np.testing.assert_array_equal(T["nbr125"].cpu().numpy(), n125)
+    from gpu_util import tap_masks
+    np.testing.assert_array_equal(T["nbr125"].mask16.cpu().numpy().view(np.uint32), tap_masks(n125))
+    np.testing.assert_array_equal(T["nbr81"][2].mask16.cpu().numpy().view(np.uint32),
+                                  tap_masks(T["nbr81"][2].cpu().numpy()))
     for L in range(4):
         s = 1 << L
         np.testing.assert_array_equal(T["nbr81"][L].cpu().numpy(),

@@ -61,9 +61,10 @@ def test_forward_signature_and_parity(setup):
     np.testing.assert_array_equal(pred["pred_labels"].cpu().numpy(), ref_pred["pred_labels"])
     np.testing.assert_allclose(pred["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"], atol=1e-3, rtol=1e-4)
     np.testing.assert_allclose(pred["pred_scores"].cpu().numpy(), ref_pred["pred_scores"], atol=2e-3)
-    for lvl, name in ((4, "ci4"), (3, "ci3"), (2, "ci2"), (1, "ci1")):
-        oh = eng._un_debug[name].cpu().numpy()[:, -4:-1]
-        np.testing.assert_array_equal(oh, dbg["unet"]["onehots"][lvl])
+    for lvl, name, C in ((4, "ci4", 128), (3, "ci3", 64), (2, "ci2", 32), (1, "ci1", 16)):
+        t = eng._un_debug[name].cpu().numpy()
+        np.testing.assert_array_equal(t[:, C:C + 3], dbg["unet"]["onehots"][lvl])
+        assert np.all(t[:, C + 3:] == 0)  # zero padding up to the next multiple of 16 channels
     assert sum(int(dbg["unet"]["onehots"][l].sum()) for l in (1, 2, 3, 4)) > 0, "instance features must be exercised"
     # --- the north-star bar
     np.testing.assert_allclose(logits, ref_logits, atol=1e-3, rtol=0)
