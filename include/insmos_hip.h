@@ -131,7 +131,8 @@ int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* 
  * heads (center_head.py:47-54) in NHWC.
  *   nbr == NULL  -> K must be 1, identity map (1x1 conv / Linear).
  *   mask16: the table's active-tap sets from insmos_build_nbr, or NULL (every tap visited).
- *   cin must be 4, 8 or a multiple of 16 (pad with ZERO columns); ld_in % 4 == 0, `in` 16-byte aligned.
+ *   in has n_in rows; cin must be 4, 8 or a multiple of 16 (pad with ZERO columns); ld_in % 4 == 0, `in`
+ *   16-byte aligned, n_in*ld_in*4 < 2^31 (gathers are 32-bit-offset buffer loads).
  *   wpacked: tap-major MFMA-fragment layout produced by insmos_pack_weights_host (below).
  *   bias: (cout_pad16) fp32.
  * ---------------------------------------------------------------------------------------------- */
@@ -139,8 +140,8 @@ size_t insmos_packed_weight_floats(int K, int cin, int cout);
 /* Host helper: taps (K,cin_real,cout_real) fp32 row-major -> packed layout for (cin,cout) padded. */
 int insmos_pack_weights_host(const float* taps_host, int K, int cin_real, int cout_real, int cin, int cout,
                              float* packed_host);
-int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16, int K,
-                       int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
+int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16,
+                       int K, int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
                        const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

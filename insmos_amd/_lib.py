@@ -30,7 +30,7 @@ SIGNATURES = {
     "insmos_down_coords3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_packed_weight_floats": (c_sz, [c_int, c_int, c_int]),
     "insmos_pack_weights_host": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
-    "insmos_sparse_conv": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
+    "insmos_sparse_conv": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
                                    c_int, c_int, c_int, c_int, c_vp]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),
     "insmos_sparse_to_bev": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),

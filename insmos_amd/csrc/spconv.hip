@@ -40,6 +40,7 @@ struct ConvP {
     float* out;
     const float* res;
     uint32_t n_out;
+    uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
     int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
 };
@@ -61,16 +62,18 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 // CK == 0: Cin is a multiple of 16, a tap is Cin/16 chunks of 16 channels (4 MFMA steps each)
 // CK == 4 / 8: the whole contraction of a tap is ONE chunk of that width (small-C 4D layers)
 // IDENT: no neighbour table -- a 1x1 convolution / Linear (row o reads row o)
+// R: depth of the operand register ring; operands of item i+R-1 are requested before item i's MFMAs
 //
-// The main loop is a COUNTED, branch-free two-stage software pipeline over work items (tap, chunk):
-// the operands of item i+1 are requested before the MFMAs of item i issue, and the neighbour indices
-// of the tap after next are already in flight.  Everything that could be a guard is a clamp instead:
-// rows past n_out re-read the last row, missing neighbours re-read row 0 and are zeroed by a select
-// right before the MFMA, and running off the end of the tap list re-requests the last item.  (Exec-
-// masked loads made hipcc wait vmcnt(0) inside each branch, and per-16-row-group skip branches made
-// it shuttle the accumulators between AGPRs and VGPRs every iteration; both cost far more than the
-// redundant work.)
-template <int COT, int JT, int CK, bool IDENT>
+// The main loop is a COUNTED, branch-free software pipeline over work items (tap, chunk).  A LOAD
+// CURSOR walks R-1 items ahead of the MFMAs: it owns the tap ring (current tap's row offsets, next
+// tap's raw indices, and the indices of the tap after that already in flight), so neighbour indices
+// are requested >= one full tap before they are needed.  All gathers are BUFFER loads through an SGPR
+// descriptor with 32-bit offsets: a missing neighbour (index -1) wraps to an out-of-range offset and
+// the hardware returns 0 -- no clamp, no select, no exec-masked branch (those made hipcc wait
+// vmcnt(0) inside each branch and shuttle the accumulators between AGPRs and VGPRs).  Running off
+// the end of the tap list re-requests the last tap (clamp instead of guard); rows past n_out compute
+// on re-read data and are masked at the store.
+template <int COT, int JT, int CK, bool IDENT, int R>
 __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
@@ -80,19 +83,22 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     const uint32_t cg = gw / P.n_otiles;
     const uint32_t ot = gw % P.n_otiles;
     const int g = lane >> 4, j = lane & 15;
-    const float* __restrict__ in = P.in;
-    const int32_t* __restrict__ nbr = P.nbr;
     const uint32_t n_out = P.n_out;
-    const uint32_t ld_in = P.ld_in;
+    const uint32_t ld4 = (uint32_t)P.ld_in * 4u;  // row pitch in bytes
 
-    uint32_t orow[JT], crow[JT];
-    bool rok[JT];
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, 0, (int)P.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_nb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(IDENT ? (const void*)P.in : (const void*)P.nbr), 0,
+                                          IDENT ? 4 : (int)((uint32_t)P.K * n_out * 4u), 0x00020000);
+
+    uint32_t orow[JT], rowoff[JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         orow[jt] = ot * (16 * JT) + jt * 16 + j;
-        rok[jt] = orow[jt] < n_out;
-        crow[jt] = rok[jt] ? orow[jt] : n_out - 1;
+        rowoff[jt] = (orow[jt] < n_out ? orow[jt] : n_out - 1) * 4u;  // byte offset inside one tap row of nbr
     }
+    constexpr uint32_t LW = CK == 4 ? 4u : CK == 8 ? 8u : 16u;  // bytes per lane per gather
+    const uint32_t goff = (uint32_t)g * LW;
 
     // ---- active-tap set of the tile = union over its 16-row groups (SGPRs)
     uint64_t tlo = 0, thi = 0;
@@ -132,91 +138,93 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     constexpr int NS = CK ? CK / 4 : 4;  // MFMA steps per chunk
     const int nchunk = CK ? 1 : P.n16;
 
-    auto load_idx = [&](int k, int (&idx)[JT]) {
+    // raw neighbour indices of tap k (one dword per 16-row group and lane)
+    auto load_idx = [&](int k, uint32_t (&idx)[JT]) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            if constexpr (IDENT) idx[jt] = (int)crow[jt];
-            else idx[jt] = nbr[(uint32_t)k * n_out + crow[jt]];
+            if constexpr (IDENT) idx[jt] = rowoff[jt] >> 2;
+            else idx[jt] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff[jt], (uint32_t)k * n_out * 4u, 0);
         }
     };
-    auto load_a = [&](int k, int c, f32x4 (&a)[COT]) {
+    // byte offsets of the gathered rows; index -1 wraps past the end of the buffer -> loads return 0
+    auto row_offsets = [&](const uint32_t (&idx)[JT], uint32_t (&off)[JT]) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) off[jt] = idx[jt] * ld4 + goff;
+    };
+    auto load_ab = [&](int k, int c, const uint32_t (&off)[JT], f32x4 (&a)[COT], f32x4 (&b)[JT]) {
+        const uint32_t so = (uint32_t)c * 64u;  // chunk byte offset inside a row (scalar)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            if constexpr (CK == 4) {
+                b[jt] = (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[jt], so, 0)), 0.f,
+                                0.f, 0.f};
+            } else if constexpr (CK == 8) {
+                f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, off[jt], so, 0));
+                b[jt] = (f32x4){t[0], t[1], 0.f, 0.f};
+            } else {
+                b[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[jt], so, 0));
+            }
+        }
         const float* wb = wbase + (uint32_t)k * tap_stride + (uint32_t)c * blk_stride;
 #pragma unroll
         for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
     };
-    auto load_b = [&](const int (&idx)[JT], int c, f32x4 (&b)[JT]) {
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const uint32_t row = (uint32_t)(idx[jt] < 0 ? 0 : idx[jt]) * ld_in;
-            if constexpr (CK == 8) {
-                f32x2 t = *(const f32x2*)(in + row + 2u * g);
-                b[jt] = (f32x4){t[0], t[1], 0.f, 0.f};
-            } else if constexpr (CK == 4) {
-                b[jt] = (f32x4){in[row + g], 0.f, 0.f, 0.f};
-            } else {
-                b[jt] = *(const f32x4*)(in + row + (uint32_t)c * 16u + 4u * g);
-            }
-        }
-    };
-    auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT], const int (&idx)[JT]) {
-        f32x4 bb[JT];
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const bool ok = rok[jt] && idx[jt] >= 0;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) bb[jt][s] = ok ? b[jt][s] : 0.f;
-        }
+    auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], bb[jt][s], acc[it][jt]);
+                for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], b[jt][s], acc[it][jt]);
     };
 
     if (nt > 0) {
-        // taps: k0 = current, k1 = next, k2 = the one after (clamped to the last tap at the end)
-        int k0 = pop_or_keep(tlo, thi, 0);
-        int k1 = pop_or_keep(tlo, thi, k0);
-        int k2 = pop_or_keep(tlo, thi, k1);
-        int i0[JT], i1[JT], i2[JT];
-        load_idx(k0, i0);
-        load_idx(k1, i1);
-        load_idx(k2, i2);
-        f32x4 bA[JT], bB[JT], aA[COT], aB[COT];
-        load_b(i0, 0, bA);
-        load_a(k0, 0, aA);
-        int c = 0;
-        const int nitems = nt * nchunk;
-        // one stage: request item i+1 into (bN,aN), run item i from (bC,aC), advance the tap ring
-#define STAGE(bC, aC, bN, aN)                                                              \
-    {                                                                                      \
-        const bool last = (c + 1 == nchunk);                                               \
-        int ir[JT], in1[JT];                                                               \
-        _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) {                                \
-            ir[jt] = i0[jt];                                                               \
-            in1[jt] = last ? i1[jt] : i0[jt];                                              \
-        }                                                                                  \
-        const int kk = last ? k1 : k0;                                                     \
-        const int cc = last ? 0 : c + 1;                                                   \
-        load_b(in1, cc, bN);                                                               \
-        load_a(kk, cc, aN);                                                                \
-        mma(aC, bC, ir);                                                                   \
-        c = cc;                                                                            \
-        if (last) {                                                                        \
-            k0 = k1; k1 = k2;                                                              \
-            _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) { i0[jt] = i1[jt]; i1[jt] = i2[jt]; } \
-            k2 = pop_or_keep(tlo, thi, k2);                                                \
-            load_idx(k2, i2);                                                              \
-        }                                                                                  \
-    }
-        int i = 0;
-        for (; i + 1 < nitems; i += 2) {
-            STAGE(bA, aA, bB, aB)
-            STAGE(bB, aB, bA, aA)
+        // ---- load cursor: (kL, cL) = next item to request; offL = its rows; tap ring kN/idxN, kNN/idxNN
+        int kL = pop_or_keep(tlo, thi, 0);
+        int kN = pop_or_keep(tlo, thi, kL);
+        int kNN = pop_or_keep(tlo, thi, kN);
+        int cL = 0;
+        uint32_t offL[JT], idxN[JT], idxNN[JT];
+        {
+            uint32_t idx0[JT];
+            load_idx(kL, idx0);
+            load_idx(kN, idxN);
+            load_idx(kNN, idxNN);
+            row_offsets(idx0, offL);
         }
-        if (i < nitems) STAGE(bA, aA, bB, aB)
-#undef STAGE
+        f32x4 bs[R][JT], as[R][COT];
+        const int nitems = nt * nchunk;
+#define REQUEST(slot)                                                                     \
+    {                                                                                     \
+        load_ab(kL, cL, offL, as[slot], bs[slot]);                                        \
+        if (cL + 1 < nchunk) {                                                            \
+            ++cL;                                                                         \
+        } else {                                                                          \
+            cL = 0;                                                                       \
+            kL = kN; kN = kNN;                                                            \
+            row_offsets(idxN, offL);                                                      \
+            _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) idxN[jt] = idxNN[jt];       \
+            kNN = pop_or_keep(tlo, thi, kNN);                                             \
+            load_idx(kNN, idxNN);                                                         \
+        }                                                                                 \
+    }
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) REQUEST(r)
+        int i = 0;
+        for (; i + R <= nitems; i += R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                REQUEST((r + R - 1) % R)
+                mma(as[r], bs[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) {
+            if (i + r < nitems) {  // wave-uniform tail, at most R-1 items (their operands are already in flight)
+                mma(as[r], bs[r]);
+            }
+        }
+#undef REQUEST
     }
 
     // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow[jt]
@@ -335,9 +343,12 @@ namespace {
 typedef void (*ConvKernel)(ConvP);
 struct Cfg { int cot, jt; };
 
+// ring depth by tile area: small tiles need more items in flight to cover L2 latency
+template <int COT, int JT> constexpr int ring_depth() { return COT * JT <= 4 ? 4 : (COT * JT <= 8 ? 3 : 2); }
+
 template <int CK, bool IDENT>
 ConvKernel pick_kernel(int cot, int jt) {
-#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT>;
+#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT, ring_depth<C, J>()>;
     if constexpr (CK == 0) {
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
         CASE(8, 1) CASE(8, 2) CASE(8, 4)
@@ -349,19 +360,20 @@ ConvKernel pick_kernel(int cot, int jt) {
 }
 }  // namespace
 
-extern "C" int insmos_sparse_conv(const float* in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16,
-                                  int K, int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out,
-                                  int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
-                                  void* stream) {
+extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
+                                  const uint32_t* mask16, int K, int64_t n_out, const float* wpacked, const float* bias,
+                                  float* out, int ld_out, int cout, const float* res, int ld_res, int res_mode,
+                                  int relu_pre, int relu_post, void* stream) {
     if (n_out <= 0) return INSMOS_OK;
-    if (!in || !wpacked || !bias || !out || cin <= 0 || cin % 4 != 0 || ld_in % 4 != 0 || ld_in < cin || K <= 0 ||
-        K > 128 || (!nbr && K != 1) || cout <= 0 || ld_out < cout || (res_mode != 0 && !res) || ((uintptr_t)in & 15) ||
-        n_out * (int64_t)K >= (1ll << 31) || n_out * (int64_t)ld_in >= (1ll << 31))
+    if (!in || n_in <= 0 || !wpacked || !bias || !out || cin <= 0 || ld_in % 4 != 0 || ld_in < cin || K <= 0 || K > 128 ||
+        (!nbr && (K != 1 || n_in < n_out)) || cout <= 0 || ld_out < cout || (res_mode != 0 && !res) ||
+        ((uintptr_t)in & 15) || n_out * (int64_t)K * 4 >= (1ll << 31) || n_in * (int64_t)ld_in * 4 >= (1ll << 31))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ConvP P;
     P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
     P.n_out = (uint32_t)n_out;
+    P.in_bytes = (uint32_t)((n_in - 1) * (int64_t)ld_in * 4 + (int64_t)cin * 4);
     P.ld_in = ld_in; P.cin = cin; P.K = K; P.ld_out = ld_out; P.cout = cout; P.ld_res = ld_res; P.res_mode = res_mode;
     P.relu_pre = relu_pre; P.relu_post = relu_post;
     chunking(cin, P.n16, P.has8, P.has4);
@@ -373,24 +385,25 @@ extern "C" int insmos_sparse_conv(const float* in, int ld_in, int cin, const int
                       : 0;
     const int ck = (cin == 4 || cin == 8) ? cin : 0;
     if (!ck && (cin % 16 != 0)) return INSMOS_EINVAL;  // supported widths: 4, 8, or a multiple of 16
-    // tile shape: the largest (COT x JT) tile (ties: squarest) that still gives >= 2 waves per SIMD;
-    // if the layer is too small for that, the shape with the most waves.
+    // tile shape by a small cost model (cycles per work item, common factors dropped):
+    //   MFMA time  = 32 * NS * COT*JT per item per wave, times the number of wave "rounds" on 1024 SIMDs
+    //   load time  = bytes requested per item (JT gathers + COT weight fragments) at ~32 B/clk/CU (L2-hit rate)
     const int max_cot = ck ? 2 : 8;
+    const int ns = ck ? ck / 4 : 4;
+    const double gather_bytes = 64.0 * (ck == 4 ? 4 : ck == 8 ? 8 : 16);
     Cfg best = {1, 1};
-    long best_waves = -1;
-    bool found = false;
-    int best_area = 0, best_skew = 99;
+    double best_cost = 1e300;
+    long best_waves = 0;
     for (int cot = 1; cot <= max_cot; cot <<= 1) {
         if (P.ntile_co % cot) continue;
         for (int jt = 1; jt <= 4; jt <<= 1) {
-            long waves = (long)((n_out + 16 * jt - 1) / (16 * jt)) * (P.ntile_co / cot);
-            int area = cot * jt, skew = cot > jt ? cot / jt : jt / cot;
-            if (waves >= 2048) {
-                if (!found || area > best_area || (area == best_area && skew < best_skew)) {
-                    found = true; best = {cot, jt}; best_area = area; best_skew = skew; best_waves = waves;
-                }
-            } else if (!found && (waves > best_waves || (waves == best_waves && area > best_area))) {
-                best = {cot, jt}; best_waves = waves; best_area = area;
+            const long waves = (long)((n_out + 16 * jt - 1) / (16 * jt)) * (P.ntile_co / cot);
+            const double rounds = waves <= 8192 ? (double)((waves + 1023) / 1024) : waves / 1024.0;
+            const double t_mfma = 32.0 * ns * cot * jt * rounds;
+            const double t_load = waves * (jt * gather_bytes + cot * 1024.0) / (256.0 * 32.0);
+            const double cost = t_mfma > t_load ? t_mfma : t_load;
+            if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && waves > best_waves)) {
+                best_cost = cost; best = {cot, jt}; best_waves = waves;
             }
         }
     }

@@ -226,7 +226,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------
     def conv(self, layer, x, ld_in, nbr, n_out, out, ld_out, col_out=0, col_in=0, res=None, ld_res=0, col_res=0,
-             res_mode=0, relu_pre=0, relu_post=0):
+             res_mode=0, relu_pre=0, relu_post=0, n_in=None):
         """out[:, col_out:col_out+cout] = epilogue(conv(x[:, col_in:col_in+cin]))."""
         if n_out == 0:
             return
@@ -240,7 +240,7 @@ class Engine:
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record(torch.cuda.current_stream(self.device))
         rc = self.lib.insmos_sparse_conv(
-            x.data_ptr() + 4 * col_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None,
+            x.data_ptr() + 4 * col_in, x.shape[0] if n_in is None else n_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None,
             mask.data_ptr() if mask is not None else None, K, n_out,
             layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr() + 4 * col_out, ld_out, layer.cout,
             (res.data_ptr() + 4 * col_res) if res is not None else None, ld_res, res_mode, relu_pre, relu_post,
@@ -467,7 +467,7 @@ class Engine:
         self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
         ncell = 4 * nsite
         head = E((ncell, self.head_ld))
-        self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld)
+        self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld, n_in=ncell)  # upf viewed as (4*nsite, upc)
         H2, W2 = 2 * self.bevH, 2 * self.bevW
         cb, cs = E((self.pre_max, 7)), E((self.pre_max,))
         cl, cc = E((self.pre_max,), torch.int32), E((self.pre_max,), torch.int32)

@@ -65,7 +65,8 @@ def run_conv(layer, x, nbr, n_out, ld_out=None, col_out=0, res=None, res_mode=0,
     ld_out = ld_out or layer.cout
     if out is None:
         out = torch.zeros((n_out, ld_out), dtype=torch.float32, device=DEV)
-    rc = lib().insmos_sparse_conv(x.data_ptr(), x.stride(0), layer.cin, nbr.data_ptr() if nbr is not None else None,
+    rc = lib().insmos_sparse_conv(x.data_ptr(), x.shape[0], x.stride(0), layer.cin,
+                                  nbr.data_ptr() if nbr is not None else None,
                                   mask.data_ptr() if mask is not None else None,
                                   layer.K, n_out, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr() + 4 * col_out,
                                   ld_out, layer.cout, res.data_ptr() if res is not None else None,
