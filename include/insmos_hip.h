@@ -144,6 +144,10 @@ int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const 
                        int K, int64_t n_out, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
                        const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, void* stream);
 
+/* Tuning hook (tools/conv_tune.py): force generic non-identity layers onto tile shape (16*cot channels x
+ * 16*jt rows) with an operand ring of depth `ring`; cot == 0 restores the built-in cost model. */
+int insmos_debug_conv_force(int cot, int jt, int ring);
+
 /* ------------------------------------------------------------------------------------------------
  * insmos_dense_nbr2d -- full-grid 3x3 (pad 1) neighbour table for an H x W NHWC map, so that the
  * BEV Conv2d layers (base_bev_backbone.py:33-47; ZeroPad2d(1)+pad 0 == pad 1) run on insmos_sparse_conv.

@@ -32,6 +32,7 @@ SIGNATURES = {
     "insmos_pack_weights_host": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "insmos_sparse_conv": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
                                    c_int, c_int, c_int, c_int, c_vp]),
+    "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),
     "insmos_sparse_to_bev": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "insmos_center_decode_select_ws_bytes": (c_sz, [c_i64]),

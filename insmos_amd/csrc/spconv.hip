@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
 
     const uint32_t blk_stride = (uint32_t)P.ntile_co * 256u;   // floats between chunk blocks of one tap
     const uint32_t tap_stride = (uint32_t)P.nblk * blk_stride;  // floats between taps
-    const float* __restrict__ wbase = P.w + (cg * COT) * 256u + lane * 4u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)P.w, 0, (int)((uint32_t)P.K * tap_stride * 4u), 0x00020000);
+    const uint32_t woff = ((cg * COT) * 256u + lane * 4u) * 4u;
     constexpr int NS = CK ? CK / 4 : 4;  // MFMA steps per chunk
     const int nchunk = CK ? 1 : P.n16;
 
@@ -165,9 +167,12 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
                 b[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[jt], so, 0));
             }
         }
-        const float* wb = wbase + (uint32_t)k * tap_stride + (uint32_t)c * blk_stride;
+        // weight fragments through a buffer descriptor too: one load KIND in the loop keeps hipcc's
+        // vmcnt accounting exact (mixing global_ and buffer_ loads made it drain to vmcnt(0))
+        const uint32_t sw = ((uint32_t)k * tap_stride + (uint32_t)c * blk_stride) * 4u;
 #pragma unroll
-        for (int it = 0; it < COT; ++it) a[it] = *(const f32x4*)(wb + it * 256);
+        for (int it = 0; it < COT; ++it)
+            a[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff + (uint32_t)it * 1024u, sw, 0));
     };
     auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT]) {
 #pragma unroll
@@ -344,7 +349,7 @@ typedef void (*ConvKernel)(ConvP);
 struct Cfg { int cot, jt; };
 
 // ring depth by tile area: small tiles need more items in flight to cover L2 latency
-template <int COT, int JT> constexpr int ring_depth() { return COT * JT <= 4 ? 4 : (COT * JT <= 8 ? 3 : 2); }
+template <int COT, int JT> constexpr int ring_depth() { return COT * JT <= 2 ? 3 : 2; }
 
 template <int CK, bool IDENT>
 ConvKernel pick_kernel(int cot, int jt) {
@@ -355,6 +360,18 @@ ConvKernel pick_kernel(int cot, int jt) {
     } else {
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4)
     }
+#undef CASE
+    return nullptr;
+}
+
+// tuning hook (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring)
+int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0;
+ConvKernel pick_forced(int cot, int jt, int ring) {
+#define CASE(C, J, RR) if (cot == C && jt == J && ring == RR) return k_sparse_conv<C, J, 0, false, RR>;
+#define CASES(C, J) CASE(C, J, 2) CASE(C, J, 3) CASE(C, J, 4)
+    CASES(1, 1) CASES(1, 2) CASES(1, 4) CASES(2, 1) CASES(2, 2) CASES(2, 4) CASES(4, 1) CASES(4, 2) CASES(4, 4)
+    CASE(8, 1, 2) CASE(8, 1, 3) CASE(8, 2, 2) CASE(8, 2, 3) CASE(8, 4, 2)
+#undef CASES
 #undef CASE
     return nullptr;
 }
@@ -385,26 +402,20 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
                       : 0;
     const int ck = (cin == 4 || cin == 8) ? cin : 0;
     if (!ck && (cin % 16 != 0)) return INSMOS_EINVAL;  // supported widths: 4, 8, or a multiple of 16
-    // tile shape by a small cost model (cycles per work item, common factors dropped):
-    //   MFMA time  = 32 * NS * COT*JT per item per wave, times the number of wave "rounds" on 1024 SIMDs
-    //   load time  = bytes requested per item (JT gathers + COT weight fragments) at ~32 B/clk/CU (L2-hit rate)
-    const int max_cot = ck ? 2 : 8;
-    const int ns = ck ? ck / 4 : 4;
-    const double gather_bytes = 64.0 * (ck == 4 ? 4 : ck == 8 ? 8 : 16);
-    Cfg best = {1, 1};
-    double best_cost = 1e300;
-    long best_waves = 0;
-    for (int cot = 1; cot <= max_cot; cot <<= 1) {
-        if (P.ntile_co % cot) continue;
-        for (int jt = 1; jt <= 4; jt <<= 1) {
-            const long waves = (long)((n_out + 16 * jt - 1) / (16 * jt)) * (P.ntile_co / cot);
-            const double rounds = waves <= 8192 ? (double)((waves + 1023) / 1024) : waves / 1024.0;
-            const double t_mfma = 32.0 * ns * cot * jt * rounds;
-            const double t_load = waves * (jt * gather_bytes + cot * 1024.0) / (256.0 * 32.0);
-            const double cost = t_mfma > t_load ? t_mfma : t_load;
-            if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && waves > best_waves)) {
-                best_cost = cost; best = {cot, jt}; best_waves = waves;
-            }
+    // tile shape, from tools/conv_tune.py sweeps on MI355X: a 16-row gather is ~8x the cost of a coalesced
+    // weight fragment, so generic layers always use 16-row tiles (JT = 1) and widen in channels instead:
+    // 2 channel tiles per wave, 4 when the layer is large enough to still give >= 2 waves per SIMD (the
+    // dense BEV convs).  Single-chunk small-C layers (Cin 4/8) use `ck_jt` row groups per wave.
+    static int ck_jt = 0;
+    if (!ck_jt) { const char* e = getenv("INSMOS_CK_JT"); ck_jt = e ? atoi(e) : 2; if (ck_jt != 1 && ck_jt != 4) ck_jt = 2; }
+    Cfg best = {1, ck ? ck_jt : 1};
+    {
+        const long groups = (long)((n_out + 15) / 16);
+        if (!ck) {
+            if (P.ntile_co % 4 == 0 && groups * (P.ntile_co / 4) >= 2048) best.cot = 4;
+            else if (P.ntile_co % 2 == 0) best.cot = 2;
+        } else if (P.ntile_co % 2 == 0) {
+            best.cot = 2;
         }
     }
     P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
@@ -413,12 +424,25 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     if (ck == 4) kern = ident ? pick_kernel<4, true>(best.cot, best.jt) : pick_kernel<4, false>(best.cot, best.jt);
     else if (ck == 8) kern = ident ? pick_kernel<8, true>(best.cot, best.jt) : pick_kernel<8, false>(best.cot, best.jt);
     else kern = ident ? pick_kernel<0, true>(best.cot, best.jt) : pick_kernel<0, false>(best.cot, best.jt);
+    if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
+        ConvKernel fk = pick_forced(g_force_cot, g_force_jt, g_force_ring);
+        if (fk) {
+            kern = fk;
+            best = {g_force_cot, g_force_jt};
+            P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
+        }
+    }
     if (!kern) return INSMOS_EINVAL;
     long waves = (long)P.n_otiles * (P.ntile_co / best.cot);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     ProfScope ps(KK_SPARSE_CONV, s);
     hipLaunchKernelGGL(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {
+    g_force_cot = cot; g_force_jt = jt; g_force_ring = ring;
     return INSMOS_OK;
 }
 
