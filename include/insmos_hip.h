@@ -61,11 +61,32 @@ int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* q
  * creates (models/MinkowskiEngine/minkunet.py:63-89): floor(c / 2s) * 2s in x,y,z, t untouched.
  * Because keys are Morton-in-space this is a prefix de-duplication of the sorted key array.
  *   shift = log2 of the OUTPUT tensor stride (1,2,3).  parent (n) i32 = fine row -> coarse row.
- *   counts[0] = #coarse voxels.
+ *   child_start (cap n) i32 = first fine row of each coarse voxel, child_mask (cap n) u32 = which of its
+ *   8 octants (x | y<<1 | z<<2) are occupied (both optional).  counts[0] = #coarse voxels.
  * ---------------------------------------------------------------------------------------------- */
 size_t insmos_level_down4d_ws_bytes(int64_t n);
 int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,
-                        int32_t* parent, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+                        int32_t* parent, int32_t* child_start, uint32_t* child_mask, int32_t* counts, void* ws,
+                        size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Search-free kernel maps from the Morton hierarchy (same tables insmos_build_nbr would produce, same
+ * reference call sites: minkunet.py:55-124).  A coarse voxel's children are contiguous in key order,
+ * so with child_start / child_mask (the 8-bit octant occupancy) from insmos_level_down4d:
+ *   insmos_nbr_from_coarse: fine-level table for taps delta_host (K,4) ([x,y,z,t] in finest-voxel units,
+ *     |spatial offset| <= 2 fine strides, |dt| <= 1) from the COARSE level's 81-tap (3x3x3x3, x fastest)
+ *     table: neighbour = child of the matching neighbour block -- no key search at all.
+ *   insmos_nbr_down_up: the kernel [2,2,2,1] / stride [2,2,2,1] conv map (dn: (8, n_c), tap = octant)
+ *     and its transpose (up: (8, n_f)).
+ *   fine_shift = log2 of the fine level's tensor stride.  mask16 outputs as in insmos_build_nbr.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                           const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                           const uint32_t* child_mask, const int32_t* delta_host, int K, int32_t* nbr,
+                           uint32_t* mask16, void* stream);
+int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift, int64_t n_c,
+                       const int32_t* child_start, const uint32_t* child_mask, int32_t* dn, uint32_t* dn_mask16,
+                       int32_t* up, uint32_t* up_mask16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * insmos_build_nbr -- the kernel map / indice pairs ("rulebook") in output-stationary form:

@@ -117,7 +117,8 @@ __global__ void k_compact_index(const int32_t* __restrict__ flag, const int32_t*
 __global__ void k_level_down_scatter(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flag,
                                      const int32_t* __restrict__ scan, int64_t n, int shift_bits,
                                      uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
-                                     int32_t* __restrict__ parent, int32_t* __restrict__ counts) {
+                                     int32_t* __restrict__ parent, int32_t* __restrict__ child_start,
+                                     uint32_t* __restrict__ child_mask, int32_t* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int vid = scan[i] - 1;
@@ -127,9 +128,84 @@ __global__ void k_level_down_scatter(const uint64_t* __restrict__ keys, const in
         int x, y, z, t;
         key4_decode(k, x, y, z, t);
         *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
+        if (child_start) child_start[vid] = (int32_t)i;
     }
     parent[i] = vid;
+    // octant of the fine voxel inside its parent = the 3 Morton bits just below the parent's stride
+    if (child_mask) atomicOr(&child_mask[vid], 1u << (unsigned)((keys[i] >> (shift_bits - 3)) & 7ull));
     if (i == n - 1) counts[0] = scan[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// search-free neighbour tables from the Morton hierarchy
+// ---------------------------------------------------------------------------------------------------
+struct TapList { int delta[128][4]; int K; };
+
+// nbr[k][o] for fine voxels (tensor stride 2^L) from the COARSE level's 3x3x3x3 table: the neighbour's
+// parent block is one of the 27(x3 in time) blocks around the voxel's own parent; inside that block the
+// children are contiguous in Morton order, so its row is child_start + popcount(mask below its octant).
+__global__ void __launch_bounds__(256) k_nbr_from_coarse(const int32_t* __restrict__ coords, int64_t n_f,
+                                                         const int32_t* __restrict__ parent, int L,
+                                                         const int32_t* __restrict__ cnbr, int64_t n_c,
+                                                         const int32_t* __restrict__ child_start,
+                                                         const uint32_t* __restrict__ child_mask, TapList T,
+                                                         int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (o >= n_f) return;
+    int4 c = *(const int4*)(coords + o * 4);
+    const int nx = c.x + T.delta[k][0], ny = c.y + T.delta[k][1], nz = c.z + T.delta[k][2], dt = T.delta[k][3];
+    const int s1 = L + 1;
+    const int bx = (nx >> s1) - (c.x >> s1), by = (ny >> s1) - (c.y >> s1), bz = (nz >> s1) - (c.z >> s1);
+    int32_t r = -1;
+    if (bx >= -1 && bx <= 1 && by >= -1 && by <= 1 && bz >= -1 && bz <= 1 && dt >= -1 && dt <= 1) {
+        const int ctap = (bx + 1) + 3 * (by + 1) + 9 * (bz + 1) + 27 * (dt + 1);
+        const int q = cnbr[(int64_t)ctap * n_c + parent[o]];
+        if (q >= 0) {
+            const unsigned oct = ((nx >> L) & 1) | (((ny >> L) & 1) << 1) | (((nz >> L) & 1) << 2);
+            const uint32_t m = child_mask[q];
+            if ((m >> oct) & 1u) r = child_start[q] + __popc(m & ((1u << oct) - 1u));
+        }
+    }
+    nbr[(int64_t)k * n_f + o] = r;
+    if (mask16) {
+        const unsigned long long bal = __ballot(r >= 0);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(o >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+    }
+}
+
+// strided k2s2 conv (coarse p reads child octant k) and its transpose (fine f reads its parent through k = octant(f))
+__global__ void __launch_bounds__(256) k_nbr_down(int64_t n_c, const int32_t* __restrict__ child_start,
+                                                  const uint32_t* __restrict__ child_mask, int32_t* __restrict__ dn,
+                                                  uint32_t* __restrict__ mask16) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (p >= n_c) return;
+    const uint32_t m = child_mask[p];
+    int32_t r = ((m >> k) & 1u) ? child_start[p] + __popc(m & ((1u << k) - 1u)) : -1;
+    dn[(int64_t)k * n_c + p] = r;
+    if (mask16) {
+        const unsigned long long bal = __ballot(r >= 0);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(p >> 4) * 4], 1u << k);
+    }
+}
+__global__ void __launch_bounds__(256) k_nbr_up(const int32_t* __restrict__ coords, int64_t n_f,
+                                                const int32_t* __restrict__ parent, int L, int32_t* __restrict__ up,
+                                                uint32_t* __restrict__ mask16) {
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (f >= n_f) return;
+    int4 c = *(const int4*)(coords + f * 4);
+    const int oct = ((c.x >> L) & 1) | (((c.y >> L) & 1) << 1) | (((c.z >> L) & 1) << 2);
+    int32_t r = (oct == k) ? parent[f] : -1;
+    up[(int64_t)k * n_f + f] = r;
+    if (mask16) {
+        const unsigned long long bal = __ballot(r >= 0);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(f >> 4) * 4], 1u << k);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -375,7 +451,8 @@ extern "C" size_t insmos_level_down4d_ws_bytes(int64_t n) {
 }
 
 extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,
-                                   int32_t* parent, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+                                   int32_t* parent, int32_t* child_start, uint32_t* child_mask, int32_t* counts,
+                                   void* ws, size_t ws_bytes, void* stream) {
     if (n <= 0 || shift < 1 || shift > 15) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     Bump b(ws, ws_bytes);
@@ -393,8 +470,9 @@ extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, u
     if (rc) return rc;
     {
         ProfScope ps(KK_LEVEL_DOWN, s);
+        if (child_mask) HIP_TRY(hipMemsetAsync(child_mask, 0, (size_t)n * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
-                           out_coords, parent, counts);
+                           out_coords, parent, child_start, child_mask, counts);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -545,6 +623,42 @@ extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, cons
         hipLaunchKernelGGL(k_down_scatter, dim3(g), dim3(TPB), 0, s, cand_s, flag, scan, (int64_t)N, P.oshape[1],
                            P.oshape[2], cap, out_keys, out_coords, counts);
     }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                                      const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                      const uint32_t* child_mask, const int32_t* delta_host, int K, int32_t* nbr,
+                                      uint32_t* mask16, void* stream) {
+    if (n_f <= 0 || n_c <= 0 || K <= 0 || K > 128 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
+        !child_mask || !delta_host || !nbr || fine_shift < 0 || fine_shift > 14)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    TapList T;
+    memset(&T, 0, sizeof(T));
+    for (int k = 0; k < K; ++k)
+        for (int d = 0; d < 4; ++d) T.delta[k][d] = delta_host[k * 4 + d];
+    T.K = K;
+    ProfScope ps(KK_BUILD_NBR, s);
+    if (mask16) HIP_TRY(hipMemsetAsync(mask16, 0, (size_t)((n_f + 15) / 16) * 4 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_nbr_from_coarse, dim3(cdiv(n_f, TPB), (unsigned)K), dim3(TPB), 0, s, fine_coords, n_f, parent,
+                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, T, nbr, mask16);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                                  int64_t n_c, const int32_t* child_start, const uint32_t* child_mask, int32_t* dn,
+                                  uint32_t* dn_mask16, int32_t* up, uint32_t* up_mask16, void* stream) {
+    if (n_f <= 0 || n_c <= 0 || !fine_coords || !parent || !child_start || !child_mask || !dn || !up) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_BUILD_NBR, s);
+    if (dn_mask16) HIP_TRY(hipMemsetAsync(dn_mask16, 0, (size_t)((n_c + 15) / 16) * 4 * sizeof(uint32_t), s));
+    if (up_mask16) HIP_TRY(hipMemsetAsync(up_mask16, 0, (size_t)((n_f + 15) / 16) * 4 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_nbr_down, dim3(cdiv(n_c, TPB), 8), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
+    hipLaunchKernelGGL(k_nbr_up, dim3(cdiv(n_f, TPB), 8), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
+                       up_mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -291,26 +291,55 @@ class Engine:
         keys = [keys0[:n0]]
         coords = [coords0[:n0]]
         n = [n0]
+        parent, child_start, child_mask = [], [], []  # index l: maps level l -> level l+1
         for l in (1, 2, 3):
             kk = self._empty((n[-1],), torch.int64)
             cc = self._empty((n[-1], 4), torch.int32)
             par = self._empty((n[-1],), torch.int32)
+            cst = self._empty((n[-1],), torch.int32)
+            cmk = self._empty((n[-1],), torch.int32)
             ws = self._workspace(lib.insmos_level_down4d_ws_bytes(n[-1]))
-            # always derived from level 0 so each level's parent map is w.r.t. the finest voxels;
-            # cheaper: derive level l from level l-1 (its keys already have the lower bits cleared)
+            # level l from level l-1 (its keys already have the lower bits cleared)
             _lib.check(lib.insmos_level_down4d(keys[-1].data_ptr(), n[-1], l, kk.data_ptr(), cc.data_ptr(),
-                                               par.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), st),
-                       "insmos_level_down4d")
+                                               par.data_ptr(), cst.data_ptr(), cmk.data_ptr(), counts.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), st), "insmos_level_down4d")
             nl = int(counts[0].item())
             keys.append(kk[:nl])
             coords.append(cc[:nl])
             n.append(nl)
+            parent.append(par)
+            child_start.append(cst)
+            child_mask.append(cmk)
         self.last_counts["me_voxels"] = list(n)
         self.last_counts["n_cur"] = ncur
-        nbr125 = self.build_nbr(coords[0], n[0], keys[0], None, n[0], 0, None, self.off125)
-        nbr81 = [self.build_nbr(coords[l], n[l], keys[l], None, n[l], 0, None, self.off81[l]) for l in range(4)]
-        dn = [self.build_nbr(coords[l + 1], n[l + 1], keys[l], None, n[l], 0, None, self.off8[l]) for l in range(3)]
-        up = [self.build_nbr(coords[l], n[l], keys[l + 1], None, n[l + 1], 0, None, -self.off8[l]) for l in range(3)]
+
+        def table(K, n_out):
+            return (self._empty((K, n_out), torch.int32), self._empty(((n_out + 15) // 16, 4), torch.int32))
+
+        def from_coarse(l, offs, coarse):
+            """level-l table for taps `offs` from the level-(l+1) 81-tap table: no key search."""
+            nb, mk = table(len(offs), n[l])
+            _lib.check(lib.insmos_nbr_from_coarse(coords[l].data_ptr(), n[l], parent[l].data_ptr(), l,
+                                                  coarse.nbr.data_ptr(), n[l + 1], child_start[l].data_ptr(),
+                                                  child_mask[l].data_ptr(), _hp(offs), len(offs), nb.data_ptr(),
+                                                  mk.data_ptr(), st), "insmos_nbr_from_coarse")
+            return NbrTable(nb, mk)
+
+        # only the coarsest level is searched; every finer table is derived through the Morton hierarchy
+        nbr81 = [None, None, None, self.build_nbr(coords[3], n[3], keys[3], None, n[3], 0, None, self.off81[3])]
+        for l in (2, 1, 0):
+            nbr81[l] = from_coarse(l, self.off81[l], nbr81[l + 1])
+        nbr125 = from_coarse(0, self.off125, nbr81[1])
+        dn, up = [], []
+        for l in range(3):
+            d_nb, d_mk = table(8, n[l + 1])
+            u_nb, u_mk = table(8, n[l])
+            _lib.check(lib.insmos_nbr_down_up(coords[l].data_ptr(), n[l], parent[l].data_ptr(), l, n[l + 1],
+                                              child_start[l].data_ptr(), child_mask[l].data_ptr(), d_nb.data_ptr(),
+                                              d_mk.data_ptr(), u_nb.data_ptr(), u_mk.data_ptr(), st),
+                       "insmos_nbr_down_up")
+            dn.append(NbrTable(d_nb, d_mk))
+            up.append(NbrTable(u_nb, u_mk))
         self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse)
 
         L, E = self.L, self._empty
