@@ -230,7 +230,7 @@ int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const
  *   coords (n,4) [b,z,y,x] int voxel indices of the level; the test uses the integer index (no +0.5).
  *   quirk_exact != 0 reproduces the order-dependent early-skip of Array_Index.cpp:48-51.
  *   onehot: fp32 written into out[i*ld_out + c], c < ncls (+ zero pad up to pad_to columns).
- *   scratch: (16*max_boxes) i32 device scratch (per-box first-hit voxel + box in voxel units).
+ *   scratch: (20*max_boxes + n) i32 device scratch (per-box first-hit voxel + box in voxel units).
  * ---------------------------------------------------------------------------------------------- */
 int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
                            int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,

@@ -188,27 +188,44 @@ __global__ void k_iou_bev(const float* __restrict__ a, int na, const float* __re
     out[t] = iou_bev_dev(A, B);
 }
 
-// 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed)
-__global__ void __launch_bounds__(64) k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ n_dev,
-                                                 int max_n, float thresh, uint64_t* __restrict__ mask) {
+// 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed).
+// 256 threads: wave w owns rows rb*64 + 16w .. +15, lane = column; the 64-bit mask word of a row is the
+// wave ballot.  Pairs whose circumscribed circles (grown by the corner MARGIN of check_in_box2d) are
+// disjoint cannot overlap: the reference's clipping yields exactly 0 for them, so they are skipped.
+__global__ void __launch_bounds__(256) k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ n_dev,
+                                                  int max_n, float thresh, uint64_t* __restrict__ mask) {
     const int n = min(n_dev[0], max_n);
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
     const int cbs = (max_n + 63) / 64;
-    __shared__ float col[64 * 7];
-    const int csize = min(n - cb * 64, 64), rsize = min(n - rb * 64, 64);
-    if ((int)threadIdx.x < csize)
-        for (int d = 0; d < 7; ++d) col[threadIdx.x * 7 + d] = boxes[(int64_t)(cb * 64 + threadIdx.x) * 7 + d];
-    __syncthreads();
-    if ((int)threadIdx.x < rsize) {
+    __shared__ float rowb[64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {
         const int i = rb * 64 + threadIdx.x;
-        float A[7];
-        for (int d = 0; d < 7; ++d) A[d] = boxes[(int64_t)i * 7 + d];
-        uint64_t t = 0;
-        int start = (rb == cb) ? threadIdx.x + 1 : 0;
-        for (int j = start; j < csize; ++j)
-            if (iou_bev_dev(A, col + j * 7) > thresh) t |= 1ull << j;
-        mask[(int64_t)i * cbs + cb] = t;
+        for (int d = 0; d < 7; ++d) rowb[threadIdx.x * 8 + d] = i < n ? boxes[(int64_t)i * 7 + d] : 0.f;
+        rowb[threadIdx.x * 8 + 7] = i < n ? 0.5f * sqrtf(rowb[threadIdx.x * 8 + 3] * rowb[threadIdx.x * 8 + 3] +
+                                                          rowb[threadIdx.x * 8 + 4] * rowb[threadIdx.x * 8 + 4]) + 0.05f
+                                          : 0.f;
+    }
+    __syncthreads();
+    const int j = cb * 64 + lane;
+    float B[7] = {0, 0, 0, 1, 1, 1, 0};
+    float rj = 0.f;
+    if (j < n) {
+        for (int d = 0; d < 7; ++d) B[d] = boxes[(int64_t)j * 7 + d];
+        rj = 0.5f * sqrtf(B[3] * B[3] + B[4] * B[4]) + 0.05f;
+    }
+    for (int r = 0; r < 16; ++r) {
+        const int il = w * 16 + r, i = rb * 64 + il;
+        if (i >= n) break;  // wave-uniform
+        const float* A = rowb + il * 8;
+        bool hit = false;
+        if (j < n && j > i) {
+            const float dx = A[0] - B[0], dy = A[1] - B[1], rr = A[7] + rj;
+            if (dx * dx + dy * dy <= rr * rr) hit = iou_bev_dev(A, B) > thresh;
+        }
+        const unsigned long long word = __ballot(hit);
+        if (lane == 0) mask[(int64_t)i * cbs + cb] = word;
     }
 }
 
@@ -281,82 +298,105 @@ __global__ void k_gather_preds(const float* __restrict__ cb, const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // point-in-rotated-box one-hot features (Array_Index.cpp:14-79), exact incl. the first-hit early skip
 // ---------------------------------------------------------------------------------------------------
-struct BoxVox { float c[3], e[3], cs, sn; int label; int pad[3]; };  // 12 x 4 bytes
+// box in voxel units; h = e/2 (division by 2 is exact, so hoisting it changes nothing); rad = conservative
+// xy radius (+1 voxel) for an integer-free cull that can only reject voxels the exact test rejects too
+struct BoxVox { float c[3], e[3], cs, sn; int label; float h[3]; float rad; float pad[3]; };  // 16 x 4 bytes
 
 __device__ __forceinline__ bool inside_box(const BoxVox& b, int x, int y, int z) {
     float c0 = x - b.c[0], c1 = y - b.c[1], c2 = z - b.c[2];
+    if (fabsf(c0) > b.rad || fabsf(c1) > b.rad || fabsf(c2) > b.h[2] + 1.0f) return false;
     float r0 = c0 * b.cs + c1 * b.sn;
     float r1 = -c0 * b.sn + c1 * b.cs;
-    return (r0 <= b.e[0] / 2) && (r0 >= -b.e[0] / 2) && (r1 <= b.e[1] / 2) && (r1 >= -b.e[1] / 2) &&
-           (c2 <= b.e[2] / 2) && (c2 >= -b.e[2] / 2);
+    return (r0 <= b.h[0]) && (r0 >= -b.h[0]) && (r1 <= b.h[1]) && (r1 >= -b.h[1]) && (c2 <= b.h[2]) && (c2 >= -b.h[2]);
 }
 
 struct OneHotP { float lo[3], iv[3]; float istr, mult; };
 
-// one block per box: box -> voxel units, first hit (min voxel row inside) by block reduction
-__global__ void __launch_bounds__(256) k_onehot_first(const float* __restrict__ boxes, const int64_t* __restrict__ labels,
-                                                      const int32_t* __restrict__ m_dev, int max_boxes, OneHotP P,
-                                                      const int32_t* __restrict__ coords, int64_t n,
-                                                      int32_t* __restrict__ first, BoxVox* __restrict__ bv) {
-    const int b = blockIdx.x;
-    const int m = min(m_dev[0], max_boxes);
-    if (b >= m) return;
-    __shared__ BoxVox sb;
-    __shared__ int smin;
-    if (threadIdx.x == 0) {
-        const float* bx = boxes + (int64_t)b * 7;
-        for (int d = 0; d < 3; ++d) {
-            // spconv_unet.py:324-329 on the CUDA path: (x - lo) * (1/v) * (1/stride), then *2 per level
-            sb.c[d] = (((bx[d] - P.lo[d]) * P.iv[d]) * P.istr) * P.mult;
-            sb.e[d] = ((bx[3 + d] * P.iv[d]) * P.istr) * P.mult;
-        }
-        double th = (double)bx[6];
-        sb.cs = (float)cos(th);
-        sb.sn = (float)sin(th);
-        sb.label = (int)(float)labels[b];
-        smin = 0x7fffffff;
-        bv[b] = sb;
+// boxes -> voxel units of the level (one thread per box)
+__global__ void k_onehot_boxes(const float* __restrict__ boxes, const int64_t* __restrict__ labels,
+                               const int32_t* __restrict__ m_dev, int max_boxes, OneHotP P, int32_t* __restrict__ first,
+                               BoxVox* __restrict__ bv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= max_boxes) return;
+    first[b] = 0x7fffffff;
+    if (b >= min(m_dev[0], max_boxes)) return;
+    BoxVox sb;
+    const float* bx = boxes + (int64_t)b * 7;
+    for (int d = 0; d < 3; ++d) {
+        // spconv_unet.py:324-329 on the CUDA path: (x - lo) * (1/v) * (1/stride), then *2 per level
+        sb.c[d] = (((bx[d] - P.lo[d]) * P.iv[d]) * P.istr) * P.mult;
+        sb.e[d] = ((bx[3 + d] * P.iv[d]) * P.istr) * P.mult;
+        sb.h[d] = sb.e[d] / 2;
     }
-    __syncthreads();
-    BoxVox lb = sb;
-    int mine = 0x7fffffff;
-    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
-        int4 q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
-        if (inside_box(lb, q.w, q.z, q.y)) { mine = (int)j; break; }  // ascending j per thread: first hit is its min
-    }
-    atomicMin(&smin, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) first[b] = smin;
+    const double th = (double)bx[6];
+    sb.cs = (float)cos(th);
+    sb.sn = (float)sin(th);
+    sb.label = (int)(float)labels[b];
+    // |rotated coords| <= h  =>  |c0|,|c1| <= sqrt(h0^2 + h1^2); +1 voxel and 1e-3 relative slack
+    sb.rad = sqrtf(sb.h[0] * sb.h[0] + sb.h[1] * sb.h[1]) * 1.001f + 1.0f;
+    sb.pad[0] = sb.pad[1] = sb.pad[2] = 0.f;
+    bv[b] = sb;
 }
 
-__global__ void __launch_bounds__(256) k_onehot_mark(const int32_t* __restrict__ m_dev, int max_boxes,
+// grid (voxel blocks, box chunks of 64): the chunk's boxes sit in LDS, each thread owns one voxel.
+// PASS 0: first hit per box (min voxel row inside) -> atomicMin.   PASS 1: class bits per voxel -> atomicOr.
+template <int PASS>
+__global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__ m_dev, int max_boxes,
                                                      const int32_t* __restrict__ coords, int64_t n,
-                                                     const int32_t* __restrict__ first, const BoxVox* __restrict__ bv,
-                                                     int ncls, int pad_to, int quirk, float* __restrict__ out, int ld_out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                     int32_t* __restrict__ first, const BoxVox* __restrict__ bv, int ncls,
+                                                     int quirk, uint32_t* __restrict__ vbits) {
     const int m = min(m_dev[0], max_boxes);
+    const int b0 = blockIdx.y * 64;
+    if (b0 >= m) return;
+    const int nb = min(64, m - b0);
+    __shared__ BoxVox sb[64];
+    __shared__ int sfirst[64];
+    __shared__ int sfx[64], sfy[64], sfz[64];
+    if ((int)threadIdx.x < nb) {
+        sb[threadIdx.x] = bv[b0 + threadIdx.x];
+        if (PASS == 1) {
+            const int f = first[b0 + threadIdx.x];
+            sfirst[threadIdx.x] = f;
+            if (f != 0x7fffffff) {
+                int4 fq = *(const int4*)(coords + (int64_t)f * 4);
+                sfx[threadIdx.x] = fq.w; sfy[threadIdx.x] = fq.z; sfz[threadIdx.x] = fq.y;
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    int4 q = *(const int4*)(coords + j * 4);
+    const int4 q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
     const int x = q.w, y = q.z, z = q.y;
     unsigned bits = 0;
-    for (int b = 0; b < m; ++b) {
-        const int f = first[b];
-        if (f == 0x7fffffff) continue;  // box contains no voxel at all
-        const BoxVox bb = bv[b];
-        if (quirk && j != f) {
-            // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
-            // extend[d] from the first-hit voxel.  Rows before the first hit are not inside by definition.
-            if (j < f) continue;
-            int4 fq = *(const int4*)(coords + (int64_t)f * 4);
-            const int fx = fq.w, fy = fq.z, fz = fq.y;
-            if (x > (fx + bb.e[0]) || x < (fx - bb.e[0]) || y > (fy + bb.e[1]) || y < (fy - bb.e[1]) ||
-                z > (fz + bb.e[2]) || z < (fz - bb.e[2]))
-                continue;
+    for (int i = 0; i < nb; ++i) {
+        const BoxVox& bb = sb[i];
+        if (PASS == 0) {
+            if (inside_box(bb, x, y, z)) atomicMin(&first[b0 + i], (int)j);
+        } else {
+            const int f = sfirst[i];
+            if (f == 0x7fffffff) continue;  // box contains no voxel at all
+            if (quirk && j != f) {
+                // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
+                // extend[d] from the first-hit voxel.  Rows before the first hit are not inside by definition.
+                if (j < f) continue;
+                if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
+                    z > (sfz[i] + bb.e[2]) || z < (sfz[i] - bb.e[2]))
+                    continue;
+            }
+            if (bb.label > 0 && bb.label <= ncls && inside_box(bb, x, y, z)) bits |= 1u << (bb.label - 1);
         }
-        if (bb.label > 0 && bb.label <= ncls && inside_box(bb, x, y, z)) bits |= 1u << (bb.label - 1);
     }
-    float* o = out + j * ld_out;
-    for (int c = 0; c < pad_to; ++c) o[c] = (c < ncls && ((bits >> c) & 1u)) ? 1.0f : 0.0f;
+    if (PASS == 1 && bits) atomicOr(&vbits[j], bits);
+}
+
+__global__ void k_onehot_write(const uint32_t* __restrict__ vbits, int64_t n, int ncls, int pad_to,
+                               float* __restrict__ out, int ld_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * pad_to) return;
+    const int64_t j = t / pad_to;
+    const int c = (int)(t % pad_to);
+    out[j * ld_out + c] = (c < ncls && ((vbits[j] >> c) & 1u)) ? 1.0f : 0.0f;
 }
 
 }  // namespace insmos
@@ -419,7 +459,7 @@ extern "C" int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, 
     if (!b.ok) return INSMOS_EWORKSPACE;
     {
         ProfScope ps(KK_NMS_MASK, s);
-        hipLaunchKernelGGL(k_nms_mask, dim3(cbs, cbs), dim3(64), 0, s, boxes, n_dev, max_n, thresh, mask);
+        hipLaunchKernelGGL(k_nms_mask, dim3(cbs, cbs), dim3(256), 0, s, boxes, n_dev, max_n, thresh, mask);
     }
     {
         ProfScope ps(KK_NMS_REDUCE, s);
@@ -466,12 +506,18 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     P.istr = 1.0f / stride;
     P.mult = mult;
     int32_t* first = scratch;
-    BoxVox* bv = (BoxVox*)(scratch + ((max_boxes + 3) & ~3));
+    BoxVox* bv = (BoxVox*)(scratch + ((max_boxes + 3) & ~3));  // 16 ints per box
+    uint32_t* vbits = (uint32_t*)(scratch + 20 * (size_t)max_boxes);
     ProfScope ps(KK_ONEHOT, s);
-    hipLaunchKernelGGL(k_onehot_first, dim3(max_boxes), dim3(256), 0, s, pred_boxes, pred_labels, n_boxes_dev, max_boxes,
-                       P, coords, n, first, bv);
-    hipLaunchKernelGGL(k_onehot_mark, dim3(cdiv(n, 256)), dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv,
-                       ncls, pad_to, quirk_exact, out, ld_out);
+    HIP_TRY(hipMemsetAsync(vbits, 0, (size_t)n * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_onehot_boxes, dim3(cdiv(max_boxes, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
+                       max_boxes, P, first, bv);
+    dim3 grid(cdiv(n, 256), cdiv(max_boxes, 64));
+    hipLaunchKernelGGL(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
+                       quirk_exact, vbits);
+    hipLaunchKernelGGL(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
+                       quirk_exact, vbits);
+    hipLaunchKernelGGL(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

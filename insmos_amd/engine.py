@@ -522,7 +522,7 @@ class Engine:
                                 keep=keep, spatial_features_2d=upf, bev=bev)
 
         # ---- upsample fusion (spconv_unet.py:319-402)
-        scratch = E((16 * self.post_max,), torch.int32)
+        scratch = E((20 * self.post_max + max(nv.values()),), torch.int32)
         lo = np.array(self.range[0:3], dtype=np.float32)
 
         def onehot(level, mult, out, ld, col):
