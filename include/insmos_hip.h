@@ -132,8 +132,9 @@ int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, int n_feat,
  * (spconv_unet.py:135-160: k3 s2 p1 x3, (3,1,1) s(2,1,1) p0): o active iff some tap reads an active
  * input (i = o*stride - pad + k), 0 <= o < out_shape.  Canonical order: ascending linear index.
  *   out_keys/out_coords capacity = min(n_in*K, prod(out_shape)) rows; counts[0] = #outputs.
+ *   Implementation: occupancy bitmap of the output grid + popcount rank scan (no sort).
  * ---------------------------------------------------------------------------------------------- */
-size_t insmos_down_coords3d_ws_bytes(int64_t n_in, int K);
+size_t insmos_down_coords3d_ws_bytes(const int32_t* out_shape_host);
 int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
                          const int32_t* stride_host, const int32_t* pad_host, const int32_t* out_shape_host,
                          uint64_t* out_keys, int32_t* out_coords, int32_t* counts, void* ws, size_t ws_bytes,

@@ -28,7 +28,7 @@ SIGNATURES = {
     "insmos_voxelize_mean_ws_bytes": (c_sz, [c_i64]),
     "insmos_voxelize_mean": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp,
                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "insmos_down_coords3d_ws_bytes": (c_sz, [c_i64, c_int]),
+    "insmos_down_coords3d_ws_bytes": (c_sz, [c_vp]),
     "insmos_down_coords3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_packed_weight_floats": (c_sz, [c_int, c_int, c_int]),
     "insmos_pack_weights_host": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),

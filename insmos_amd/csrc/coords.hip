@@ -352,8 +352,9 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
 // ---------------------------------------------------------------------------------------------------
 struct DownParams { int ks[3], st[3], pd[3], oshape[3]; };
 
-__global__ void k_down_candidates(const int32_t* __restrict__ in_coords, int64_t n_in, int K, DownParams P,
-                                  uint64_t* __restrict__ cand) {
+// mark every output cell some tap of some active input reaches, in an occupancy bitmap of the output grid
+__global__ void k_down_mark(const int32_t* __restrict__ in_coords, int64_t n_in, int K, DownParams P,
+                            uint32_t* __restrict__ bitmap) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_in * K) return;
     int64_t i = t / K;
@@ -361,28 +362,35 @@ __global__ void k_down_candidates(const int32_t* __restrict__ in_coords, int64_t
     int kx = k % P.ks[2], ky = (k / P.ks[2]) % P.ks[1], kz = k / (P.ks[2] * P.ks[1]);
     int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
     int nz = c.y + P.pd[0] - kz, ny = c.z + P.pd[1] - ky, nx = c.w + P.pd[2] - kx;
-    uint64_t key = INSMOS_INVALID_KEY;
-    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % P.st[0] == 0 && ny % P.st[1] == 0 && nx % P.st[2] == 0)
-        key = key3_encode(nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
-    cand[t] = key;
-}
-
-__global__ void k_down_scatter(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ flag,
-                               const int32_t* __restrict__ scan, int64_t n, int H, int W, int64_t cap,
-                               uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
-                               int32_t* __restrict__ counts) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) {
-        int vid = scan[i] - 1;
-        if (vid < cap) {
-            uint64_t k = keys_s[i];
-            okeys[vid] = k;
-            int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(k / ((uint64_t)W * H));
-            *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(0, z, y, x);
-        }
+    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % P.st[0] == 0 && ny % P.st[1] == 0 && nx % P.st[2] == 0) {
+        uint64_t key = key3_encode(nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
+        if (key != INSMOS_INVALID_KEY) atomicOr(&bitmap[key >> 5], 1u << (unsigned)(key & 31));
     }
-    if (i == n - 1) counts[0] = scan[i];
+}
+__global__ void k_word_popc(const uint32_t* __restrict__ bitmap, int64_t nwords, int32_t* __restrict__ cnt) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) cnt[w] = __popc(bitmap[w]);
+}
+// ascending linear order falls out of the bitmap: row of a cell = (#set bits in lower words) + rank inside its word
+__global__ void k_down_expand(const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ scan, int64_t nwords,
+                              int H, int W, int64_t cap, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                              int32_t* __restrict__ counts) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t m = bitmap[w];
+    int base = scan[w] - __popc(m);  // scan is inclusive
+    while (m) {
+        int b = __ffs(m) - 1;
+        m &= m - 1;
+        if (base < cap) {
+            uint64_t k = (uint64_t)w * 32 + b;
+            okeys[base] = k;
+            int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(k / ((uint64_t)W * H));
+            *(int4*)(ocoords + (int64_t)base * 4) = make_int4(0, z, y, x);
+        }
+        ++base;
+    }
+    if (w == nwords - 1) counts[0] = scan[w];
 }
 
 }  // namespace insmos
@@ -576,10 +584,9 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     return INSMOS_OK;
 }
 
-extern "C" size_t insmos_down_coords3d_ws_bytes(int64_t n_in, int K) {
-    size_t N = (size_t)n_in * (size_t)K;
-    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
-    return pad256(N * 8) * 2 + pad256(N * 4) * 2 + (st > sc ? st : sc) + 1024;
+extern "C" size_t insmos_down_coords3d_ws_bytes(const int32_t* out_shape_host) {
+    size_t nwords = ((size_t)out_shape_host[0] * out_shape_host[1] * out_shape_host[2] + 31) / 32;
+    return pad256(nwords * 4) * 3 + scan_i32_temp(nwords) + 1024;
 }
 
 extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
@@ -594,33 +601,29 @@ extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, cons
         P.ks[d] = ksize_host[d]; P.st[d] = stride_host[d]; P.pd[d] = pad_host[d]; P.oshape[d] = out_shape_host[d];
         K *= ksize_host[d];
     }
-    size_t N = (size_t)n_in * (size_t)K;
-    int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2];
-    int64_t cap = (int64_t)N < cells ? (int64_t)N : cells;
+    const int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2];
+    if (cells <= 0 || cells >= (1ll << 36)) return INSMOS_EINVAL;
+    const int64_t N = n_in * K;
+    const int64_t cap = N < cells ? N : cells;
+    const int64_t nwords = (cells + 31) / 32;
     Bump b(ws, ws_bytes);
-    uint64_t* cand = b.take<uint64_t>(N);
-    uint64_t* cand_s = b.take<uint64_t>(N);
-    int32_t* flag = b.take<int32_t>(N);
-    int32_t* scan = b.take<int32_t>(N);
-    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
-    char* tmp = b.take<char>(st > sc ? st : sc);
+    uint32_t* bitmap = b.take<uint32_t>((size_t)nwords);
+    int32_t* cnt = b.take<int32_t>((size_t)nwords);
+    int32_t* scan = b.take<int32_t>((size_t)nwords);
+    size_t sc = scan_i32_temp((size_t)nwords);
+    char* tmp = b.take<char>(sc);
     if (!b.ok) return INSMOS_EWORKSPACE;
-    unsigned g = cdiv((int64_t)N, TPB);
     {
         ProfScope ps(KK_DOWN_CAND, s);
-        hipLaunchKernelGGL(k_down_candidates, dim3(g), dim3(TPB), 0, s, in_coords, n_in, K, P, cand);
+        HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, s));
+        hipLaunchKernelGGL(k_down_mark, dim3(cdiv(N, TPB)), dim3(TPB), 0, s, in_coords, n_in, K, P, bitmap);
+        hipLaunchKernelGGL(k_word_popc, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, nwords, cnt);
     }
-    int rc = sort_keys_u64(tmp, st, cand, cand_s, N, 0, 64, s);
+    int rc = inclusive_scan_i32(tmp, sc, cnt, scan, (size_t)nwords, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_DOWN_UNIQUE, s);
-        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, cand_s, (int64_t)N, 0, flag);
-    }
-    rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
-    if (rc) return rc;
-    {
-        ProfScope ps(KK_DOWN_UNIQUE, s);
-        hipLaunchKernelGGL(k_down_scatter, dim3(g), dim3(TPB), 0, s, cand_s, flag, scan, (int64_t)N, P.oshape[1],
+        hipLaunchKernelGGL(k_down_expand, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, scan, nwords, P.oshape[1],
                            P.oshape[2], cap, out_keys, out_coords, counts);
     }
     HIP_TRY(hipGetLastError());

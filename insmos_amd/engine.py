@@ -433,7 +433,7 @@ class Engine:
             oc = E((cap, 4), torch.int32)
             if n_in == 0:
                 return ok[:0], oc[:0], 0
-            w = self._workspace(lib.insmos_down_coords3d_ws_bytes(n_in, K))
+            w = self._workspace(lib.insmos_down_coords3d_ws_bytes(_hp(_np_i32(oshape))))
             _lib.check(lib.insmos_down_coords3d(coords[lvl_in].data_ptr(), n_in, _hp(ks), _hp(stv), _hp(pd),
                                                 _hp(_np_i32(oshape)), ok.data_ptr(), oc.data_ptr(), counts.data_ptr(),
                                                 w.data_ptr(), w.numel(), st), "insmos_down_coords3d")

@@ -106,3 +106,30 @@ def test_n1_window_and_no_detection_checkpoint(setup):
     assert pred[0][0]["pred_boxes"].shape == (0, 7) and len(ref_pred["pred_boxes"]) == 0
     np.testing.assert_allclose(logits[0].cpu().numpy(), ref_logits, atol=1e-3, rtol=0)
     np.testing.assert_array_equal(R.output_stage(logits[0].cpu().numpy())[0], R.output_stage(ref_logits)[0])
+
+
+def test_dense_stress_config_voxel_005():
+    """cfg-4 shape (BASELINE.json configs[3]): voxel 0.05 m -> grid [81,2000,2400], BEV depth 5 -> NUM_BEV_FEATURES 640,
+    500x600 head map.  Not weight-compatible with the 0.1 m checkpoints, so random weights; parity
+    is against the oracle on a reduced scan, plus the voxel cap (max_voxels) being hit."""
+    import copy
+    from insmos_amd import params as P
+    from insmos_amd.engine import Engine
+    from insmos_amd.synth import make_window
+    cfg = copy.deepcopy(P.default_cfg())
+    cfg["DATA"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    cfg["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"] = 640
+    cfg["MODEL"]["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    sd = P.random_state_dict(cfg, 4)
+    w = make_window(seed=9, n_scans=3, n_az=300)
+    cap = 6000  # force the max-voxel cap path (models.py:287 uses 100000; real cfg-4 scenes exceed it)
+    eng = Engine(cfg, sd, max_voxels=cap)
+    assert eng.shape[1] == [81, 2000, 2400] and eng.shape[5] == [5, 250, 300]
+    logits, pred = eng.forward_window(torch.from_numpy(w).cuda())
+    torch.cuda.synchronize()
+    ref_logits, ref_pred = M.forward_window(sd, cfg, w, max_voxels=cap)
+    assert eng.last_counts["unet_voxels"][0] == cap
+    assert int((eng._un_tables["pcid"] < 0).sum()) > 0  # points dropped by the cap get zero logits
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, atol=1e-3, rtol=0)
+    np.testing.assert_array_equal(R.output_stage(logits.cpu().numpy())[0], R.output_stage(ref_logits)[0])
+    assert pred["pred_boxes"].shape[0] == len(ref_pred["pred_boxes"])
