@@ -73,15 +73,24 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 // vmcnt(0) inside each branch and shuttle the accumulators between AGPRs and VGPRs).  Running off
 // the end of the tap list re-requests the last tap (clamp instead of guard); rows past n_out compute
 // on re-read data and are masked at the store.
-template <int COT, int JT, int CK, bool IDENT, int R>
+// SPLIT > 1 (generic layers with >= 64 output channels): the tile covers ALL its channel tiles in one wave
+// and the SPLIT consecutive waves of a block share the tile's row group but take every SPLIT-th active
+// tap, so each input row chunk is gathered exactly once per tile (instead of once per channel group);
+// the partial accumulators are summed through LDS in fixed wave order (deterministic) in the epilogue.
+template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT>
 __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
-    const uint32_t gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * 4 + wib;
     const uint32_t n_cg = P.ntile_co / COT;
-    if (gw >= (uint32_t)P.n_otiles * n_cg) return;  // wave-uniform
-    const uint32_t cg = gw / P.n_otiles;
-    const uint32_t ot = gw % P.n_otiles;
+    const uint32_t n_tiles = (uint32_t)P.n_otiles * n_cg;
+    const uint32_t tile_raw = gw / SPLIT, ws = gw % SPLIT;
+    const bool live = tile_raw < n_tiles;
+    if (SPLIT == 1 && !live) return;  // wave-uniform; split kernels keep dead waves alive for the block barrier
+    const uint32_t tile = live ? tile_raw : n_tiles - 1;
+    const uint32_t cg = tile / P.n_otiles;
+    const uint32_t ot = tile % P.n_otiles;
     const int g = lane >> 4, j = lane & 15;
     const uint32_t n_out = P.n_out;
     const uint32_t ld4 = (uint32_t)P.ld_in * 4u;  // row pitch in bytes
@@ -124,7 +133,20 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
             thi = K > 64 ? (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull)) : 0ull;
         }
     }
-    const int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
+    int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
+    if constexpr (SPLIT > 1) {
+        for (uint32_t q = 0; q < ws; ++q) (void)pop_or_keep(tlo, thi, 0);  // my taps: ranks ws, ws+SPLIT, ...
+        nt = (live && nt > (int)ws) ? (nt - (int)ws + SPLIT - 1) / SPLIT : 0;
+    }
+    // next tap of THIS wave (skips the taps owned by the other waves of the tile)
+    auto next_tap = [&](int keep) {
+        const int k = pop_or_keep(tlo, thi, keep);
+        if constexpr (SPLIT > 1) {
+#pragma unroll
+            for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
+        }
+        return k;
+    };
 
     f32x4 acc[COT][JT];
 #pragma unroll
@@ -185,9 +207,9 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
 
     if (nt > 0) {
         // ---- load cursor: (kL, cL) = next item to request; offL = its rows; tap ring kN/idxN, kNN/idxNN
-        int kL = pop_or_keep(tlo, thi, 0);
-        int kN = pop_or_keep(tlo, thi, kL);
-        int kNN = pop_or_keep(tlo, thi, kN);
+        int kL = next_tap(0);
+        int kN = next_tap(kL);
+        int kNN = next_tap(kN);
         int cL = 0;
         uint32_t offL[JT], idxN[JT], idxNN[JT];
         {
@@ -209,7 +231,7 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
             kL = kN; kN = kNN;                                                            \
             row_offsets(idxN, offL);                                                      \
             _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) idxN[jt] = idxNN[jt];       \
-            kNN = pop_or_keep(tlo, thi, kNN);                                             \
+            kNN = next_tap(kNN);                                                          \
             load_idx(kNN, idxNN);                                                         \
         }                                                                                 \
     }
@@ -234,45 +256,64 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
 
     // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow[jt]
     const uint32_t cout = P.cout;
-#pragma unroll
-    for (int it = 0; it < COT; ++it) {
+    auto finish = [&](int it, int jt, f32x4 v) {
         const uint32_t co0 = (cg * COT + it) * 16 + 4 * g;
-        const f32x4 bz = *(const f32x4*)(P.bias + co0);
+        const uint32_t o = orow[jt];
+        if (o >= n_out || co0 >= cout) return;
+        v += *(const f32x4*)(P.bias + co0);
+        if (P.relu_pre) {
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const uint32_t o = orow[jt];
-            if (o >= n_out || co0 >= cout) continue;
-            f32x4 v = acc[it][jt] + bz;
-            if (P.relu_pre) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (P.res_mode == 1) {
-                const float* rp = P.res + (size_t)o * P.ld_res + co0;
-                if (P.vec_store && co0 + 3 < cout) {
-                    v += *(const f32x4*)rp;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (co0 + r < cout) v[r] += rp[r];
-                }
-            } else if (P.res_mode == 2) {
-                const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
-            }
-            if (P.relu_post) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            float* op = P.out + (size_t)o * P.ld_out + co0;
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (P.res_mode == 1) {
+            const float* rp = P.res + (size_t)o * P.ld_res + co0;
             if (P.vec_store && co0 + 3 < cout) {
-                *(f32x4*)op = v;
+                v += *(const f32x4*)rp;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < cout) op[r] = v[r];
+                    if (co0 + r < cout) v[r] += rp[r];
+            }
+        } else if (P.res_mode == 2) {
+            const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
+        }
+        if (P.relu_post) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        float* op = P.out + (size_t)o * P.ld_out + co0;
+        if (P.vec_store && co0 + 3 < cout) {
+            *(f32x4*)op = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < cout) op[r] = v[r];
+        }
+    };
+    if constexpr (SPLIT == 1) {
+#pragma unroll
+        for (int it = 0; it < COT; ++it)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) finish(it, jt, acc[it][jt]);
+    } else {
+        static_assert(SPLIT == 1 || (JT == 1 && COT % SPLIT == 0), "tap-split tiles are 16 rows x all channels");
+        __shared__ f32x4 red[4][COT][64];  // [wave in block][channel tile][lane]
+#pragma unroll
+        for (int it = 0; it < COT; ++it) red[wib][it][lane] = acc[it][0];
+        __syncthreads();
+        if (live) {
+            const uint32_t w0 = wib - ws;  // first wave of this tile inside the block
+            constexpr int PER = COT / SPLIT;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int it = (int)ws * PER + q;
+                f32x4 v = red[w0][it][lane];
+#pragma unroll
+                for (int p = 1; p < SPLIT; ++p) v += red[w0 + p][it][lane];  // fixed order -> deterministic
+                finish(it, 0, v);
             }
         }
     }
@@ -353,7 +394,7 @@ template <int COT, int JT> constexpr int ring_depth() { return COT * JT <= 2 ? 3
 
 template <int CK, bool IDENT>
 ConvKernel pick_kernel(int cot, int jt) {
-#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT, ring_depth<C, J>()>;
+#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT, ring_depth<C, J>(), 1>;
     if constexpr (CK == 0) {
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
         CASE(8, 1) CASE(8, 2) CASE(8, 4)
@@ -367,7 +408,7 @@ ConvKernel pick_kernel(int cot, int jt) {
 // tuning hook (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring)
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0;
 ConvKernel pick_forced(int cot, int jt, int ring) {
-#define CASE(C, J, RR) if (cot == C && jt == J && ring == RR) return k_sparse_conv<C, J, 0, false, RR>;
+#define CASE(C, J, RR) if (cot == C && jt == J && ring == RR) return k_sparse_conv<C, J, 0, false, RR, 1>;
 #define CASES(C, J) CASE(C, J, 2) CASE(C, J, 3) CASE(C, J, 4)
     CASES(1, 1) CASES(1, 2) CASES(1, 4) CASES(2, 1) CASES(2, 2) CASES(2, 4) CASES(4, 1) CASES(4, 2) CASES(4, 4)
     CASE(8, 1, 2) CASE(8, 1, 3) CASE(8, 2, 2) CASE(8, 2, 3) CASE(8, 4, 2)
@@ -424,7 +465,20 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     if (ck == 4) kern = ident ? pick_kernel<4, true>(best.cot, best.jt) : pick_kernel<4, false>(best.cot, best.jt);
     else if (ck == 8) kern = ident ? pick_kernel<8, true>(best.cot, best.jt) : pick_kernel<8, false>(best.cot, best.jt);
     else kern = ident ? pick_kernel<0, true>(best.cot, best.jt) : pick_kernel<0, false>(best.cot, best.jt);
+    // tap-split tiles: all channel tiles in one wave, the block's waves share the row group and split the taps
+    int split = 1;
+    static int split_env = -1;
+    if (split_env < 0) { const char* e = getenv("INSMOS_CONV_SPLIT"); split_env = e ? atoi(e) : 1; }
+    // (measured: +20-30 % on the masked 27-tap C >= 64 layers; no gain on dense 9-tap BEV convs or 3-tap layers)
+    if (split_env && !ck && !ident && mask16 && (P.ntile_co == 4 || P.ntile_co == 8) && K >= 16) {
+        split = 4;
+        best = {P.ntile_co, 1};
+        P.n_otiles = (int)((n_out + 15) / 16);
+        if (P.ntile_co == 8) kern = split == 4 ? k_sparse_conv<8, 1, 0, false, 2, 4> : k_sparse_conv<8, 1, 0, false, 2, 2>;
+        else kern = split == 4 ? k_sparse_conv<4, 1, 0, false, 2, 4> : k_sparse_conv<4, 1, 0, false, 2, 2>;
+    }
     if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
+        split = 1;
         ConvKernel fk = pick_forced(g_force_cot, g_force_jt, g_force_ring);
         if (fk) {
             kern = fk;
@@ -433,7 +487,7 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
         }
     }
     if (!kern) return INSMOS_EINVAL;
-    long waves = (long)P.n_otiles * (P.ntile_co / best.cot);
+    long waves = (long)P.n_otiles * (P.ntile_co / best.cot) * split;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     ProfScope ps(KK_SPARSE_CONV, s);
     hipLaunchKernelGGL(kern, grid, block, 0, s, P);

@@ -41,7 +41,8 @@ def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
     if not identity:  # same result when the active-tap bitmasks drive the tap loop
         from gpu_util import tap_masks
         ym = run_conv(layer, dev(x), dev(nbr), n_out, mask=dev(tap_masks(nbr).view(np.int32))).cpu().numpy()
-        np.testing.assert_array_equal(ym, y)
+        # not bitwise: tap-split tiles hand taps to waves by rank in the ACTIVE set, so the summation grouping differs
+        np.testing.assert_allclose(ym, y, rtol=1e-5, atol=1e-5)
 
 
 def test_clustered_occupancy_with_masks():
