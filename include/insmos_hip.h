@@ -84,6 +84,18 @@ int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_
                            const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                            const uint32_t* child_mask, const int32_t* delta_host, int K, int32_t* nbr,
                            uint32_t* mask16, void* stream);
+/* 3x3x3x3 table specialisation of insmos_nbr_from_coarse: one thread per voxel fetches its <= 24 coarse
+ * entries once (LDS-cached) and resolves all 81 taps with bit arithmetic; masks need no atomics. */
+int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                             const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                             const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);
+/* First MotionNet layer (minkunet.py:55-60, kernel [5,5,5,1], 1 -> 8 channels) for a CONSTANT input feature
+ * (motionnet.py:29-32 feeds 0.5 on every point): out[o, 0:8] = relu?(bias8 + sum over existing taps k of
+ * w125x8[k, 0:8]) with w125x8 = value * BN-folded kernel.  No 125-tap table is built and nothing is gathered. */
+int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                                     const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                     const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
+                                     int ld_out, int relu, void* stream);
 int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift, int64_t n_c,
                        const int32_t* child_start, const uint32_t* child_mask, int32_t* dn, uint32_t* dn_mask16,
                        int32_t* up, uint32_t* up_mask16, void* stream);

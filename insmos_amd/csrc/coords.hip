@@ -393,6 +393,102 @@ __global__ void k_down_expand(const uint32_t* __restrict__ bitmap, const int32_t
     if (w == nwords - 1) counts[0] = scan[w];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// per-voxel tap resolver: one thread = one fine voxel.  The <= 27 coarse neighbour blocks a voxel's taps
+// can fall into are fetched ONCE (independent loads, entries cached in LDS as (child_start, child_mask)),
+// then every tap of the (2*RANGE+1)^3 x NDT kernel is resolved with bit arithmetic only.
+//   MODE 0: write the neighbour table column-by-column (+ active-tap masks by a 16-lane OR reduction)
+//   MODE 1: constant-input convolution -- out[o] = relu(bias + sum_{valid taps} w[k]) -- for the first
+//           MotionNet layer, whose input is 0.5 on every voxel (motionnet.py:29-32): no table, no gathers.
+// Tap order = ME kernel-region order (x fastest, then y, z, t).
+// ---------------------------------------------------------------------------------------------------
+template <int RANGE, int NDT, int MODE>
+__global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict__ coords, int64_t n_f,
+                                                      const int32_t* __restrict__ parent, int L,
+                                                      const int32_t* __restrict__ cnbr, int64_t n_c,
+                                                      const int32_t* __restrict__ child_start,
+                                                      const uint32_t* __restrict__ child_mask,
+                                                      int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int ld_out, int relu) {
+    constexpr int NB = RANGE == 1 ? 2 : 3;       // candidate coarse blocks per axis
+    constexpr int E = NB * NB * NB * NDT;        // cached coarse entries per voxel
+    constexpr int W1 = 2 * RANGE + 1;
+    __shared__ uint32_t sl[E][256];  // child_start (24 bits) << 8 | child_mask (8 bits)
+    const int tid = threadIdx.x;
+    const int64_t o_raw = (int64_t)blockIdx.x * blockDim.x + tid;
+    const bool live = o_raw < n_f;
+    const int64_t o = live ? o_raw : n_f - 1;
+    const int4 c = *(const int4*)(coords + o * 4);
+    const int px = (c.x >> L) & 1, py = (c.y >> L) & 1, pz = (c.z >> L) & 1;
+    const int p = parent[o];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ibx = e % NB, iby = (e / NB) % NB, ibz = (e / (NB * NB)) % NB, idt = e / (NB * NB * NB);
+        const int bx = RANGE == 1 ? px - 1 + ibx : ibx - 1;
+        const int by = RANGE == 1 ? py - 1 + iby : iby - 1;
+        const int bz = RANGE == 1 ? pz - 1 + ibz : ibz - 1;
+        const int dt = NDT == 3 ? idt - 1 : 0;
+        const int ctap = (bx + 1) + 3 * (by + 1) + 9 * (bz + 1) + 27 * (dt + 1);
+        const int q = cnbr[(int64_t)ctap * n_c + p];
+        uint32_t v = 0u;
+        if (q >= 0) v = ((uint32_t)child_start[q] << 8) | (child_mask[q] & 0xFFu);
+        sl[e][tid] = v;
+    }
+    // (each thread reads back only its own column: no barrier needed)
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};
+    float acc[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;  // bias is added last, like the generic kernel's epilogue
+    }
+    int k = 0;
+#pragma unroll
+    for (int idt = 0; idt < NDT; ++idt)
+#pragma unroll
+        for (int dz = -RANGE; dz <= RANGE; ++dz)
+#pragma unroll
+            for (int dy = -RANGE; dy <= RANGE; ++dy)
+#pragma unroll
+                for (int dx = -RANGE; dx <= RANGE; ++dx, ++k) {
+                    const int vx = px + dx, vy = py + dy, vz = pz + dz;
+                    const int ibx = RANGE == 1 ? (vx >> 1) - (px - 1) : (vx >> 1) + 1;
+                    const int iby = RANGE == 1 ? (vy >> 1) - (py - 1) : (vy >> 1) + 1;
+                    const int ibz = RANGE == 1 ? (vz >> 1) - (pz - 1) : (vz >> 1) + 1;
+                    const int e = ((idt * NB + ibz) * NB + iby) * NB + ibx;
+                    const unsigned oct = (vx & 1) | ((vy & 1) << 1) | ((vz & 1) << 2);
+                    const uint32_t ent = sl[e][tid];
+                    const bool hit = (ent >> oct) & 1u;
+                    if (MODE == 0) {
+                        const int32_t r = hit ? (int32_t)(ent >> 8) + __popc(ent & ((1u << oct) - 1u)) : -1;
+                        if (live) nbr[(int64_t)k * n_f + o] = r;
+                        if (hit && live) mw[k >> 5] |= 1u << (k & 31);
+                    } else {
+                        const float sel = hit ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(sel, w[k * 8 + i], acc[i]);
+                    }
+                }
+    static_assert(W1 * W1 * W1 * NDT <= 128, "tap count");
+    if (MODE == 0) {
+        if (mask16) {
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                uint32_t v = mw[wd];
+                v |= __shfl_xor(v, 8); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 1);
+                if ((tid & 15) == 0 && live) mask16[(o >> 4) * 4 + wd] = v;
+            }
+        }
+    } else if (live) {
+        float* op = out + o * ld_out;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = acc[i] + bias[i];
+            op[i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -662,6 +758,38 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
     hipLaunchKernelGGL(k_nbr_down, dim3(cdiv(n_c, TPB), 8), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
     hipLaunchKernelGGL(k_nbr_up, dim3(cdiv(n_f, TPB), 8), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
                        up_mask16);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                                        const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                        const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream) {
+    if (n_f <= 0 || n_f >= (1 << 24) || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
+        !child_mask || !nbr || fine_shift < 0 || fine_shift > 14)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_BUILD_NBR, s);
+    hipLaunchKernelGGL((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent,
+                                                int fine_shift, const int32_t* coarse_nbr81, int64_t n_c,
+                                                const int32_t* child_start, const uint32_t* child_mask,
+                                                const float* w125x8, const float* bias8, float* out, int ld_out, int relu,
+                                                void* stream) {
+    if (n_f <= 0 || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start || !child_mask || !w125x8 ||
+        !bias8 || !out || ld_out < 8 || fine_shift < 0 || fine_shift > 14)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_SPARSE_CONV, s);
+    hipLaunchKernelGGL((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
+                       w125x8, bias8, out, ld_out, relu);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

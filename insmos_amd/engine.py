@@ -131,6 +131,7 @@ class Engine:
             raise NotImplementedError("BEV deconv stride 2 only (config.yaml:118)")
         self._ws = None
         self._conv_log = []
+        self.const_input = True  # MotionNet input features are the constant 0.5 (motionnet.py:29-32)
         self.layer_timing = None  # set to [] to record per-conv (name, K, cin, cout, n_out, ev0, ev1)
         self._load_weights(state_dict)
         self._static_tables()
@@ -167,6 +168,10 @@ class Engine:
             if ci != co:
                 L[name + ".ds"] = me(name + ".downsample.0", name + ".downsample.1", _padc(ci), co)
         L["final"] = me("final", None, 8, 3, bias=self._sd(M + "final.bias"))
+        # constant-input form of conv0: 0.5 * BN-folded taps (125, 8) and the folded shift
+        t0, b0 = P.fold_bn(P.me_kernel_to_taps(self._sd(M + "conv0p1s1.kernel")), *self._bn(M + "bn0.bn"), 1e-5)
+        self.w0_const = torch.from_numpy(np.ascontiguousarray(np.float32(0.5) * t0[:, 0, :])).to(dev)
+        self.b0_const = torch.from_numpy(np.ascontiguousarray(b0)).to(dev)
 
         U = P.UNET_PREFIX
         for conv, bn, ks, ci, co in P.unet_convs(self.in_ch, self.ncls):
@@ -328,8 +333,14 @@ class Engine:
         # only the coarsest level is searched; every finer table is derived through the Morton hierarchy
         nbr81 = [None, None, None, self.build_nbr(coords[3], n[3], keys[3], None, n[3], 0, None, self.off81[3])]
         for l in (2, 1, 0):
-            nbr81[l] = from_coarse(l, self.off81[l], nbr81[l + 1])
-        nbr125 = from_coarse(0, self.off125, nbr81[1])
+            nb, mk = table(81, n[l])
+            _lib.check(lib.insmos_nbr81_from_coarse(coords[l].data_ptr(), n[l], parent[l].data_ptr(), l,
+                                                    nbr81[l + 1].nbr.data_ptr(), n[l + 1], child_start[l].data_ptr(),
+                                                    child_mask[l].data_ptr(), nb.data_ptr(), mk.data_ptr(), st),
+                       "insmos_nbr81_from_coarse")
+            nbr81[l] = NbrTable(nb, mk)
+        # the 125-tap table is only materialised when the first layer's input is not constant (generic path)
+        nbr125 = from_coarse(0, self.off125, nbr81[1]) if not self.const_input else None
         dn, up = [], []
         for l in range(3):
             d_nb, d_mk = table(8, n[l + 1])
@@ -343,14 +354,25 @@ class Engine:
         self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse)
 
         L, E = self.L, self._empty
-        x_in = E((n[0], 4))
-        x_in.zero_()
-        _lib.check(lib.insmos_fill_cols(x_in.data_ptr(), n[0], 4, 0, 1, 0.5, st), "insmos_fill_cols")
+        x_in = None
+        if not self.const_input:
+            x_in = E((n[0], 4))
+            x_in.zero_()
+            _lib.check(lib.insmos_fill_cols(x_in.data_ptr(), n[0], 4, 0, 1, 0.5, st), "insmos_fill_cols")
         cat8 = E((n[0], 16))  # [convtr7 (8) | out_p1 (8)]
         cat7 = E((n[1], 32))  # [convtr6 (16) | out_b1p2 (8) | zero pad (8)]
         _lib.check(lib.insmos_fill_cols(cat7.data_ptr(), n[1], 32, 24, 8, 0.0, st), "insmos_fill_cols")
         cat6 = E((n[2], 48))  # [convtr5 (32) | out_b2p4 (16)]
-        self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
+        if self.const_input:
+            # motionnet.py:29-32: every point carries the feature 0.5 -> conv0 needs no table and no gathers
+            _lib.check(lib.insmos_const_conv125_from_coarse(coords[0].data_ptr(), n[0], parent[0].data_ptr(), 0,
+                                                            nbr81[1].nbr.data_ptr(), n[1], child_start[0].data_ptr(),
+                                                            child_mask[0].data_ptr(), self.w0_const.data_ptr(),
+                                                            self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1, st),
+                       "insmos_const_conv125_from_coarse")
+            self._conv_log.append((None, n[0], L["conv0p1s1"]))
+        else:
+            self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
         x1 = E((n[1], 8))
         self.conv(L["conv1p1s2"], cat8, 16, dn[0], n[1], x1, 8, col_in=8, relu_post=1)
 
@@ -389,7 +411,7 @@ class Engine:
         _lib.check(lib.insmos_build_current_points(pts.data_ptr(), ld, motion.data_ptr(), 4, inverse.data_ptr(),
                                                    cur_index.data_ptr(), ncur, cur.data_ptr(), 8, st),
                    "insmos_build_current_points")
-        self._me_debug = dict(b3=b3, b8=b8, motion=motion)
+        self._me_debug = dict(b3=b3, b8=b8, motion=motion, cat8=cat8)
         return cur
 
     # ------------------------------------------------------------------------------------------------

@@ -26,8 +26,18 @@ def engine():
 def test_quantize_levels_and_tables(window, engine):
     from gpu_util import dev, u64
     pts = dev(window)
-    cur = engine.motionnet(pts)
+    engine.const_input = True
+    engine.motionnet(pts)
     torch.cuda.synchronize()
+    out_p1_const = engine._me_debug["cat8"][:, 8:16].clone()
+    engine.const_input = False  # generic path: materialises the 125-tap table and gathers the 0.5 features
+    try:
+        cur = engine.motionnet(pts)
+        torch.cuda.synchronize()
+    finally:
+        engine.const_input = True
+    # the constant-input first layer is bitwise the generic MFMA path (same tap order, 0.5*w exact)
+    assert torch.equal(out_p1_const, engine._me_debug["cat8"][:, 8:16])
     T = engine._me_tables
     pts4 = np.concatenate([window[:, :3], window[:, 4:5]], 1)
     c, k, inv = R.me_quantize(pts4, [0.1, 0.1, 0.1, 0.1])
