@@ -59,6 +59,16 @@ def calibrate_head(model, pts, target):
     eng._load_weights(sd)
 
 
+def pmc_traffic(args):
+    """HBM bytes per conv launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE), committed under profiles/; null when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.n_az != 1886 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"])
+
+
 def read_profile(lib):
     ids = (ctypes.c_int * 64)()
     ms = (ctypes.c_double * 64)()
@@ -168,7 +178,7 @@ def main():
         out["roofline"] = {
             "kernel": "k_sparse_conv (all %d launches of one window)" % work["launches"], "bound": "mfma",
             "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args),
             "algorithmic_gflop_per_window": round(work["flops"] / 1e9, 3),
             "kernel_ms_per_window": round(conv_ms_per_window, 3),
             "avg_launch_us": round(1000.0 * conv_ms / max(conv_launches, 1), 2),
