@@ -1,0 +1,73 @@
+"""-m gpu: BASELINE.json cfg-2 at FULL size (synthetic S0, 1.2 M points) through size-independent properties --
+the oracle is too slow to run here, so: the survey's known voxel / pair counts, structural
+invariants of the kernel maps, determinism, and invariance of the result under a permutation of the past scans'
+points (MinkowskiEngine quantisation is order-free; the current scan keeps its order because spconv's voxel ids are
+first-come)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s0_run():
+    from insmos_amd import params as P
+    from insmos_amd.engine import Engine
+    from insmos_amd.synth import make_window
+    cfg = P.default_cfg()
+    eng = Engine(cfg, P.random_state_dict(cfg, 0))
+    w = make_window(0, 10, 1886)
+    logits, pred = eng.forward_window(torch.from_numpy(w).cuda())
+    torch.cuda.synchronize()
+    return eng, w, logits, pred
+
+
+def test_s0_known_counts(s0_run):
+    eng, w, logits, pred = s0_run
+    assert w.shape == (1199606, 5)
+    assert eng.last_counts["me_voxels"] == [468007, 211916, 83805, 30183]
+    assert eng.last_counts["n_cur"] == 119817
+    assert eng.last_counts["unet_voxels"] == [42280, 30867, 12564, 6717, 4810]
+    T = eng._me_tables
+    assert [int((t >= 0).sum()) for t in T["nbr81"]] == [7593359, 4161552, 1814733, 691903]
+    U = eng._un_tables
+    assert [int((U["subm"][l] >= 0).sum()) for l in (1, 2, 3, 4)] == [263860, 350793, 151384, 102743]
+    assert int((U["down5"] >= 0).sum()) == 8400
+    assert int((U["pcid"] >= 0).sum()) == 118333
+    assert logits.shape == (119817, 3) and bool(torch.isfinite(logits).all())
+    assert float(logits[U["pcid"] < 0].abs().sum()) == 0.0  # points without a voxel get zero logits
+
+
+def test_s0_kernel_map_invariants(s0_run):
+    eng = s0_run[0]
+    T = eng._me_tables
+    for l in range(3):
+        dn, up = T["dn"][l].nbr, T["up"][l].nbr
+        # every fine voxel has exactly one parent; strided and transposed maps hold the same pairs
+        assert bool(((up >= 0).sum(0) == 1).all())
+        assert int((dn >= 0).sum()) == up.shape[1] == int((up >= 0).sum())
+        k = (up >= 0).int().argmax(0)                       # octant of each fine voxel
+        f = torch.arange(up.shape[1], device=up.device)
+        p = up[k, f].long()
+        assert bool((dn[k, p] == f.int()).all())            # dn[k][parent(f)] == f
+    for l in range(4):
+        n81 = T["nbr81"][l].nbr
+        ctr = 1 + 3 + 9 + 27                                # the (0,0,0,0) tap is the voxel itself
+        assert bool((n81[ctr] == torch.arange(n81.shape[1], device=n81.device, dtype=torch.int32)).all())
+        # symmetry: if tap k of o is q then the mirrored tap (80-k) of q is o
+        k = 7
+        o = torch.nonzero(n81[k] >= 0).flatten()
+        assert bool((n81[80 - k][n81[k][o].long()] == o.int()).all())
+
+
+def test_s0_deterministic_and_past_order_free(s0_run):
+    eng, w, logits, pred = s0_run
+    logits2, pred2 = eng.forward_window(torch.from_numpy(w).cuda())
+    assert torch.equal(logits, logits2) and torch.equal(pred["pred_boxes"], pred2["pred_boxes"])
+    rng = np.random.default_rng(1)
+    past = np.nonzero(w[:, 4] != 0)[0]
+    perm = np.arange(len(w))
+    perm[past] = past[rng.permutation(len(past))]
+    logits3, _ = eng.forward_window(torch.from_numpy(np.ascontiguousarray(w[perm])).cuda())
+    assert torch.equal(logits, logits3)
