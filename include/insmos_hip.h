@@ -266,6 +266,18 @@ int insmos_build_current_points(const float* points, int ld_pts, const float* mo
 int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, float value, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Caller-side stages ("next" rows of the scope table; scripts/predict_mos.py).
+ * insmos_stack_scan: pose-align one raw scan (n,4) [x,y,z,intensity] into the current frame with the float64 3x4
+ *   transform T_host (row-major, first 12 entries of inv(to_pose) @ from_pose), append timestamp t, write rows
+ *   [x',y',z',intensity,t] at `out` (predict_mos.py:131-166).
+ * insmos_output_stage: ignored classes -> -inf, softmax, confidence (n, ncls-1) = softmax[:,1:], argmax (first max),
+ *   labels (n) = lut[argmax] (learning_map_inv), predict_mos.py:440-453.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_stack_scan(const float* scan, int64_t n, const double* T_host, float t, float* out, int ld_out, void* stream);
+int insmos_output_stage(const float* logits, int ld, int64_t n, int ncls, unsigned ignore_mask, const int32_t* lut,
+                        int32_t* labels, float* confidence, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * insmos_confusion3 -- ClassificationMetrics.compute_confusion_matrix (models/metrics.py:16-30):
  * ignored class columns of the logits are treated as -inf, argmax (first max), cm[pred, gt] += 1.
  *   cm (ncls*ncls) i64 is ACCUMULATED into (zero it once per evaluation).  ignore_mask bit c set =>

@@ -52,6 +52,8 @@ SIGNATURES = {
     "insmos_gather_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp]),
     "insmos_build_current_points": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
     "insmos_fill_cols": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_f32, c_vp]),
+    "insmos_stack_scan": (c_int, [c_vp, c_i64, c_vp, c_f32, c_vp, c_int, c_vp]),
+    "insmos_output_stage": (c_int, [c_vp, c_int, c_i64, c_int, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "insmos_confusion3": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp]),
 }
 

@@ -56,6 +56,47 @@ __global__ void __launch_bounds__(256) k_confusion(const float* __restrict__ log
     if ((int)threadIdx.x < ncls * ncls && h[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+struct Mat34d { double m[12]; };
+
+// pose alignment + timestamp + concat of one scan (scripts/predict_mos.py:131-166): xyz' = (T @ [x,y,z,1]) in float64,
+// rounded to float32 on store; intensity copied; t appended.
+__global__ void k_stack_scan(const float* __restrict__ scan, int64_t n, Mat34d T, float t, float* __restrict__ out, int ld) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = *(const float4*)(scan + i * 4);
+    const double x = p.x, y = p.y, z = p.z;
+    float* o = out + i * ld;
+    o[0] = (float)(((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3]);
+    o[1] = (float)(((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7]);
+    o[2] = (float)(((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11]);
+    o[3] = p.w;
+    o[4] = t;
+}
+
+// output stage of the driver (scripts/predict_mos.py:440-453): ignored classes -> -inf, softmax, confidence =
+// softmax[:, 1:], argmax (first max), learning_map_inv lookup -> int32 labels
+__global__ void k_output_stage(const float* __restrict__ logits, int ld, int64_t n, int ncls, unsigned ignore_mask,
+                               const int32_t* __restrict__ lut, int32_t* __restrict__ labels, float* __restrict__ conf) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* l = logits + i * ld;
+    float v[8], m = -INFINITY;
+    for (int c = 0; c < ncls; ++c) {
+        v[c] = ((ignore_mask >> c) & 1u) ? -INFINITY : l[c];
+        m = fmaxf(m, v[c]);
+    }
+    float s = 0.f;
+    for (int c = 0; c < ncls; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
+    int best = 0;
+    float bv = -1.f;
+    for (int c = 0; c < ncls; ++c) {
+        const float pr = v[c] / s;
+        if (pr > bv) { bv = pr; best = c; }
+        if (c >= 1) conf[i * (ncls - 1) + c - 1] = pr;
+    }
+    labels[i] = lut[best];
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -104,6 +145,31 @@ extern "C" int insmos_confusion3(const float* logits, int ld, const int64_t* gt,
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_confusion, dim3(g), dim3(256), 0, s, logits, ld, gt, n, ncls, ignore_mask,
                        (unsigned long long*)cm);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_stack_scan(const float* scan, int64_t n, const double* T_host, float t, float* out, int ld_out,
+                                 void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!scan || !T_host || !out || ld_out < 5 || ((uintptr_t)scan & 15)) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Mat34d T;
+    for (int i = 0; i < 12; ++i) T.m[i] = T_host[i];
+    ProfScope ps(KK_CUR_POINTS, s);
+    hipLaunchKernelGGL(k_stack_scan, dim3(cdiv(n, 256)), dim3(256), 0, s, scan, n, T, t, out, ld_out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_output_stage(const float* logits, int ld, int64_t n, int ncls, unsigned ignore_mask,
+                                   const int32_t* lut, int32_t* labels, float* confidence, void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!logits || !lut || !labels || !confidence || ncls < 2 || ncls > 8) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_GATHER_ROWS, s);
+    hipLaunchKernelGGL(k_output_stage, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, ld, n, ncls, ignore_mask, lut, labels,
+                       confidence);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

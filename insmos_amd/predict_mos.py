@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""MI355X counterpart of the reference's inference driver (scripts/predict_mos.py).
+
+Same inputs and outputs as the reference:
+  * checkpoint: Lightning-style .ckpt, cfg taken from ckpt["hyper_parameters"] (predict_mos.py:288) -- or, without
+    --ckpt, a seeded random checkpoint (there are no published weights offline);
+  * data: <data_path>/<seq:02d>/{velodyne/*.bin, poses.txt, calib.txt} (SemanticKITTI layout);
+  * for every scan: preb_out/<ID>/mos_preb/sequences/<seq>/predictions/<stem>.label  (int32, learning_map_inv),
+                    preb_out/<ID>/confidence/sequences/<seq>/predictions/<stem>.npy   (softmax[:, 1:]),
+                    preb_out/<ID>/bbox_preb/sequences/<seq>/predictions/<stem>.npy     (dict of numpy arrays)
+    (predict_mos.py:421-461; stem = the 6 digits of the current scan's file name);
+  * the first N-1 scans are predicted with shortened histories N' = 1 .. N-1 (predict_mos.py:308-383).
+What differs: scans are uploaded once and pose-aligned / stacked on the GPU (insmos_amd/data.py), the model is built
+once (the reference reloads the checkpoint for every warm-up length), the output stage runs on the device, and with
+`torchrun --nproc-per-node N` the windows of a sequence are sharded over the ranks (window j -> rank j % N).
+"""
+import argparse
+import copy
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, params as P
+from .data import SequenceWindows
+from .metrics import shard_indices
+from .models import InsMOSNet, load_semantic_config
+
+
+def output_stage(logits, ignore_index, learning_map_inv):
+    """(labels int32 (n,), confidence fp32 (n, ncls-1)) on the device -- predict_mos.py:440-453."""
+    lib = _lib.load()
+    n, ncls = int(logits.shape[0]), int(logits.shape[1])
+    lut_np = np.zeros(ncls, dtype=np.int32)
+    for k, v in learning_map_inv.items():
+        lut_np[int(k)] = int(v)
+    lut = torch.from_numpy(lut_np).to(logits.device)
+    labels = torch.empty((n,), dtype=torch.int32, device=logits.device)
+    conf = torch.empty((n, ncls - 1), dtype=torch.float32, device=logits.device)
+    mask = 0
+    for c in ignore_index:
+        mask |= 1 << int(c)
+    lg = logits if logits.stride(1) == 1 else logits.contiguous()
+    st = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+    _lib.check(lib.insmos_output_stage(lg.data_ptr(), lg.stride(0), n, ncls, mask, lut.data_ptr(), labels.data_ptr(),
+                                       conf.data_ptr(), st), "insmos_output_stage")
+    return labels, conf
+
+
+def write_outputs(out_root, exp_id, seq, stem, labels, conf, pred):
+    d_mos = os.path.join(out_root, exp_id, "mos_preb", "sequences", str(seq).zfill(2), "predictions")
+    d_conf = os.path.join(out_root, exp_id, "confidence", "sequences", str(seq).zfill(2), "predictions")
+    d_box = os.path.join(out_root, exp_id, "bbox_preb", "sequences", str(seq).zfill(2), "predictions")
+    for d in (d_mos, d_conf, d_box):
+        os.makedirs(d, exist_ok=True)
+    labels.cpu().numpy().astype(np.int32).tofile(os.path.join(d_mos, stem + ".label"))
+    np.save(os.path.join(d_conf, stem + ".npy"), conf.cpu().numpy())
+    np.save(os.path.join(d_box, stem + ".npy"), {k: v.cpu().numpy() for k, v in pred.items()})
+
+
+def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device="cuda:0", limit=None):
+    sem = model.semantic_config
+    ignore_index = model.ignore_index
+    exp_id = cfg["EXPERIMENT"]["ID"]
+    n_full = int(cfg["MODEL"]["N_PAST_STEPS"])
+    jobs = []  # (n_past, window index)
+    for i in range(n_full - 1):  # warm-up: scan i predicted from scans 0..i
+        jobs.append((i + 1, 0))
+    full = SequenceWindows(cfg, seq_dir, n_full, device)
+    for j in range(len(full)):
+        jobs.append((n_full, j))
+    if limit is not None:
+        jobs = jobs[:limit]
+    readers = {n_full: full}
+    done = 0
+    for idx in shard_indices(len(jobs), rank, world):
+        n_past, j = jobs[idx]
+        if n_past not in readers:
+            c2 = copy.deepcopy(cfg)
+            c2["MODEL"]["DELTA_T_PREDICTION"] = 0.1  # predict_mos.py:311
+            readers[n_past] = SequenceWindows(c2, seq_dir, n_past, device)
+        rd = readers[n_past]
+        if j >= len(rd):
+            continue
+        pts, meta = rd.window(j)
+        pred_list, _, logits_list = model.forward([{"past_point_clouds": pts, "meta": meta, "batch_size_npast": n_past}],
+                                                  "test")
+        labels, conf = output_stage(logits_list[0], ignore_index, sem["learning_map_inv"])
+        stem = str(meta[2][-1])[-10:-4]
+        write_outputs(out_root, exp_id, seq, stem, labels, conf, pred_list[0][0])
+        done += 1
+    return done
+
+
+def main():
+    ap = argparse.ArgumentParser(description="InsMOS inference on MI355X (counterpart of scripts/predict_mos.py)")
+    ap.add_argument("--ckpt", type=str, default=None, help="Lightning checkpoint; omitted -> seeded random weights")
+    ap.add_argument("--data_path", type=str, required=True, help="root holding <seq>/velodyne, poses.txt, calib.txt")
+    ap.add_argument("--split", type=str, default="valid", help="valid (seq 08) or test (11..21), as the reference")
+    ap.add_argument("--sequences", type=int, nargs="*", default=None, help="explicit sequence list (overrides --split)")
+    ap.add_argument("--out", type=str, default="preb_out")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--limit", type=int, default=None, help="only the first LIMIT windows of each sequence")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if args.ckpt:
+        cfg = torch.load(args.ckpt, map_location="cpu", weights_only=False)["hyper_parameters"]
+        model = InsMOSNet.load_from_checkpoint(args.ckpt, hparams=cfg)
+    else:
+        cfg = P.default_cfg()
+        model = InsMOSNet(cfg, seed=args.seed)
+    cfg["TRAIN"]["BATCH_SIZE"] = 1
+    model.cuda(local).eval()
+    seqs = args.sequences if args.sequences is not None else ([8] if args.split == "valid" else list(range(11, 22)))
+    total = 0
+    with torch.no_grad():
+        for seq in seqs:
+            seq_dir = os.path.join(args.data_path, "{0:02d}".format(int(seq)))
+            total += predict_sequence(model, cfg, seq_dir, seq, args.out, rank, world, f"cuda:{local}", args.limit)
+    torch.cuda.synchronize()
+    print(f"[rank {rank}] wrote predictions for {total} scans")
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ Sources exercised (all importable / compilable here):
   post_process.npz  models/post_process.py:112-224 end-to-end (class-agnostic branch) with
                     iou3d_nms_cuda.nms_gpu stubbed by the compiled reference IoU + the greedy reduce
   height_compression.npz  models/backbones_2d/height_compression.py:24-31 view semantics (on a dense tensor)
+  poses.npz         dataloader/utils.py:10-68 load_poses / load_calib / load_files on tiny hand-written files
 """
 import ctypes
 import os
@@ -232,5 +233,38 @@ def main():
     print("golden vectors written to", HERE)
 
 
+
+
+def poses_golden():
+    """dataloader/utils.py:10-68 (load_poses / load_calib / load_files) on tiny hand-written files."""
+    import tempfile
+    from dataloader.utils import load_calib, load_files, load_poses
+    rng = np.random.default_rng(77)
+    lines = []
+    for i in range(6):
+        a = 0.03 * i
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        t = np.array([0.1 * i, 0.01 * i, 1.3 * i]) + rng.normal(0, 1e-3, 3)
+        lines.append(" ".join("%.9e" % v for v in np.hstack([R, t[:, None]]).ravel()))
+    poses_txt = "\n".join(lines) + "\n"
+    calib_txt = ("P0: 7.188560e+02 0 6.071928e+02 0 0 7.188560e+02 1.852157e+02 0 0 0 1 0\n"
+                 "Tr: 4.276802385584e-04 -9.999672484946e-01 -8.084491683471e-03 -1.198459927713e-02 "
+                 "-7.210626507497e-03 8.081198471645e-03 -9.999413164504e-01 -5.403984729748e-02 "
+                 "9.999738645903e-01 4.859485810390e-04 -7.206933692422e-03 -2.921968648686e-01\n")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "poses.txt"), "w").write(poses_txt)
+        open(os.path.join(d, "calib.txt"), "w").write(calib_txt)
+        os.makedirs(os.path.join(d, "velodyne"))
+        for n in ("000002.bin", "000000.bin", "000001.bin"):
+            open(os.path.join(d, "velodyne", n), "wb").write(b"")
+        poses = np.array(load_poses(os.path.join(d, "poses.txt")))
+        T_cam_velo = np.asarray(load_calib(os.path.join(d, "calib.txt"))).reshape(4, 4)
+        files = [os.path.basename(f) for f in load_files(os.path.join(d, "velodyne"))]
+    np.savez(os.path.join(HERE, "poses.npz"), poses_txt=np.array(poses_txt), calib_txt=np.array(calib_txt), poses=poses,
+             T_cam_velo=T_cam_velo, files=np.array(files))
+
+
 if __name__ == "__main__":
-    main()
+    if "--poses-only" not in sys.argv:
+        main()
+    poses_golden()

@@ -1,0 +1,151 @@
+"""Input / output stages of the driver ("next" row 1): pose parsing against golden vectors produced by the reference's
+own dataloader/utils.py, window indexing, and (on the GPU) pose alignment + stacking, the output stage and the
+predict_mos-style driver end to end against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_ops as R
+
+
+def _write_seq(root, seq, scans, poses_txt, calib_txt):
+    d = os.path.join(root, "{0:02d}".format(seq))
+    os.makedirs(os.path.join(d, "velodyne"), exist_ok=True)
+    for i, s in enumerate(scans):
+        s.astype(np.float32).tofile(os.path.join(d, "velodyne", "%06d.bin" % i))
+    open(os.path.join(d, "poses.txt"), "w").write(poses_txt)
+    open(os.path.join(d, "calib.txt"), "w").write(calib_txt)
+    return d
+
+
+def _ref_window(scans, poses, idx, n, dt):
+    """numpy restatement of DemoDataset.__getitem__ (scripts/predict_mos.py:114-166)."""
+    out = []
+    to_pose = poses[idx[-1]]
+    for k, i in enumerate(idx):
+        pc = scans[i].astype(np.float32).copy()
+        T = np.linalg.inv(to_pose) @ poses[i]
+        xyz1 = np.hstack([pc[:, :3], np.ones((len(pc), 1))]).T
+        pc[:, :3] = (T @ xyz1).T[:, :3]
+        ts = np.full((len(pc), 1), round((k - n + 1) * dt, 3), dtype=np.float32)
+        out.append(np.hstack([pc[:, :4], ts]))
+    return np.concatenate(out, 0).astype(np.float32)
+
+
+def test_pose_parsing_vs_reference_golden(golden_dir, tmp_path):
+    from insmos_amd import data as D
+    g = np.load(os.path.join(golden_dir, "poses.npz"))
+    d = tmp_path / "08"
+    os.makedirs(d / "velodyne")
+    (d / "poses.txt").write_text(str(g["poses_txt"]))
+    (d / "calib.txt").write_text(str(g["calib_txt"]))
+    for n in ("000002.bin", "000000.bin", "000001.bin"):
+        (d / "velodyne" / n).write_bytes(b"")
+    np.testing.assert_array_equal(D.load_poses(str(d / "poses.txt")), g["poses"])
+    np.testing.assert_array_equal(D.load_calib(str(d / "calib.txt")), g["T_cam_velo"])
+    assert [os.path.basename(f) for f in D.load_files(str(d / "velodyne"))] == list(g["files"])
+    lp = D.read_lidar_poses(str(d))
+    Tcv = g["T_cam_velo"]
+    exp = np.array([np.linalg.inv(Tcv).dot(np.linalg.inv(g["poses"][0])).dot(p).dot(Tcv) for p in g["poses"]])
+    np.testing.assert_array_equal(lp, exp)
+    np.testing.assert_allclose(lp[0], np.eye(4), atol=1e-12)
+
+
+def test_window_indexing():
+    from insmos_amd.data import SequenceWindows
+    w = SequenceWindows.__new__(SequenceWindows)
+    w.n, w.skip, w.files = 4, 2, list(range(11))
+    assert len(w) == 11 - 2 * 3
+    assert w.indices(0) == [0, 2, 4, 6] and w.indices(4) == [4, 6, 8, 10]
+
+
+@pytest.fixture(scope="module")
+def mini_dataset(tmp_path_factory, golden_dir):
+    from insmos_amd.synth import make_world, make_scan
+    g = np.load(os.path.join(golden_dir, "poses.npz"))
+    rng = np.random.default_rng(3)
+    world = make_world(rng, 20, 10)
+    scans = []
+    for i in range(6):
+        p = make_scan(rng, 0.5 * i, 160, world)
+        scans.append(np.hstack([p, rng.uniform(0, 1, (len(p), 1)).astype(np.float32)]))
+    root = str(tmp_path_factory.mktemp("kitti"))
+    d = _write_seq(root, 8, scans, str(g["poses_txt"]), str(g["calib_txt"]))
+    return root, d, scans
+
+
+@pytest.mark.gpu
+def test_stack_scans_matches_reference_restated(mini_dataset):
+    import torch
+    from insmos_amd import data as D, params as P
+    root, d, scans = mini_dataset
+    cfg = P.default_cfg()
+    cfg["MODEL"]["N_PAST_STEPS"] = 4
+    sw = D.SequenceWindows(cfg, d, 4)
+    assert len(sw) == 3
+    for j in range(3):
+        pts, meta = sw.window(j)
+        torch.cuda.synchronize()
+        ref = _ref_window(scans, sw.poses, sw.indices(j), 4, 0.1)
+        got = pts.cpu().numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got[:, 3:], ref[:, 3:])          # intensity, timestamps: exact
+        np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=2e-6)  # float64 transform, fp32 store
+        assert (got[:, :3] == ref[:, :3]).mean() > 0.99
+        assert meta[1] == sw.indices(j)[-1] and os.path.basename(meta[2][-1]) == "%06d.bin" % sw.indices(j)[-1]
+
+
+@pytest.mark.gpu
+def test_output_stage_vs_oracle():
+    import torch
+    from insmos_amd.predict_mos import output_stage
+    rng = np.random.default_rng(0)
+    lg = rng.normal(size=(5000, 3)).astype(np.float32)
+    lg[:50] = 0.0          # ties -> class 1 (static), predict_mos.py:441-451
+    lg[50:60, 0] = 100.0   # the ignored class never wins
+    lab, conf = output_stage(torch.from_numpy(lg).cuda(), [0], {0: 0, 1: 9, 2: 251})
+    rl, rc = R.output_stage(lg)
+    np.testing.assert_array_equal(lab.cpu().numpy(), rl)
+    np.testing.assert_allclose(conf.cpu().numpy(), rc, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_driver_end_to_end_files(mini_dataset, tmp_path):
+    """predict_sequence writes the reference's three files per scan; labels equal the oracle pipeline's."""
+    import torch
+    from insmos_amd import params as P
+    from insmos_amd.models import InsMOSNet
+    from insmos_amd.predict_mos import predict_sequence
+    from oracle import ref_model as M
+    root, d, scans = mini_dataset
+    cfg = P.default_cfg()
+    cfg["MODEL"]["N_PAST_STEPS"] = 3
+    sd = P.random_state_dict(cfg, 2)
+    model = InsMOSNet(cfg, state_dict=sd).cuda().eval()
+    out_root = str(tmp_path / "preb_out")
+    with torch.no_grad():
+        n = predict_sequence(model, cfg, d, 8, out_root)
+    assert n == 6  # 2 warm-up scans + 4 full windows
+    base = os.path.join(out_root, "InsMOS")
+    from insmos_amd.data import SequenceWindows
+    import copy
+    for scan_idx, n_past in ((0, 1), (1, 2), (2, 3), (5, 3)):
+        stem = "%06d" % scan_idx
+        lab = np.fromfile(os.path.join(base, "mos_preb", "sequences", "08", "predictions", stem + ".label"), dtype=np.int32)
+        conf = np.load(os.path.join(base, "confidence", "sequences", "08", "predictions", stem + ".npy"))
+        box = np.load(os.path.join(base, "bbox_preb", "sequences", "08", "predictions", stem + ".npy"), allow_pickle=True).item()
+        assert set(box) == {"pred_boxes", "pred_scores", "pred_labels"}
+        c2 = copy.deepcopy(cfg)
+        c2["MODEL"]["N_PAST_STEPS"] = n_past
+        sw = SequenceWindows(c2, d, n_past)
+        j = scan_idx - (n_past - 1)
+        assert sw.indices(j)[-1] == scan_idx
+        win = sw.window(j)[0].cpu().numpy()   # device-stacked window (checked against numpy in the test above)
+        ref_logits, ref_pred = M.forward_window(sd, cfg, win)
+        rl, rc = R.output_stage(ref_logits)
+        assert lab.shape == (len(scans[scan_idx]),) and conf.shape == (len(lab), 2)
+        np.testing.assert_array_equal(lab, rl)
+        np.testing.assert_allclose(conf, rc, atol=1e-3)
+        assert len(box["pred_boxes"]) == len(ref_pred["pred_boxes"])
+        assert set(np.unique(lab)) <= {0, 9, 251}
