@@ -42,7 +42,7 @@ struct ConvP {
     uint32_t n_out;
     uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
-    int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store, xcd_remap;
+    int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -73,32 +73,32 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 // vmcnt(0) inside each branch and shuttle the accumulators between AGPRs and VGPRs).  Running off
 // the end of the tap list re-requests the last tap (clamp instead of guard); rows past n_out compute
 // on re-read data and are masked at the store.
-// SPLIT > 1 (generic layers with >= 64 output channels): the tile covers ALL its channel tiles in one wave
-// and the SPLIT consecutive waves of a block share the tile's row group but take every SPLIT-th active
-// tap, so each input row chunk is gathered exactly once per tile (instead of once per channel group);
-// the partial accumulators are summed through LDS in fixed wave order (deterministic) in the epilogue.
-template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT>
-__global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
+//
+// SPLIT > 1: the tile covers ALL its channel tiles in one wave and the SPLIT consecutive waves of a block
+// share the tile's row group and split its contraction -- by 16-channel chunk when SPLITC (Cin/16 is a
+// multiple of SPLIT: perfectly even), else by every SPLIT-th active tap -- so each input row chunk is
+// gathered exactly once per tile (instead of once per channel group); the partial accumulators are summed
+// through LDS in fixed wave order (deterministic) in the epilogue.
+//
+// LOAD BALANCE.  Active-tap counts vary 4x between tiles on LiDAR data (tools/conv_probe.py: the same launch with
+// the same total work spread evenly over the tiles runs 1.2-1.6x faster), and mid-size layers have only a few tiles
+// per SIMD.  Two launch-shape rules follow (measured; a device-side atomic tile queue and a residency cap that
+// would let the dispatcher re-balance were both slower):
+//  * unsplit tiles run as ONE-WAVE workgroups, so a finished wave's slot is refilled at once instead of waiting for
+//    the slowest of four waves in its block;
+//  * masked layers with enough work per tile are SPLIT (above): 4x the waves, each a quarter as long.
+// DBG (probe builds only, tools/conv_probe.py): bit 0 = no weight loads, bit 1 = no gathers, bit 2 = no MFMAs
+template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0>
+__global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) {
+    static_assert(SPLIT == 1 || (JT == 1 && (COT % SPLIT == 0 || SPLIT % COT == 0)), "split tiles are 16 rows x all channels");
+    static_assert(!SPLITC || (SPLIT > 1 && CK == 0), "chunk split needs 16-channel chunks");
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
-    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware remap (bijective for any grid size): workgroup b runs on XCD b % 8, so give each XCD one
-    // CONTIGUOUS range of tiles -- rows are Morton-/raster-ordered, a contiguous range is spatially compact
-    // and its gathered rows (own range + halo) stay in that XCD's private 4 MiB L2.  Speed only, never correctness.
-    uint32_t bid = blockIdx.x;
-    if (P.xcd_remap) {
-        const uint32_t nb = gridDim.x, xcd = bid & 7u, q = nb >> 3, r = nb & 7u;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const uint32_t gw = bid * 4 + wib;
+    const uint32_t wib = SPLIT == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr uint32_t TPB = 4 / SPLIT;  // tiles per block (SPLIT > 1); unsplit tiles are one-wave blocks
     const uint32_t n_cg = P.ntile_co / COT;
     const uint32_t n_tiles = (uint32_t)P.n_otiles * n_cg;
-    const uint32_t tile_raw = gw / SPLIT, ws = gw % SPLIT;
-    const bool live = tile_raw < n_tiles;
-    if (SPLIT == 1 && !live) return;  // wave-uniform; split kernels keep dead waves alive for the block barrier
-    const uint32_t tile = live ? tile_raw : n_tiles - 1;
-    const uint32_t cg = tile / P.n_otiles;
-    const uint32_t ot = tile % P.n_otiles;
+    const uint32_t ws = wib % SPLIT;
     const int g = lane >> 4, j = lane & 15;
     const uint32_t n_out = P.n_out;
     const uint32_t ld4 = (uint32_t)P.ld_in * 4u;  // row pitch in bytes
@@ -107,221 +107,260 @@ __global__ void __launch_bounds__(256) k_sparse_conv(ConvP P) {
     const __amdgpu_buffer_rsrc_t rs_nb =
         __builtin_amdgcn_make_buffer_rsrc((void*)(IDENT ? (const void*)P.in : (const void*)P.nbr), 0,
                                           IDENT ? 4 : (int)((uint32_t)P.K * n_out * 4u), 0x00020000);
-
-    uint32_t orow[JT], rowoff[JT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        orow[jt] = ot * (16 * JT) + jt * 16 + j;
-        rowoff[jt] = (orow[jt] < n_out ? orow[jt] : n_out - 1) * 4u;  // byte offset inside one tap row of nbr
-    }
     constexpr uint32_t LW = CK == 4 ? 4u : CK == 8 ? 8u : 16u;  // bytes per lane per gather
     const uint32_t goff = (uint32_t)g * LW;
-
-    // ---- active-tap set of the tile = union over its 16-row groups (SGPRs)
-    uint64_t tlo = 0, thi = 0;
-    if constexpr (IDENT) {
-        tlo = 1;
-    } else {
-        const int K = P.K;
-        const uint32_t ngrp = (n_out + 15) >> 4;
-        if (P.mask16) {
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const uint32_t grp = ot * JT + jt;
-                const uint32_t* mp = P.mask16 + (size_t)(grp < ngrp ? grp : ngrp - 1) * 4;
-                uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
-                uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
-                if (grp < ngrp) {
-                    tlo |= ((uint64_t)w1 << 32) | w0;
-                    thi |= ((uint64_t)w3 << 32) | w2;
-                }
-            }
-        } else {
-            tlo = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
-            thi = K > 64 ? (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull)) : 0ull;
-        }
-    }
-    int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
-    if constexpr (SPLIT > 1) {
-        for (uint32_t q = 0; q < ws; ++q) (void)pop_or_keep(tlo, thi, 0);  // my taps: ranks ws, ws+SPLIT, ...
-        nt = (live && nt > (int)ws) ? (nt - (int)ws + SPLIT - 1) / SPLIT : 0;
-    }
-    // next tap of THIS wave (skips the taps owned by the other waves of the tile)
-    auto next_tap = [&](int keep) {
-        const int k = pop_or_keep(tlo, thi, keep);
-        if constexpr (SPLIT > 1) {
-#pragma unroll
-            for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
-        }
-        return k;
-    };
-
-    f32x4 acc[COT][JT];
-#pragma unroll
-    for (int it = 0; it < COT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const uint32_t blk_stride = (uint32_t)P.ntile_co * 256u;   // floats between chunk blocks of one tap
     const uint32_t tap_stride = (uint32_t)P.nblk * blk_stride;  // floats between taps
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.w, 0, (int)((uint32_t)P.K * tap_stride * 4u), 0x00020000);
-    const uint32_t woff = ((cg * COT) * 256u + lane * 4u) * 4u;
     constexpr int NS = CK ? CK / 4 : 4;  // MFMA steps per chunk
     const int nchunk = CK ? 1 : P.n16;
+    constexpr int CSTEP = SPLITC ? SPLIT : 1;
+    const int c0 = SPLITC ? (int)ws : 0;
+    const uint32_t cout = P.cout;
+    {
+        const uint32_t unit = blockIdx.x;
+        const uint32_t tile_raw = SPLIT == 1 ? unit : unit * TPB + wib / SPLIT;
+        const bool live = tile_raw < n_tiles;  // only split blocks can hold a dead tile (kept for the barriers)
+        const uint32_t tile = live ? tile_raw : n_tiles - 1;
+        const uint32_t cg = tile / P.n_otiles;
+        const uint32_t ot = tile % P.n_otiles;
 
-    // raw neighbour indices of tap k (one dword per 16-row group and lane)
-    auto load_idx = [&](int k, uint32_t (&idx)[JT]) {
+        uint32_t orow[JT], rowoff[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            if constexpr (IDENT) idx[jt] = rowoff[jt] >> 2;
-            else idx[jt] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff[jt], (uint32_t)k * n_out * 4u, 0);
+            orow[jt] = ot * (16 * JT) + jt * 16 + j;
+            rowoff[jt] = (orow[jt] < n_out ? orow[jt] : n_out - 1) * 4u;  // byte offset inside one tap row of nbr
         }
-    };
-    // byte offsets of the gathered rows; index -1 wraps past the end of the buffer -> loads return 0
-    auto row_offsets = [&](const uint32_t (&idx)[JT], uint32_t (&off)[JT]) {
+
+        // ---- active-tap set of the tile = union over its 16-row groups (SGPRs)
+        uint64_t tlo = 0, thi = 0;
+        if constexpr (IDENT) {
+            tlo = 1;
+        } else {
+            const int K = P.K;
+            const uint32_t ngrp = (n_out + 15) >> 4;
+            if (P.mask16) {
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) off[jt] = idx[jt] * ld4 + goff;
-    };
-    auto load_ab = [&](int k, int c, const uint32_t (&off)[JT], f32x4 (&a)[COT], f32x4 (&b)[JT]) {
-        const uint32_t so = (uint32_t)c * 64u;  // chunk byte offset inside a row (scalar)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            if constexpr (CK == 4) {
-                b[jt] = (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[jt], so, 0)), 0.f,
-                                0.f, 0.f};
-            } else if constexpr (CK == 8) {
-                f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, off[jt], so, 0));
-                b[jt] = (f32x4){t[0], t[1], 0.f, 0.f};
+                for (int jt = 0; jt < JT; ++jt) {
+                    const uint32_t grp = ot * JT + jt;
+                    const uint32_t* mp = P.mask16 + (size_t)(grp < ngrp ? grp : ngrp - 1) * 4;
+                    uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
+                    uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
+                    if (grp < ngrp) {
+                        tlo |= ((uint64_t)w1 << 32) | w0;
+                        thi |= ((uint64_t)w3 << 32) | w2;
+                    }
+                }
             } else {
-                b[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[jt], so, 0));
+                tlo = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+                thi = K > 64 ? (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull)) : 0ull;
             }
         }
-        // weight fragments through a buffer descriptor too: one load KIND in the loop keeps hipcc's
-        // vmcnt accounting exact (mixing global_ and buffer_ loads made it drain to vmcnt(0))
-        const uint32_t sw = ((uint32_t)k * tap_stride + (uint32_t)c * blk_stride) * 4u;
+        int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
+        if constexpr (SPLIT > 1 && !SPLITC) {
+            for (uint32_t q = 0; q < ws; ++q) (void)pop_or_keep(tlo, thi, 0);  // my taps: ranks ws, ws+SPLIT, ...
+            nt = (live && nt > (int)ws) ? (nt - (int)ws + SPLIT - 1) / SPLIT : 0;
+        } else if constexpr (SPLIT > 1) {
+            nt = live ? nt : 0;
+        }
+        // next tap of THIS wave (a tap-split wave skips the taps owned by the other waves of the tile)
+        auto next_tap = [&](int keep) {
+            const int k = pop_or_keep(tlo, thi, keep);
+            if constexpr (SPLIT > 1 && !SPLITC) {
+#pragma unroll
+                for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
+            }
+            return k;
+        };
+
+        f32x4 acc[COT][JT];
 #pragma unroll
         for (int it = 0; it < COT; ++it)
-            a[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff + (uint32_t)it * 1024u, sw, 0));
-    };
-    auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT]) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], b[jt][s], acc[it][jt]);
-    };
+            for (int jt = 0; jt < JT; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nt > 0) {
-        // ---- load cursor: (kL, cL) = next item to request; offL = its rows; tap ring kN/idxN, kNN/idxNN
-        int kL = next_tap(0);
-        int kN = next_tap(kL);
-        int kNN = next_tap(kN);
-        int cL = 0;
-        uint32_t offL[JT], idxN[JT], idxNN[JT];
-        {
-            uint32_t idx0[JT];
-            load_idx(kL, idx0);
-            load_idx(kN, idxN);
-            load_idx(kNN, idxNN);
-            row_offsets(idx0, offL);
-        }
-        f32x4 bs[R][JT], as[R][COT];
-        const int nitems = nt * nchunk;
+        const uint32_t woff = ((cg * COT) * 256u + lane * 4u) * 4u;
+
+        // raw neighbour indices of tap k (one dword per 16-row group and lane)
+        auto load_idx = [&](int k, uint32_t (&idx)[JT]) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if constexpr (IDENT) idx[jt] = rowoff[jt] >> 2;
+                else idx[jt] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff[jt], (uint32_t)k * n_out * 4u, 0);
+            }
+        };
+        // byte offsets of the gathered rows; index -1 wraps past the end of the buffer -> loads return 0
+        auto row_offsets = [&](const uint32_t (&idx)[JT], uint32_t (&off)[JT]) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) off[jt] = idx[jt] * ld4 + goff;
+        };
+        auto load_ab = [&](int k, int c, const uint32_t (&off)[JT], f32x4 (&a)[COT], f32x4 (&b)[JT]) {
+            const uint32_t so = (uint32_t)c * 64u;  // chunk byte offset inside a row (scalar)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if constexpr (DBG & 2) {
+                    if (k == 1000) b[jt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                } else if constexpr (CK == 4) {
+                    b[jt] = (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off[jt], so, 0)),
+                                    0.f, 0.f, 0.f};
+                } else if constexpr (CK == 8) {
+                    f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, off[jt], so, 0));
+                    b[jt] = (f32x4){t[0], t[1], 0.f, 0.f};
+                } else {
+                    b[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[jt], so, 0));
+                }
+            }
+            // weight fragments through a buffer descriptor too: one load KIND in the loop keeps hipcc's
+            // vmcnt accounting exact (mixing global_ and buffer_ loads made it drain to vmcnt(0))
+            const uint32_t sw = ((uint32_t)k * tap_stride + (uint32_t)c * blk_stride) * 4u;
+#pragma unroll
+            for (int it = 0; it < COT; ++it) {
+                if constexpr (DBG & 1) {
+                    if (k == 1000) a[it] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                } else {
+                    a[it] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff + (uint32_t)it * 1024u, sw, 0));
+                }
+            }
+        };
+        auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT]) {
+            if constexpr (DBG & 4) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) asm volatile("" ::"v"(b[jt]));
+#pragma unroll
+                for (int it = 0; it < COT; ++it) asm volatile("" ::"v"(a[it]));
+                return;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], b[jt][s], acc[it][jt]);
+        };
+
+        if (nt > 0) {
+            // ---- load cursor: (kL, cL) = next item to request; tap ring: offL = row offsets of the current tap,
+            // offN = those of the next one (already scaled), idxNN = raw indices of the tap after that, in flight.
+            // (The ring holds SCALED offsets on purpose: rotating raw loaded indices between variables made hipcc
+            // copy the just-issued load at the loop back-edge, i.e. wait vmcnt(0) every iteration.)
+            int kL = next_tap(0);
+            int kN = next_tap(kL);
+            int kNN = next_tap(kN);
+            int cL = c0;
+            uint32_t offL[JT], offN[JT], idxNN[JT];
+            {
+                uint32_t idx0[JT], idx1[JT];
+                load_idx(kL, idx0);
+                load_idx(kN, idx1);
+                load_idx(kNN, idxNN);
+                row_offsets(idx0, offL);
+                row_offsets(idx1, offN);
+            }
+            f32x4 bs[R][JT], as[R][COT];
+            if constexpr (DBG != 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) bs[r][jt] = (f32x4){0.5f, 0.5f, 0.5f, 0.5f};
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) as[r][it] = (f32x4){0.5f, 0.5f, 0.5f, 0.5f};
+                }
+            }
+            const int nitems = nt * (nchunk / CSTEP);
 #define REQUEST(slot)                                                                     \
     {                                                                                     \
         load_ab(kL, cL, offL, as[slot], bs[slot]);                                        \
-        if (cL + 1 < nchunk) {                                                            \
-            ++cL;                                                                         \
+        if (cL + CSTEP < nchunk) {                                                        \
+            cL += CSTEP;                                                                  \
         } else {                                                                          \
-            cL = 0;                                                                       \
+            cL = c0;                                                                      \
             kL = kN; kN = kNN;                                                            \
-            row_offsets(idxN, offL);                                                      \
-            _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) idxN[jt] = idxNN[jt];       \
+            _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) offL[jt] = offN[jt];        \
+            row_offsets(idxNN, offN);                                                     \
             kNN = next_tap(kNN);                                                          \
             load_idx(kNN, idxNN);                                                         \
         }                                                                                 \
     }
 #pragma unroll
-        for (int r = 0; r < R - 1; ++r) REQUEST(r)
-        int i = 0;
-        for (; i + R <= nitems; i += R) {
+            for (int r = 0; r < R - 1; ++r) REQUEST(r)
+            int i = 0;
+            for (; i + R <= nitems; i += R) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                REQUEST((r + R - 1) % R)
-                mma(as[r], bs[r]);
+                for (int r = 0; r < R; ++r) {
+                    REQUEST((r + R - 1) % R)
+                    mma(as[r], bs[r]);
+                }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R - 1; ++r) {
-            if (i + r < nitems) {  // wave-uniform tail, at most R-1 items (their operands are already in flight)
-                mma(as[r], bs[r]);
+            for (int r = 0; r < R - 1; ++r) {
+                if (i + r < nitems) {  // wave-uniform tail, at most R-1 items (their operands are already in flight)
+                    mma(as[r], bs[r]);
+                }
             }
-        }
 #undef REQUEST
-    }
-
-    // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow[jt]
-    const uint32_t cout = P.cout;
-    auto finish = [&](int it, int jt, f32x4 v) {
-        const uint32_t co0 = (cg * COT + it) * 16 + 4 * g;
-        const uint32_t o = orow[jt];
-        if (o >= n_out || co0 >= cout) return;
-        v += *(const f32x4*)(P.bias + co0);
-        if (P.relu_pre) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        if (P.res_mode == 1) {
-            const float* rp = P.res + (size_t)o * P.ld_res + co0;
+
+        // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow[jt]
+        auto finish = [&](int it, int jt, f32x4 v) {
+            const uint32_t co0 = (cg * COT + it) * 16 + 4 * g;
+            const uint32_t o = orow[jt];
+            if (o >= n_out || co0 >= cout) return;
+            v += *(const f32x4*)(P.bias + co0);
+            if (P.relu_pre) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (P.res_mode == 1) {
+                const float* rp = P.res + (size_t)o * P.ld_res + co0;
+                if (P.vec_store && co0 + 3 < cout) {
+                    v += *(const f32x4*)rp;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co0 + r < cout) v[r] += rp[r];
+                }
+            } else if (P.res_mode == 2) {
+                const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
+            }
+            if (P.relu_post) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            float* op = P.out + (size_t)o * P.ld_out + co0;
             if (P.vec_store && co0 + 3 < cout) {
-                v += *(const f32x4*)rp;
+                *(f32x4*)op = v;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co0 + r < cout) v[r] += rp[r];
+                    if (co0 + r < cout) op[r] = v[r];
             }
-        } else if (P.res_mode == 2) {
-            const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
+        };
+        if constexpr (SPLIT == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
-        }
-        if (P.relu_post) {
+            for (int it = 0; it < COT; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        float* op = P.out + (size_t)o * P.ld_out + co0;
-        if (P.vec_store && co0 + 3 < cout) {
-            *(f32x4*)op = v;
+                for (int jt = 0; jt < JT; ++jt) finish(it, jt, acc[it][jt]);
         } else {
+            __shared__ f32x4 red[4][COT][64];  // [wave in block][channel tile][lane]
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < cout) op[r] = v[r];
-        }
-    };
-    if constexpr (SPLIT == 1) {
+            for (int it = 0; it < COT; ++it) red[wib][it][lane] = acc[it][0];
+            __syncthreads();
+            if (live && (COT >= SPLIT || ws < (uint32_t)COT)) {  // (fewer channel tiles than waves: the first COT waves finish)
+                const uint32_t w0 = wib - ws;  // first wave of this tile inside the block
+                constexpr int PER = COT >= SPLIT ? COT / SPLIT : 1;
 #pragma unroll
-        for (int it = 0; it < COT; ++it)
+                for (int q = 0; q < PER; ++q) {
+                    const int it = (int)ws * PER + q;
+                    f32x4 v = red[w0][it][lane];
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) finish(it, jt, acc[it][jt]);
-    } else {
-        static_assert(SPLIT == 1 || (JT == 1 && COT % SPLIT == 0), "tap-split tiles are 16 rows x all channels");
-        __shared__ f32x4 red[4][COT][64];  // [wave in block][channel tile][lane]
-#pragma unroll
-        for (int it = 0; it < COT; ++it) red[wib][it][lane] = acc[it][0];
-        __syncthreads();
-        if (live) {
-            const uint32_t w0 = wib - ws;  // first wave of this tile inside the block
-            constexpr int PER = COT / SPLIT;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int it = (int)ws * PER + q;
-                f32x4 v = red[w0][it][lane];
-#pragma unroll
-                for (int p = 1; p < SPLIT; ++p) v += red[w0 + p][it][lane];  // fixed order -> deterministic
-                finish(it, 0, v);
+                    for (int p = 1; p < SPLIT; ++p) v += red[w0 + p][it][lane];  // fixed order -> deterministic
+                    finish(it, 0, v);
+                }
             }
         }
     }
@@ -402,7 +441,7 @@ template <int COT, int JT> constexpr int ring_depth() { return COT * JT <= 2 ? 3
 
 template <int CK, bool IDENT>
 ConvKernel pick_kernel(int cot, int jt) {
-#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT, ring_depth<C, J>(), 1>;
+#define CASE(C, J) if (cot == C && jt == J) return k_sparse_conv<C, J, CK, IDENT, ring_depth<C, J>(), 1, false>;
     if constexpr (CK == 0) {
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4) CASE(4, 1) CASE(4, 2) CASE(4, 4)
         CASE(8, 1) CASE(8, 2) CASE(8, 4)
@@ -413,10 +452,34 @@ ConvKernel pick_kernel(int cot, int jt) {
     return nullptr;
 }
 
-// tuning hook (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring)
-int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0;
+// split tiles: 4 waves per 16-row tile, all channel tiles per wave; contraction split by chunk (even) or by tap
+ConvKernel pick_split(int cot, int ck, bool by_chunk) {
+    if (ck == 8) {
+        if (cot == 1) return k_sparse_conv<1, 1, 8, false, 3, 4, false>;
+        if (cot == 2) return k_sparse_conv<2, 1, 8, false, 3, 4, false>;
+        return nullptr;
+    }
+    if (ck) return nullptr;
+#define CASE(C, RR) if (cot == C) return by_chunk ? k_sparse_conv<C, 1, 0, false, RR, 4, true> : k_sparse_conv<C, 1, 0, false, RR, 4, false>;
+    CASE(8, 2) CASE(4, 2) CASE(2, 3) CASE(1, 3)
+#undef CASE
+    return nullptr;
+}
+
+// tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
+int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
+// probe variants of the kernel configurations the heavy S0 layers use (ring >= 16 selects dbg = ring / 16)
+template <int DBG>
+ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
+    if (ck == 8 && cot == 1 && jt == 2) return k_sparse_conv<1, 2, 8, false, 3, 1, false, DBG>;
+    if (ck == 0 && split == 1 && cot == 1 && jt == 1) return k_sparse_conv<1, 1, 0, false, 3, 1, false, DBG>;
+    if (ck == 0 && split == 1 && cot == 2 && jt == 1) return k_sparse_conv<2, 1, 0, false, 3, 1, false, DBG>;
+    if (ck == 0 && split == 1 && cot == 4 && jt == 1) return k_sparse_conv<4, 1, 0, false, 2, 1, false, DBG>;
+    if (ck == 0 && split == 4 && cot == 8 && by_chunk) return k_sparse_conv<8, 1, 0, false, 2, 4, true, DBG>;
+    return nullptr;
+}
 ConvKernel pick_forced(int cot, int jt, int ring) {
-#define CASE(C, J, RR) if (cot == C && jt == J && ring == RR) return k_sparse_conv<C, J, 0, false, RR, 1>;
+#define CASE(C, J, RR) if (cot == C && jt == J && ring == RR) return k_sparse_conv<C, J, 0, false, RR, 1, false>;
 #define CASES(C, J) CASE(C, J, 2) CASE(C, J, 3) CASE(C, J, 4)
     CASES(1, 1) CASES(1, 2) CASES(1, 4) CASES(2, 1) CASES(2, 2) CASES(2, 4) CASES(4, 1) CASES(4, 2) CASES(4, 4)
     CASE(8, 1, 2) CASE(8, 1, 3) CASE(8, 2, 2) CASE(8, 2, 3) CASE(8, 4, 2)
@@ -424,6 +487,12 @@ ConvKernel pick_forced(int cot, int jt, int ring) {
 #undef CASE
     return nullptr;
 }
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 }  // namespace
 
 extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
@@ -453,19 +522,17 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     if (!ck && (cin % 16 != 0)) return INSMOS_EINVAL;  // supported widths: 4, 8, or a multiple of 16
     // tile shape, from tools/conv_tune.py sweeps on MI355X: a 16-row gather is ~8x the cost of a coalesced
     // weight fragment, so generic layers always use 16-row tiles (JT = 1) and widen in channels instead:
-    // 2 channel tiles per wave, 4 when the layer is large enough to still give >= 2 waves per SIMD (the
-    // dense BEV convs).  Single-chunk small-C layers (Cin 4/8) use `ck_jt` row groups per wave.
+    // 2 channel tiles per wave, 4 when the layer is large enough to still give >= 2 waves per SIMD.
+    // Single-chunk small-C layers (Cin 4/8) use `ck_jt` row groups per wave.
     static int ck_jt = 0;
-    if (!ck_jt) { const char* e = getenv("INSMOS_CK_JT"); ck_jt = e ? atoi(e) : 2; if (ck_jt != 1 && ck_jt != 4) ck_jt = 2; }
+    if (!ck_jt) { ck_jt = env_int("INSMOS_CK_JT", 2); if (ck_jt != 1 && ck_jt != 4) ck_jt = 2; }
     Cfg best = {1, ck ? ck_jt : 1};
-    {
-        const long groups = (long)((n_out + 15) / 16);
-        if (!ck) {
-            if (P.ntile_co % 4 == 0 && groups * (P.ntile_co / 4) >= 2048) best.cot = 4;
-            else if (P.ntile_co % 2 == 0) best.cot = 2;
-        } else if (P.ntile_co % 2 == 0) {
-            best.cot = 2;
-        }
+    const long groups = (long)((n_out + 15) / 16);
+    if (!ck) {
+        if (P.ntile_co % 4 == 0 && groups * (P.ntile_co / 4) >= 2048) best.cot = 4;
+        else if (P.ntile_co % 2 == 0) best.cot = 2;
+    } else if (P.ntile_co % 2 == 0) {
+        best.cot = 2;
     }
     P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
     const bool ident = (nbr == nullptr);
@@ -473,33 +540,59 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     if (ck == 4) kern = ident ? pick_kernel<4, true>(best.cot, best.jt) : pick_kernel<4, false>(best.cot, best.jt);
     else if (ck == 8) kern = ident ? pick_kernel<8, true>(best.cot, best.jt) : pick_kernel<8, false>(best.cot, best.jt);
     else kern = ident ? pick_kernel<0, true>(best.cot, best.jt) : pick_kernel<0, false>(best.cot, best.jt);
-    // tap-split tiles: all channel tiles in one wave, the block's waves share the row group and split the taps
+    // split tiles: all channel tiles in one wave, the 4 waves of a block share the row group and split the
+    // contraction (by chunk when Cin/16 is a multiple of 4 -- even work --, else by active tap).  Each input row
+    // chunk is gathered once per tile instead of once per channel group, and the layer gets 4x the waves.
     int split = 1;
-    static int split_env = -1;
-    if (split_env < 0) { const char* e = getenv("INSMOS_CONV_SPLIT"); split_env = e ? atoi(e) : 1; }
-    // (measured: +20-30 % on the masked 27-tap C >= 64 layers; no gain on dense 9-tap BEV convs or 3-tap layers)
-    if (split_env && !ck && !ident && mask16 && (P.ntile_co == 4 || P.ntile_co == 8) && K >= 16) {
-        split = 4;
-        best = {P.ntile_co, 1};
-        P.n_otiles = (int)((n_out + 15) / 16);
-        if (P.ntile_co == 8) kern = split == 4 ? k_sparse_conv<8, 1, 0, false, 2, 4> : k_sparse_conv<8, 1, 0, false, 2, 2>;
-        else kern = split == 4 ? k_sparse_conv<4, 1, 0, false, 2, 4> : k_sparse_conv<4, 1, 0, false, 2, 2>;
+    bool by_chunk = false;
+    static int split_env = -1, split_dense = -1;
+    if (split_env < 0) { split_env = env_int("INSMOS_CONV_SPLIT", 1); split_dense = env_int("INSMOS_CONV_SPLIT_DENSE", 1); }
+    // (measured on S0: splitting pays when a tile carries >= ~100 (tap, chunk, channel-tile) MFMA groups -- the
+    // 81-tap C >= 32 4D layers gain 20-30 % -- and costs 30-50 % on the small-C layers that already have 10k+ tiles)
+    static int split_work = -1;
+    if (split_work < 0) split_work = env_int("INSMOS_CONV_SPLIT_WORK", 100);
+    const bool co_ok = P.ntile_co == 1 || P.ntile_co == 2 || P.ntile_co == 4 || P.ntile_co == 8;
+    const bool wide = P.ntile_co >= 4;
+    const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
+    if (split_env && !ident && co_ok && (ck == 0 || ck == 8) &&
+        ((mask16 && K >= 16 && (wide || tile_work >= split_work)) || (!ck && wide && split_dense && P.n16 % 4 == 0 && K >= 3))) {
+        ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0);
+        if (sk) {
+            split = 4;
+            by_chunk = (!ck && P.n16 % 4 == 0);
+            best = {P.ntile_co, 1};
+            P.n_otiles = (int)groups;
+            kern = sk;
+        }
     }
     if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
-        split = 1;
         ConvKernel fk = pick_forced(g_force_cot, g_force_jt, g_force_ring);
         if (fk) {
+            split = 1;
+            by_chunk = false;
             kern = fk;
             best = {g_force_cot, g_force_jt};
             P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
         }
     }
+    if (g_dbg && !ident) {
+        ConvKernel pk = nullptr;
+        switch (g_dbg) {
+            case 1: pk = pick_probe<1>(best.cot, best.jt, ck, split, by_chunk); break;
+            case 2: pk = pick_probe<2>(best.cot, best.jt, ck, split, by_chunk); break;
+            case 3: pk = pick_probe<3>(best.cot, best.jt, ck, split, by_chunk); break;
+            case 4: pk = pick_probe<4>(best.cot, best.jt, ck, split, by_chunk); break;
+            case 7: pk = pick_probe<7>(best.cot, best.jt, ck, split, by_chunk); break;
+        }
+        if (pk) kern = pk;
+    }
     if (!kern) return INSMOS_EINVAL;
-    static int xcd_env = -1;
-    if (xcd_env < 0) { const char* e = getenv("INSMOS_XCD_REMAP"); xcd_env = e ? atoi(e) : 0; }  // measured on S0: -4 % (weights are re-read per XCD, ranges imbalance) -> off by default
-    P.xcd_remap = xcd_env;
-    long waves = (long)P.n_otiles * (P.ntile_co / best.cot) * split;
-    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+
+    // ---- launch shape: one ONE-WAVE block per tile (split: one 4-wave block per tile)
+    const long tiles = (long)P.n_otiles * (P.ntile_co / best.cot);
+    const int wpb = split == 1 ? 1 : 4;  // waves per block
+    const long nblocks = split == 1 ? tiles : (tiles + (4 / split) - 1) / (4 / split);
+    dim3 grid((unsigned)nblocks), block(64 * wpb);
     ProfScope ps(KK_SPARSE_CONV, s);
     hipLaunchKernelGGL(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
@@ -507,7 +600,8 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
 }
 
 extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {
-    g_force_cot = cot; g_force_jt = jt; g_force_ring = ring;
+    g_dbg = ring / 16;
+    g_force_cot = cot; g_force_jt = jt; g_force_ring = ring % 16;
     return INSMOS_OK;
 }
 
