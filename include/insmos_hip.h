@@ -40,6 +40,9 @@ int insmos_prof_reset(void);
 /* Synchronises, then writes up to `max` entries; returns the number of kernel kinds. */
 int insmos_prof_read(int max, int* kind_ids_host, double* total_ms_host, int64_t* launches_host);
 const char* insmos_prof_name(int kind_id);
+/* One kernel kind when launches overlap on several streams: length of the union of the launches' event intervals,
+ * the plain sum of their durations, and their number. */
+int insmos_prof_read_union(int kind_id, double* union_ms_host, double* sum_ms_host, int64_t* launches_host);
 
 /* ------------------------------------------------------------------------------------------------
  * insmos_quantize4d -- replaces ME.utils.sparse_collate + ME.TensorField(...).sparse() as called
@@ -285,6 +288,45 @@ int insmos_output_stage(const float* logits, int ld, int64_t n, int ncls, unsign
  * ---------------------------------------------------------------------------------------------- */
 int insmos_confusion3(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
                       int64_t* cm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native window runner -- InsMOS_Model.forward(list, 'test') for ONE batch item (models/models.py:313-364) as one
+ * foreign call: the same operator sequence insmos_amd/engine.py issues step by step (MotionNet -> voxelise ->
+ * UNetV2 encoder -> BEV CenterHead -> NMS -> instance-fused decoder -> per-point logits), driven from C++ so that
+ * windows can be in flight on several HIP streams from several host threads without interpreter work in between.
+ *   insmos_ctx_create: `layers[i]` (device pointers to weights packed by insmos_pack_weights_host + padded bias) under
+ *     `names[i]` = the engine's layer names ("block1.0.conv1", "conv_up_t4.conv2", "bev0", "head", ...); a missing
+ *     layer makes insmos_forward_window return INSMOS_EINVAL.  The context is immutable after creation and may be
+ *     shared by threads; each concurrent window needs its own arena and stream.
+ *   insmos_forward_window: points (N, ld >= 5) fp32 device [x, y, z, intensity, t]; every intermediate and the
+ *     outputs live in `arena` (device, bump-allocated); INSMOS_EWORKSPACE => out->arena_needed holds a size that is
+ *     enough for this window's allocations so far (grow and retry).  Outputs (byte offsets into the arena, valid
+ *     until the arena's next use): logits (n_cur, 3) fp32, boxes (n_boxes, 7) fp32, scores (n_boxes) fp32,
+ *     labels (n_boxes) i64.  Synchronises the stream (the count read-backs size the next launches).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct InsmosConvW {
+    const float* w; /* packed taps */
+    const float* b; /* bias, padded to a multiple of 16 */
+    int32_t K, cin, cout, reserved;
+} InsmosConvW;
+typedef struct InsmosNetCfg {
+    const float* w0_const;   /* (125, 8): 0.5 * BN-folded conv0 taps (constant-input first layer, motionnet.py:29-32) */
+    const float* b0_const;   /* (8) */
+    const int32_t* nbr_bev;  /* insmos_dense_nbr2d(bevH, bevW) */
+    float vs[3], dt, range[6], score_thresh, nms_thresh, out_factor, tvs[2];
+    int32_t in_ch, ncls, max_voxels, max_points;
+    int32_t shape[6][3]; /* spconv spatial shapes [z, y, x] of levels 1..5 (index 0 unused), spconv_unet.py:114 */
+    int32_t bevD, bevH, bevW, nbev, n_bev_layers, up_ch, head_ld, pre_max, post_max, quirk_exact;
+} InsmosNetCfg;
+typedef struct InsmosForwardOut {
+    int64_t me_voxels[4], n_cur, unet_voxels[5], n_candidates, n_boxes, n_out_of_window;
+    int64_t logits_off, boxes_off, scores_off, labels_off, arena_needed;
+} InsmosForwardOut;
+int insmos_ctx_create(const InsmosNetCfg* cfg, const char* const* names, const InsmosConvW* layers, int n_layers,
+                      void** ctx_out);
+int insmos_ctx_destroy(void* ctx);
+int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts, void* arena, size_t arena_bytes,
+                          void* stream, InsmosForwardOut* out);
 
 #ifdef __cplusplus
 }

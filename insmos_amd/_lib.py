@@ -18,6 +18,7 @@ SIGNATURES = {
     "insmos_prof_reset": (c_int, []),
     "insmos_prof_read": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "insmos_prof_name": (ctypes.c_char_p, [c_int]),
+    "insmos_prof_read_union": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "insmos_quantize4d_ws_bytes": (c_sz, [c_i64]),
     "insmos_quantize4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_level_down4d_ws_bytes": (c_sz, [c_i64]),
@@ -55,7 +56,32 @@ SIGNATURES = {
     "insmos_stack_scan": (c_int, [c_vp, c_i64, c_vp, c_f32, c_vp, c_int, c_vp]),
     "insmos_output_stage": (c_int, [c_vp, c_int, c_i64, c_int, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "insmos_confusion3": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp]),
+    "insmos_ctx_create": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    "insmos_ctx_destroy": (c_int, [c_vp]),
+    "insmos_forward_window": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp]),
 }
+
+
+class ConvW(ctypes.Structure):  # InsmosConvW
+    _fields_ = [("w", c_vp), ("b", c_vp), ("K", ctypes.c_int32), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class NetCfg(ctypes.Structure):  # InsmosNetCfg
+    _fields_ = [("w0_const", c_vp), ("b0_const", c_vp), ("nbr_bev", c_vp),
+                ("vs", c_f32 * 3), ("dt", c_f32), ("range", c_f32 * 6), ("score_thresh", c_f32), ("nms_thresh", c_f32),
+                ("out_factor", c_f32), ("tvs", c_f32 * 2),
+                ("in_ch", ctypes.c_int32), ("ncls", ctypes.c_int32), ("max_voxels", ctypes.c_int32),
+                ("max_points", ctypes.c_int32), ("shape", (ctypes.c_int32 * 3) * 6),
+                ("bevD", ctypes.c_int32), ("bevH", ctypes.c_int32), ("bevW", ctypes.c_int32), ("nbev", ctypes.c_int32),
+                ("n_bev_layers", ctypes.c_int32), ("up_ch", ctypes.c_int32), ("head_ld", ctypes.c_int32),
+                ("pre_max", ctypes.c_int32), ("post_max", ctypes.c_int32), ("quirk_exact", ctypes.c_int32)]
+
+
+class ForwardOut(ctypes.Structure):  # InsmosForwardOut
+    _fields_ = [("me_voxels", c_i64 * 4), ("n_cur", c_i64), ("unet_voxels", c_i64 * 5), ("n_candidates", c_i64),
+                ("n_boxes", c_i64), ("n_out_of_window", c_i64), ("logits_off", c_i64), ("boxes_off", c_i64),
+                ("scores_off", c_i64), ("labels_off", c_i64), ("arena_needed", c_i64)]
 
 _lib = None
 

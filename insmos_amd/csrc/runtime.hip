@@ -1,5 +1,7 @@
 // insmos_amd/csrc/runtime.hip -- version / error / profiler plumbing of libinsmos_hip.so.
+#include <algorithm>
 #include <mutex>
+#include <utility>
 #include <vector>
 #include "common.h"
 
@@ -62,4 +64,37 @@ extern "C" int insmos_prof_read(int max, int* kind_ids_host, double* total_ms_ho
         kind_ids_host[n] = k; total_ms_host[n] = tot[k]; launches_host[n] = cnt[k]; ++n;
     }
     return n;
+}
+
+// Busy time of one kernel kind when launches on several streams overlap: the length of the UNION of the launches'
+// [start, end] event intervals (same device clock), next to the plain sum of their durations.
+extern "C" int insmos_prof_read_union(int kind_id, double* union_ms_host, double* sum_ms_host, int64_t* launches_host) {
+    if (!union_ms_host || !sum_ms_host || !launches_host) return INSMOS_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<std::pair<double, double>> iv;
+    double sum = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        hipEvent_t base = nullptr;
+        for (auto& sp : g_spans) {
+            if (!base) base = sp.e0;
+            if (sp.kind != kind_id) continue;
+            float a = 0.f, d = 0.f;
+            if (hipEventElapsedTime(&a, base, sp.e0) != hipSuccess || hipEventElapsedTime(&d, sp.e0, sp.e1) != hipSuccess) continue;
+            iv.emplace_back((double)a, (double)a + (double)d);
+            sum += d;
+        }
+    }
+    std::sort(iv.begin(), iv.end());
+    double uni = 0.0, lo = 0.0, hi = -1.0;
+    for (auto& p : iv) {
+        if (hi < 0.0) { lo = p.first; hi = p.second; }
+        else if (p.first <= hi) hi = std::max(hi, p.second);
+        else { uni += hi - lo; lo = p.first; hi = p.second; }
+    }
+    if (hi >= 0.0) uni += hi - lo;
+    *union_ms_host = uni;
+    *sum_ms_host = sum;
+    *launches_host = (int64_t)iv.size();
+    return INSMOS_OK;
 }

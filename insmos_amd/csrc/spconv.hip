@@ -525,7 +525,7 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     // 2 channel tiles per wave, 4 when the layer is large enough to still give >= 2 waves per SIMD.
     // Single-chunk small-C layers (Cin 4/8) use `ck_jt` row groups per wave.
     static int ck_jt = 0;
-    if (!ck_jt) { ck_jt = env_int("INSMOS_CK_JT", 2); if (ck_jt != 1 && ck_jt != 4) ck_jt = 2; }
+    if (!ck_jt) { ck_jt = env_int("INSMOS_CK_JT", 1); if (ck_jt != 2 && ck_jt != 4) ck_jt = 1; }
     Cfg best = {1, ck ? ck_jt : 1};
     const long groups = (long)((n_out + 15) / 16);
     if (!ck) {

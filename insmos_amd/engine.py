@@ -93,8 +93,11 @@ class NbrTable:
 
 
 class Engine:
-    def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5):
+    def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5, native=False):
         self.lib = _lib.load()
+        self.native = native      # default path of forward_window (see there)
+        self._ctx_box = [None]    # native context, shared with clones
+        self._arena = None
         self.cfg = cfg
         self.device = torch.device(device)
         self.quirk_exact = quirk_exact
@@ -148,6 +151,7 @@ class Engine:
 
     def _load_weights(self, sd):
         self.sd = sd
+        self._ctx_box = [None]  # (old contexts are leaked on purpose: clones may still run on them)
         L, dev, lib = {}, self.device, self.lib
         M = P.ME_PREFIX
 
@@ -607,15 +611,96 @@ class Engine:
         return logits, pred
 
     # ------------------------------------------------------------------------------------------------
-    def forward_window(self, pts):
-        """One batch item of InsMOS_Model.forward(..., 'test') (models/models.py:313-364)."""
+    def forward_window(self, pts, native=None):
+        """One batch item of InsMOS_Model.forward(..., 'test') (models/models.py:313-364).
+
+        native=True runs the window through insmos_forward_window (csrc/forward.hip: the same operator sequence
+        driven from C++, one foreign call, no interpreter work between launches); native=False issues the operators
+        step by step from Python and keeps every intermediate for inspection (tests, profiling hooks).  Both give
+        identical bits (tests/test_gpu_model.py).  Default: the engine's `native` attribute."""
         if pts.dtype != torch.float32 or pts.device.type != "cuda" or pts.dim() != 2 or pts.shape[1] < 5:
             raise ValueError("past_point_clouds must be a float32 CUDA tensor of shape (N, 5) [x,y,z,intensity,t]")
         if pts.stride(1) != 1:
             pts = pts.contiguous()
+        if self.native if native is None else native:
+            return self._forward_native(pts)
         self._conv_log = []
         cur = self.motionnet(pts)
         return self.unet(cur)
+
+    # ------------------------------------------------------------------------------------------------
+    def _native_ctx(self):
+        """The immutable C++ context (layer table + config) -- built once, shared by clones."""
+        if self._ctx_box[0] is None:
+            cfgs = _lib.NetCfg()
+            cfgs.w0_const, cfgs.b0_const = self.w0_const.data_ptr(), self.b0_const.data_ptr()
+            cfgs.nbr_bev = self.nbr_bev.data_ptr()
+            cfgs.vs[:] = self.vs
+            cfgs.dt = self.dt
+            cfgs.range[:] = self.range
+            cfgs.score_thresh, cfgs.nms_thresh, cfgs.out_factor = self.score_thresh, self.nms_thresh, self.out_factor
+            cfgs.tvs[:] = self.tvs[:2]
+            cfgs.in_ch, cfgs.ncls, cfgs.max_voxels, cfgs.max_points = self.in_ch, self.ncls, self.max_voxels, self.max_points
+            for l in (1, 2, 3, 4, 5):
+                cfgs.shape[l][:] = self.shape[l]
+            cfgs.bevD, cfgs.bevH, cfgs.bevW, cfgs.nbev = self.bevD, self.bevH, self.bevW, self.nbev
+            cfgs.n_bev_layers, cfgs.up_ch, cfgs.head_ld = self.n_bev_layers, self.up_ch, self.head_ld
+            cfgs.pre_max, cfgs.post_max, cfgs.quirk_exact = self.pre_max, self.post_max, 1 if self.quirk_exact else 0
+            names = sorted(self.L)
+            arr_n = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+            arr_l = (_lib.ConvW * len(names))()
+            for i, n in enumerate(names):
+                l = self.L[n]
+                arr_l[i].w, arr_l[i].b, arr_l[i].K, arr_l[i].cin, arr_l[i].cout = l.w.data_ptr(), l.b.data_ptr(), l.K, l.cin, l.cout
+            ctx = ctypes.c_void_p()
+            _lib.check(self.lib.insmos_ctx_create(ctypes.byref(cfgs), arr_n, arr_l, len(names), ctypes.byref(ctx)),
+                       "insmos_ctx_create")
+            self._ctx_box[0] = ctx
+        return self._ctx_box[0]
+
+    def _forward_native(self, pts):
+        if not self.const_input:
+            raise NotImplementedError("the native runner implements the constant-input first layer only")
+        ctx = self._native_ctx()
+        N = int(pts.shape[0])
+        if self._arena is None:
+            self._arena = torch.empty(640 * N + (192 << 20), dtype=torch.uint8, device=self.device)
+        out = _lib.ForwardOut()
+        for _ in range(12):
+            rc = self.lib.insmos_forward_window(ctx, pts.data_ptr(), N, pts.stride(0), self._arena.data_ptr(),
+                                                self._arena.numel(), self._stream(), ctypes.byref(out))
+            if rc != -3:  # INSMOS_EWORKSPACE: grow the arena and retry
+                break
+            self._arena = None
+            self._arena = torch.empty(max(int(out.arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
+        if rc == -1 and out.n_out_of_window:
+            raise ValueError(f"{int(out.n_out_of_window)} points fall outside the +-32768-voxel key window")
+        if rc == -1 and out.n_cur == 0 and out.me_voxels[0] > 0:
+            raise ValueError("window has no current-scan points (t == 0)")
+        _lib.check(rc, "insmos_forward_window")
+        ncur, K = int(out.n_cur), int(out.n_boxes)
+        self.last_counts = {"me_voxels": [int(v) for v in out.me_voxels], "n_cur": ncur,
+                            "unet_voxels": [int(v) for v in out.unet_voxels], "n_boxes": K,
+                            "n_candidates": int(out.n_candidates)}
+        a = self._arena
+
+        def view(off, count, dtype, shape):
+            nb = count * torch.empty((), dtype=dtype).element_size()
+            return a[off:off + nb].view(dtype).reshape(shape).clone()  # the arena is rewritten by the next window
+
+        logits = view(out.logits_off, ncur * 3, torch.float32, (ncur, 3))
+        pred = {"pred_boxes": view(out.boxes_off, K * 7, torch.float32, (K, 7)),
+                "pred_scores": view(out.scores_off, K, torch.float32, (K,)),
+                "pred_labels": view(out.labels_off, K, torch.int64, (K,))}
+        return logits, pred
+
+    def clone_shared(self):
+        """A second runner over the SAME device weights, tables and native context, with its own arena/workspace --
+        one per window in flight (InsMOS_Model.forward with several batch items)."""
+        import copy
+        e = copy.copy(self)
+        e._ws, e._arena, e._conv_log, e.last_counts, e.layer_timing = None, None, [], {}, None
+        return e
 
     def algorithmic_work(self):
         """Algorithmic work of the LAST forward_window over all sparse_conv launches:

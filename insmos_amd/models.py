@@ -3,7 +3,7 @@
 `InsMOSNet` mirrors the Lightning wrapper the reference's driver uses (models/models.py:27-59,
 scripts/predict_mos.py:326-328,405-407,434): `InsMOSNet.load_from_checkpoint(ckpt, hparams=cfg)`,
 `.cuda()`, `.eval()`, `.forward(list_of_dicts, 'test')`.  `InsMOS_Model` mirrors
-models/models.py:269-376: batch items are processed one after another and three lists are returned:
+models/models.py:269-376: three lists are returned (batch items may be in flight concurrently, see the class):
 `(pred_dicts_list, recall_dicts_list, point_logits_list)` with
   pred_dicts_list[i][0] = {"pred_boxes" (K,7) fp32, "pred_scores" (K,) fp32, "pred_labels" (K,) int64}
   recall_dicts_list[i]  = {}           (no gt_boxes on the test path, post_process.py:68-69)
@@ -13,6 +13,7 @@ the training harness, which are out of scope.  No pytorch_lightning is needed: a
 torch-pickled dict with "hyper_parameters" and "state_dict" (models/models.py:30,52).
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import yaml
@@ -36,31 +37,80 @@ def load_semantic_config(cfg):
 
 
 class InsMOS_Model:
-    """models/models.py:269-376 (test mode)."""
+    """models/models.py:269-376 (test mode).
 
-    def __init__(self, cfg, n_mos_classes, ignore_index, state_dict, device="cuda:0", quirk_exact=True):
+    The reference walks the batch list sequentially (models/models.py:313).  Here up to `windows_in_flight` batch items
+    are processed concurrently -- one host thread, HIP stream and arena each, all sharing the device weights -- because
+    one window leaves a large part of an MI355X idle (few tiles per SIMD in the deep layers, count read-backs).  The
+    results are the same bits as the sequential walk; the caller's current stream waits for all of them."""
+
+    def __init__(self, cfg, n_mos_classes, ignore_index, state_dict, device="cuda:0", quirk_exact=True,
+                 windows_in_flight=None):
         self.cfg = cfg
         self.mos_class = n_mos_classes
         self.ignore_index = ignore_index
         self.state_dict_ref = state_dict
         self.device = device
         self.quirk_exact = quirk_exact
+        if windows_in_flight is None:
+            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "4"))
+        self.windows_in_flight = max(1, int(windows_in_flight))
         self._engine = None
+        self._workers = None  # (engines, streams, executor)
 
     @property
     def engine(self):
         if self._engine is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("insmos_amd needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
-            self._engine = Engine(self.cfg, self.state_dict_ref, self.device, quirk_exact=self.quirk_exact)
+            self._engine = Engine(self.cfg, self.state_dict_ref, self.device, quirk_exact=self.quirk_exact, native=True)
+            self._drop_workers()
         return self._engine
+
+    def _drop_workers(self):
+        if self._workers is not None:
+            self._workers[2].shutdown(wait=True)
+            self._workers = None
+
+    def _get_workers(self, w):
+        eng = self.engine
+        if self._workers is None or len(self._workers[0]) < w or self._workers[3] is not eng.L:
+            self._drop_workers()
+            dev = torch.device(self.device)
+            engines = [eng] + [eng.clone_shared() for _ in range(w - 1)]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(w)]
+            self._workers = (engines, streams, ThreadPoolExecutor(max_workers=w, thread_name_prefix="insmos-window"), eng.L)
+        return self._workers[:3]
 
     def forward(self, list_batch_dict, Model_mode):
         if Model_mode != "test":
             raise NotImplementedError("insmos_amd implements the inference path: Model_mode == 'test'")
+        n = len(list_batch_dict)
+        w = min(n, self.windows_in_flight)
+        if w <= 1:
+            results = [self.engine.forward_window(b["past_point_clouds"]) for b in list_batch_dict]
+        else:
+            engines, streams, pool = self._get_workers(w)
+            dev = torch.device(self.device)
+            cur = torch.cuda.current_stream(dev)
+            results = [None] * n
+
+            def run(wi):
+                torch.cuda.set_device(dev)  # device and current stream are per host thread
+                streams[wi].wait_stream(cur)  # the inputs were produced on the caller's stream
+                with torch.cuda.stream(streams[wi]):
+                    for i in range(wi, n, w):
+                        results[i] = engines[wi].forward_window(list_batch_dict[i]["past_point_clouds"])
+
+            for f in [pool.submit(run, wi) for wi in range(w)]:
+                f.result()  # re-raises worker exceptions
+            for st in streams[:w]:
+                cur.wait_stream(st)
+            for logits, pred in results:
+                for t in (logits, *pred.values()):
+                    t.record_stream(cur)  # allocated on a worker stream, consumed on the caller's
         preb_dict_list, recall_dict_list, preb_mos_lable_list = [], [], []
-        for batch_dict in list_batch_dict:  # sequential, as models/models.py:313
-            logits, pred = self.engine.forward_window(batch_dict["past_point_clouds"])
+        for logits, pred in results:
             preb_dict_list.append([pred])
             recall_dict_list.append({})
             preb_mos_lable_list.append(logits)
@@ -104,6 +154,7 @@ class InsMOSNet:
             self._device = f"cuda:{device}" if isinstance(device, int) else str(device)
             self.model.device = self._device
             self.model._engine = None
+            self.model._drop_workers()
         _ = self.model.engine  # build now: weights are packed and uploaded once
         return self
 

@@ -45,6 +45,13 @@ def test_forward_signature_and_parity(setup):
     logits = logits_list[0].cpu().numpy()
     ref_logits, ref_pred, dbg = setup["ref_logits"], setup["ref_pred"], setup["dbg"]
     eng = model.model.engine
+    # --- the product path is the native runner (csrc/forward.hip); the step-by-step Python path keeps the
+    # intermediates for the stage checks below and must give the same bits
+    assert eng.native
+    logits_step, pred_step = eng.forward_window(batch[0]["past_point_clouds"], native=False)
+    assert torch.equal(logits_step, logits_list[0])
+    for k in pred:
+        assert torch.equal(pred_step[k], pred[k]), k
     # --- stage checks (sharper diagnostics than the end result)
     cur_ref = dbg["current_point"]
     assert logits.shape == ref_logits.shape == (len(cur_ref), 3)
@@ -92,6 +99,23 @@ def test_idempotent_and_batch_of_two(setup):
     assert torch.equal(a[0][0]["pred_boxes"], a[1][0]["pred_boxes"])
 
 
+def test_windows_in_flight_match_sequential(setup):
+    """A list of different windows processed concurrently (threads + streams + arenas) == one at a time, bit for bit,
+    in list order; the caller's stream sees finished results."""
+    from insmos_amd.synth import make_window
+    model = setup["model"]
+    wins = [torch.from_numpy(make_window(seed=20 + i, n_scans=4 + i, n_az=160 + 32 * i)).cuda() for i in range(5)]
+    assert model.model.windows_in_flight >= 2
+    for _ in range(2):  # second round re-uses the worker arenas
+        pl, _, ll = model.forward([{"past_point_clouds": w} for w in wins], "test")
+        got = [(l.clone(), {k: v.clone() for k, v in p[0].items()}) for l, p in zip(ll, pl)]
+    for w, (lg, pr) in zip(wins, got):
+        p1, _, l1 = model.forward([{"past_point_clouds": w}], "test")
+        assert torch.equal(l1[0], lg)
+        for k in pr:
+            assert torch.equal(p1[0][0][k], pr[k]), k
+
+
 def test_n1_window_and_no_detection_checkpoint(setup):
     """cfg-1 shape: a single scan (N=1, t==0 only) and the default head bias (no detections)."""
     from insmos_amd import params as P
@@ -133,3 +157,6 @@ def test_dense_stress_config_voxel_005():
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, atol=1e-3, rtol=0)
     np.testing.assert_array_equal(R.output_stage(logits.cpu().numpy())[0], R.output_stage(ref_logits)[0])
     assert pred["pred_boxes"].shape[0] == len(ref_pred["pred_boxes"])
+    logits_n, pred_n = eng.forward_window(torch.from_numpy(w).cuda(), native=True)  # same bits through the native runner
+    assert torch.equal(logits_n, logits) and torch.equal(pred_n["pred_boxes"], pred["pred_boxes"])
+    assert eng.last_counts["unet_voxels"][0] == cap
