@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-az", type=int, default=472)
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
-    ap.add_argument("--windows-per-step", type=int, default=4, help="batch items of one forward() = one step")
+    ap.add_argument("--windows-per-step", type=int, default=6, help="batch items of one forward() = one step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -98,6 +98,10 @@ def load():
             raise InsmosHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  insmos_amd has no CPU fallback.")
+        # torch first: its bundled HIP runtime must be the one in the process' global symbol scope before this library
+        # is mapped, so that both talk to the SAME runtime (streams and device pointers cross the boundary).  Loading
+        # libinsmos_hip.so before torch binds it to /opt/rocm's runtime instead and every launch fails (hipErrorNoDevice).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -17,6 +17,13 @@ extern int g_last_hip_error;
             return INSMOS_EHIP;                         \
         }                                               \
     } while (0)
+// hipGetLastError() is sticky per host thread: a benign failure inside ANOTHER library's HIP call (e.g. torch probing a
+// pointer or counting devices) would otherwise surface at our next launch check.  Clear it right before launching.
+#define INSMOS_LAUNCH(...)                \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
 
 // ---- per-kernel profiler (HIP events on the launch stream) ----------------------------------------
 enum KernelKind : int {

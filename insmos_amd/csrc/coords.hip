@@ -524,27 +524,27 @@ extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, con
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_QUANT_KEYS, s);
-        hipLaunchKernelGGL(k_quant_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+        INSMOS_LAUNCH(k_quant_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
                            quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
     }
     int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, 64, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
-        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
+        INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
     }
     rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
-        hipLaunchKernelGGL(k_quant_scatter, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
+        INSMOS_LAUNCH(k_quant_scatter, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
                            counts);
     }
     rc = inclusive_scan_i32(tmp, sc, tflag, tscan, N, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
-        hipLaunchKernelGGL(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
+        INSMOS_LAUNCH(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -568,14 +568,14 @@ extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, u
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_LEVEL_DOWN, s);
-        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, keys, n, 3 * shift, flag);
+        INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, keys, n, 3 * shift, flag);
     }
     int rc = inclusive_scan_i32(tmp, sc, flag, scan, (size_t)n, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_LEVEL_DOWN, s);
         if (child_mask) HIP_TRY(hipMemsetAsync(child_mask, 0, (size_t)n * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
+        INSMOS_LAUNCH(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
                            out_coords, parent, child_start, child_mask, counts);
     }
     HIP_TRY(hipGetLastError());
@@ -604,10 +604,10 @@ extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const 
     ProfScope ps(KK_BUILD_NBR, s);
     if (mask16) HIP_TRY(hipMemsetAsync(mask16, 0, (size_t)((n_out + 15) / 16) * 4 * sizeof(uint32_t), s));
     if (key_mode == 0)
-        hipLaunchKernelGGL(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
+        INSMOS_LAUNCH(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
                            mask16);
     else
-        hipLaunchKernelGGL(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
+        INSMOS_LAUNCH(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
                            mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -651,7 +651,7 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_VOX_KEYS, s);
-        hipLaunchKernelGGL(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, range_host[0], range_host[1],
+        INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, range_host[0], range_host[1],
                            range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1], g3[2], k_in,
                            pc_voxel_id, mark, counts);
     }
@@ -660,19 +660,19 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_SEGMENTS, s);
-        hipLaunchKernelGGL(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, VOX_IDX_BITS, flag);
+        INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, VOX_IDX_BITS, flag);
     }
     rc = inclusive_scan_i32(tmp, sc, flag, sid_scan, N, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_SEGMENTS, s);
-        hipLaunchKernelGGL(k_vox_heads, dim3(g), dim3(TPB), 0, s, k_s, flag, sid_scan, n, seg_start, seg_first, mark);
+        INSMOS_LAUNCH(k_vox_heads, dim3(g), dim3(TPB), 0, s, k_s, flag, sid_scan, n, seg_start, seg_first, mark);
     }
     rc = inclusive_scan_i32(tmp, sc, mark, rank_scan, N, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_MEAN, s);
-        hipLaunchKernelGGL(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
+        INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
                            seg_first, rank_scan, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords, num_points,
                            pc_voxel_id, ukeys, uperm, counts);
     }
@@ -712,14 +712,14 @@ extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, cons
     {
         ProfScope ps(KK_DOWN_CAND, s);
         HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, s));
-        hipLaunchKernelGGL(k_down_mark, dim3(cdiv(N, TPB)), dim3(TPB), 0, s, in_coords, n_in, K, P, bitmap);
-        hipLaunchKernelGGL(k_word_popc, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, nwords, cnt);
+        INSMOS_LAUNCH(k_down_mark, dim3(cdiv(N, TPB)), dim3(TPB), 0, s, in_coords, n_in, K, P, bitmap);
+        INSMOS_LAUNCH(k_word_popc, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, nwords, cnt);
     }
     int rc = inclusive_scan_i32(tmp, sc, cnt, scan, (size_t)nwords, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_DOWN_UNIQUE, s);
-        hipLaunchKernelGGL(k_down_expand, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, scan, nwords, P.oshape[1],
+        INSMOS_LAUNCH(k_down_expand, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, scan, nwords, P.oshape[1],
                            P.oshape[2], cap, out_keys, out_coords, counts);
     }
     HIP_TRY(hipGetLastError());
@@ -741,7 +741,7 @@ extern "C" int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, c
     T.K = K;
     ProfScope ps(KK_BUILD_NBR, s);
     if (mask16) HIP_TRY(hipMemsetAsync(mask16, 0, (size_t)((n_f + 15) / 16) * 4 * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_nbr_from_coarse, dim3(cdiv(n_f, TPB), (unsigned)K), dim3(TPB), 0, s, fine_coords, n_f, parent,
+    INSMOS_LAUNCH(k_nbr_from_coarse, dim3(cdiv(n_f, TPB), (unsigned)K), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, T, nbr, mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -755,8 +755,8 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
     ProfScope ps(KK_BUILD_NBR, s);
     if (dn_mask16) HIP_TRY(hipMemsetAsync(dn_mask16, 0, (size_t)((n_c + 15) / 16) * 4 * sizeof(uint32_t), s));
     if (up_mask16) HIP_TRY(hipMemsetAsync(up_mask16, 0, (size_t)((n_f + 15) / 16) * 4 * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_nbr_down, dim3(cdiv(n_c, TPB), 8), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
-    hipLaunchKernelGGL(k_nbr_up, dim3(cdiv(n_f, TPB), 8), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
+    INSMOS_LAUNCH(k_nbr_down, dim3(cdiv(n_c, TPB), 8), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
+    INSMOS_LAUNCH(k_nbr_up, dim3(cdiv(n_f, TPB), 8), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
                        up_mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -770,7 +770,7 @@ extern "C" int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f,
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_BUILD_NBR, s);
-    hipLaunchKernelGGL((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+    INSMOS_LAUNCH((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, 0, 0);
     HIP_TRY(hipGetLastError());
@@ -787,7 +787,7 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_SPARSE_CONV, s);
-    hipLaunchKernelGGL((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+    INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
                        w125x8, bias8, out, ld_out, relu);
     HIP_TRY(hipGetLastError());

@@ -429,14 +429,14 @@ extern "C" int insmos_center_decode_select(const float* head, int ld_head, int n
     HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
     {
         ProfScope ps(KK_DECODE, s);
-        hipLaunchKernelGGL(k_score_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, head, ld_head, ncls, n, W, up, score_thresh,
+        INSMOS_LAUNCH(k_score_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, head, ld_head, ncls, n, W, up, score_thresh,
                            keys, vals, counts);
     }
     int rc = sort_pairs_u64_u32(tmp, st, keys, keys_s, vals, vals_s, (size_t)n, 0, 64, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_SELECT, s);
-        hipLaunchKernelGGL(k_select_decode, dim3(cdiv(pre_max, 256)), dim3(256), 0, s, head, ld_head, ncls, W, up,
+        INSMOS_LAUNCH(k_select_decode, dim3(cdiv(pre_max, 256)), dim3(256), 0, s, head, ld_head, ncls, W, up,
                            out_factor, vx, vy, x0, y0, keys_s, vals_s, n, pre_max, cand_boxes, cand_scores, cand_labels,
                            cand_cell, counts);
     }
@@ -459,11 +459,11 @@ extern "C" int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, 
     if (!b.ok) return INSMOS_EWORKSPACE;
     {
         ProfScope ps(KK_NMS_MASK, s);
-        hipLaunchKernelGGL(k_nms_mask, dim3(cbs, cbs), dim3(256), 0, s, boxes, n_dev, max_n, thresh, mask);
+        INSMOS_LAUNCH(k_nms_mask, dim3(cbs, cbs), dim3(256), 0, s, boxes, n_dev, max_n, thresh, mask);
     }
     {
         ProfScope ps(KK_NMS_REDUCE, s);
-        hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(64), 0, s, mask, n_dev, max_n, post_max, keep, counts);
+        INSMOS_LAUNCH(k_nms_reduce, dim3(1), dim3(64), 0, s, mask, n_dev, max_n, post_max, keep, counts);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -473,7 +473,7 @@ extern "C" int insmos_iou_bev(const float* a, int na, const float* b, int nb, fl
     if (na <= 0 || nb <= 0) return INSMOS_OK;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_IOU, s);
-    hipLaunchKernelGGL(k_iou_bev, dim3(cdiv((int64_t)na * nb, 128)), dim3(128), 0, s, a, na, b, nb, out);
+    INSMOS_LAUNCH(k_iou_bev, dim3(cdiv((int64_t)na * nb, 128)), dim3(128), 0, s, a, na, b, nb, out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -483,7 +483,7 @@ extern "C" int insmos_gather_preds(const float* cand_boxes, const float* cand_sc
                                    float* pred_scores, int64_t* pred_labels, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_GATHER_PREDS, s);
-    hipLaunchKernelGGL(k_gather_preds, dim3(cdiv(post_max, 256)), dim3(256), 0, s, cand_boxes, cand_scores, cand_labels,
+    INSMOS_LAUNCH(k_gather_preds, dim3(cdiv(post_max, 256)), dim3(256), 0, s, cand_boxes, cand_scores, cand_labels,
                        keep, n_keep_dev, post_max, pred_boxes, pred_scores, pred_labels);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -510,14 +510,14 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     uint32_t* vbits = (uint32_t*)(scratch + 20 * (size_t)max_boxes);
     ProfScope ps(KK_ONEHOT, s);
     HIP_TRY(hipMemsetAsync(vbits, 0, (size_t)n * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_onehot_boxes, dim3(cdiv(max_boxes, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
+    INSMOS_LAUNCH(k_onehot_boxes, dim3(cdiv(max_boxes, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
                        max_boxes, P, first, bv);
     dim3 grid(cdiv(n, 256), cdiv(max_boxes, 64));
-    hipLaunchKernelGGL(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
+    INSMOS_LAUNCH(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
                        quirk_exact, vbits);
-    hipLaunchKernelGGL(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
+    INSMOS_LAUNCH(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
                        quirk_exact, vbits);
-    hipLaunchKernelGGL(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
+    INSMOS_LAUNCH(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -107,7 +107,7 @@ extern "C" int insmos_gather_rows(const float* src, int ld_src, int c, const int
     if (!src || !idx || !out || c <= 0) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_GATHER_ROWS, s);
-    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(n * c, 256)), dim3(256), 0, s, src, ld_src, c, idx, n, out, ld_out);
+    INSMOS_LAUNCH(k_gather_rows, dim3(cdiv(n * c, 256)), dim3(256), 0, s, src, ld_src, c, idx, n, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -120,7 +120,7 @@ extern "C" int insmos_build_current_points(const float* points, int ld_pts, cons
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_CUR_POINTS, s);
-    hipLaunchKernelGGL(k_current_points, dim3(cdiv(n_cur, 256)), dim3(256), 0, s, points, ld_pts, motion, ld_motion,
+    INSMOS_LAUNCH(k_current_points, dim3(cdiv(n_cur, 256)), dim3(256), 0, s, points, ld_pts, motion, ld_motion,
                        inverse, cur_index, n_cur, cur, ld_cur);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -130,7 +130,7 @@ extern "C" int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, fl
     if (n <= 0 || c <= 0) return INSMOS_OK;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_FILL, s);
-    hipLaunchKernelGGL(k_fill_cols, dim3(cdiv(n * c, 256)), dim3(256), 0, s, dst, n, ld, c0, c, value);
+    INSMOS_LAUNCH(k_fill_cols, dim3(cdiv(n * c, 256)), dim3(256), 0, s, dst, n, ld, c0, c, value);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -143,7 +143,7 @@ extern "C" int insmos_confusion3(const float* logits, int ld, const int64_t* gt,
     ProfScope ps(KK_CONFUSION, s);
     unsigned g = cdiv(n, 256);
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_confusion, dim3(g), dim3(256), 0, s, logits, ld, gt, n, ncls, ignore_mask,
+    INSMOS_LAUNCH(k_confusion, dim3(g), dim3(256), 0, s, logits, ld, gt, n, ncls, ignore_mask,
                        (unsigned long long*)cm);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -157,7 +157,7 @@ extern "C" int insmos_stack_scan(const float* scan, int64_t n, const double* T_h
     Mat34d T;
     for (int i = 0; i < 12; ++i) T.m[i] = T_host[i];
     ProfScope ps(KK_CUR_POINTS, s);
-    hipLaunchKernelGGL(k_stack_scan, dim3(cdiv(n, 256)), dim3(256), 0, s, scan, n, T, t, out, ld_out);
+    INSMOS_LAUNCH(k_stack_scan, dim3(cdiv(n, 256)), dim3(256), 0, s, scan, n, T, t, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -168,7 +168,7 @@ extern "C" int insmos_output_stage(const float* logits, int ld, int64_t n, int n
     if (!logits || !lut || !labels || !confidence || ncls < 2 || ncls > 8) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_GATHER_ROWS, s);
-    hipLaunchKernelGGL(k_output_stage, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, ld, n, ncls, ignore_mask, lut, labels,
+    INSMOS_LAUNCH(k_output_stage, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, ld, n, ncls, ignore_mask, lut, labels,
                        confidence);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;

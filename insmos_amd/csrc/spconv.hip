@@ -594,7 +594,7 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     const long nblocks = split == 1 ? tiles : (tiles + (4 / split) - 1) / (4 / split);
     dim3 grid((unsigned)nblocks), block(64 * wpb);
     ProfScope ps(KK_SPARSE_CONV, s);
-    hipLaunchKernelGGL(kern, grid, block, 0, s, P);
+    INSMOS_LAUNCH(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -610,7 +610,7 @@ extern "C" int insmos_dense_nbr2d(int H, int W, int32_t* nbr, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_DENSE_NBR, s);
     int64_t n = (int64_t)H * W * 9;
-    hipLaunchKernelGGL(k_dense_nbr2d, dim3(cdiv(n, 256)), dim3(256), 0, s, H, W, nbr);
+    INSMOS_LAUNCH(k_dense_nbr2d, dim3(cdiv(n, 256)), dim3(256), 0, s, H, W, nbr);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -625,7 +625,7 @@ extern "C" int insmos_sparse_to_bev(const float* feat, int ld_feat, int C, const
     }
     if (n > 0) {
         ProfScope ps(KK_TO_BEV, s);
-        hipLaunchKernelGGL(k_sparse_to_bev, dim3(cdiv(n * C, 256)), dim3(256), 0, s, feat, ld_feat, C, coords, n, D, H, W,
+        INSMOS_LAUNCH(k_sparse_to_bev, dim3(cdiv(n * C, 256)), dim3(256), 0, s, feat, ld_feat, C, coords, n, D, H, W,
                            bev);
     }
     HIP_TRY(hipGetLastError());

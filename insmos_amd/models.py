@@ -53,7 +53,7 @@ class InsMOS_Model:
         self.device = device
         self.quirk_exact = quirk_exact
         if windows_in_flight is None:
-            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "4"))
+            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "3"))
         self.windows_in_flight = max(1, int(windows_in_flight))
         self._engine = None
         self._workers = None  # (engines, streams, executor)
