@@ -21,7 +21,10 @@ def _rand_nbr(rng, K, n_out, n_in, density):
     (8, 8, 81, 1000, 0.2), (1, 8, 125, 777, 0.15), (16, 8, 81, 513, 0.2), (24, 16, 81, 300, 0.3),
     (48, 32, 81, 260, 0.3), (32, 32, 8, 4000, 0.13), (7, 16, 27, 2000, 0.3), (131, 128, 27, 500, 0.4),
     (67, 64, 27, 300, 0.4), (35, 32, 27, 300, 0.4), (19, 16, 27, 129, 0.4), (256, 128, 27, 200, 0.5),
-    (128, 128, 3, 64, 0.7), (16, 3, 1, 1000, 1.0), (8, 3, 1, 70, 1.0), (64, 64, 27, 70000, 0.25)])
+    (128, 128, 3, 64, 0.7), (16, 3, 1, 1000, 1.0), (8, 3, 1, 70, 1.0), (64, 64, 27, 70000, 0.25),
+    # >= 2048 row groups, one or two channel tiles: the weights-in-LDS variant
+    (8, 8, 81, 40000, 0.2), (16, 8, 81, 36000, 0.2), (16, 16, 27, 40000, 0.3), (8, 16, 27, 33000, 0.3),
+    (32, 16, 27, 34000, 0.3), (16, 32, 27, 35011, 0.3), (8, 8, 8, 33000, 0.13)])
 def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
     from gpu_util import dev, pack_layer, run_conv
     rng = np.random.default_rng(cin * 1000 + cout)
