@@ -290,6 +290,26 @@ int insmos_confusion3(const float* logits, int ld, const int64_t* gt, int64_t n,
                       int64_t* cm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Refine stage (scripts/refine.py:167-302), the step after the forward in the published pipeline.
+ * insmos_points_in_instance_boxes -- Array_Index.find_point_in_instance_bbox_with_yaw (models/utils/src/
+ *   Array_Index.cpp:85-154, called at refine.py:196): points (n, ld >= 3) fp32 xyz, boxes (m, 7) fp32, labels (m) i64,
+ *   all device; index (n, ncls) i32 out: index[j][c-1] = 1-based number of the class-c box containing point j (0 =
+ *   none).  Box z is lifted by ground_offset; quirk_exact = 1 reproduces the order-dependent early skip (:124-127).
+ *   Where two boxes of one class share a point the reference's OpenMP loop races; here the larger box number wins
+ *   (= the sequential walk).  scratch: 20*m i32.
+ * insmos_instance_stats -- per instance of class column `col`: {points, points labelled 2 (moving), points with
+ *   confidence[:,1] >= 1e-5} (refine.py:210-217); mos (n) i32 in {0,1,2}; conf (n,2) fp32 or null; stats (m,3) i32 out.
+ * insmos_instance_relabel -- mos[j] = decision[id-1] for points of instance id with decision > 0 (refine.py:243-285).
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_points_in_instance_boxes(const float* points, int64_t n, int ld_pts, const float* boxes,
+                                    const int64_t* labels, int m, float ground_offset, int ncls, int quirk_exact,
+                                    int32_t* index, int32_t* scratch, void* stream);
+int insmos_instance_stats(const int32_t* index, int ncls, int col, const int32_t* mos, const float* conf, int64_t n,
+                          int m, int32_t* stats, void* stream);
+int insmos_instance_relabel(const int32_t* index, int ncls, int col, const int32_t* decision, int64_t n, int m,
+                            int32_t* mos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native window runner -- InsMOS_Model.forward(list, 'test') for ONE batch item (models/models.py:313-364) as one
  * foreign call: the same operator sequence insmos_amd/engine.py issues step by step (MotionNet -> voxelise ->
  * UNetV2 encoder -> BEV CenterHead -> NMS -> instance-fused decoder -> per-point logits), driven from C++ so that

@@ -56,6 +56,9 @@ SIGNATURES = {
     "insmos_stack_scan": (c_int, [c_vp, c_i64, c_vp, c_f32, c_vp, c_int, c_vp]),
     "insmos_output_stage": (c_int, [c_vp, c_int, c_i64, c_int, c_u32, c_vp, c_vp, c_vp, c_vp]),
     "insmos_confusion3": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp]),
+    "insmos_points_in_instance_boxes": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_int, c_int, c_vp, c_vp, c_vp]),
+    "insmos_instance_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "insmos_instance_relabel": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "insmos_ctx_create": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "insmos_ctx_destroy": (c_int, [c_vp]),
     "insmos_forward_window": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp]),

@@ -399,6 +399,102 @@ __global__ void k_onehot_write(const uint32_t* __restrict__ vbits, int64_t n, in
     out[j * ld_out + c] = (c < ncls && ((vbits[j] >> c) & 1u)) ? 1.0f : 0.0f;
 }
 
+
+// ---- refine stage (scripts/refine.py:196): point -> instance id, Array_Index.cpp:85-154 -------------------------
+__device__ __forceinline__ bool inside_box_pt(const BoxVox& b, float x, float y, float z) {
+    float c0 = x - b.c[0], c1 = y - b.c[1], c2 = z - b.c[2];
+    if (fabsf(c0) > b.rad || fabsf(c1) > b.rad || fabsf(c2) > b.h[2] + 1e-3f) return false;  // can only reject true misses
+    float r0 = c0 * b.cs + c1 * b.sn;
+    float r1 = -c0 * b.sn + c1 * b.cs;
+    return (r0 <= b.h[0]) && (r0 >= -b.h[0]) && (r1 <= b.h[1]) && (r1 >= -b.h[1]) && (c2 <= b.h[2]) && (c2 >= -b.h[2]);
+}
+
+__global__ void k_inst_boxes(const float* __restrict__ boxes, const int64_t* __restrict__ labels, int m, float ground,
+                             int32_t* __restrict__ first, BoxVox* __restrict__ bv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= m) return;
+    first[b] = 0x7fffffff;
+    BoxVox sb;
+    const float* bx = boxes + (int64_t)b * 7;
+    sb.c[0] = bx[0]; sb.c[1] = bx[1]; sb.c[2] = bx[2] + ground;  // Array_Index.cpp:108
+    for (int d = 0; d < 3; ++d) { sb.e[d] = bx[3 + d]; sb.h[d] = sb.e[d] / 2; }
+    const double th = (double)bx[6];
+    sb.cs = (float)cos(th);
+    sb.sn = (float)sin(th);
+    sb.label = (int)(float)labels[b];  // refine.py:184 carries the label as a float column
+    sb.rad = sqrtf(sb.h[0] * sb.h[0] + sb.h[1] * sb.h[1]) * 1.001f + 1e-3f;
+    sb.pad[0] = sb.pad[1] = sb.pad[2] = 0.f;
+    bv[b] = sb;
+}
+
+// grid (point blocks, box chunks of 64).  PASS 0: first inside point per box (atomicMin over the point index).
+// PASS 1: index[j][label-1] = max over boxes containing j of (box + 1) -- the sequential walk's "last writer".
+template <int PASS>
+__global__ void __launch_bounds__(256) k_inst_scan(int m, const float* __restrict__ pts, int ld, int64_t n,
+                                                   int32_t* __restrict__ first, const BoxVox* __restrict__ bv, int ncls,
+                                                   int quirk, int32_t* __restrict__ index) {
+    const int b0 = blockIdx.y * 64;
+    if (b0 >= m) return;
+    const int nb = min(64, m - b0);
+    __shared__ BoxVox sb[64];
+    __shared__ int sfirst[64];
+    __shared__ float sfx[64], sfy[64], sfz[64];
+    if ((int)threadIdx.x < nb) {
+        sb[threadIdx.x] = bv[b0 + threadIdx.x];
+        if (PASS == 1) {
+            const int f = first[b0 + threadIdx.x];
+            sfirst[threadIdx.x] = f;
+            if (f != 0x7fffffff) {
+                const float* q = pts + (int64_t)f * ld;
+                sfx[threadIdx.x] = q[0]; sfy[threadIdx.x] = q[1]; sfz[threadIdx.x] = q[2];
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float x = pts[j * ld], y = pts[j * ld + 1], z = pts[j * ld + 2];
+    for (int i = 0; i < nb; ++i) {
+        const BoxVox& bb = sb[i];
+        if (PASS == 0) {
+            if (inside_box_pt(bb, x, y, z)) atomicMin(&first[b0 + i], (int)j);
+        } else {
+            const int f = sfirst[i];
+            if (f == 0x7fffffff) continue;
+            if (quirk && j != f) {
+                if (j < f) continue;  // rows before the first hit are not inside by definition
+                if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
+                    z > (sfz[i] + bb.e[2]) || z < (sfz[i] - bb.e[2]))
+                    continue;
+            }
+            if (bb.label > 0 && bb.label <= ncls && inside_box_pt(bb, x, y, z))
+                atomicMax(&index[j * ncls + bb.label - 1], b0 + i + 1);
+        }
+    }
+}
+
+// per-instance point statistics of one class column (refine.py:210-217) and the relabel pass (refine.py:243-285)
+__global__ void k_inst_stats(const int32_t* __restrict__ index, int ncls, int col, const int32_t* __restrict__ mos,
+                             const float* __restrict__ conf, int64_t n, int m, int32_t* __restrict__ stats) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int id = index[j * ncls + col];
+    if (id <= 0 || id > m) return;
+    atomicAdd(&stats[(id - 1) * 3 + 0], 1);
+    if (mos[j] == 2) atomicAdd(&stats[(id - 1) * 3 + 1], 1);
+    if (conf && conf[j * 2 + 1] >= 0.00001f) atomicAdd(&stats[(id - 1) * 3 + 2], 1);
+}
+
+__global__ void k_inst_relabel(const int32_t* __restrict__ index, int ncls, int col, const int32_t* __restrict__ decision,
+                               int64_t n, int m, int32_t* __restrict__ mos) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int id = index[j * ncls + col];
+    if (id <= 0 || id > m) return;
+    const int d = decision[id - 1];
+    if (d > 0) mos[j] = d;
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -518,6 +614,47 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     INSMOS_LAUNCH(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
                        quirk_exact, vbits);
     INSMOS_LAUNCH(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_points_in_instance_boxes(const float* points, int64_t n, int ld_pts, const float* boxes,
+                                               const int64_t* labels, int m, float ground_offset, int ncls,
+                                               int quirk_exact, int32_t* index, int32_t* scratch, void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!points || ld_pts < 3 || !index || ncls <= 0 || m < 0 || (m > 0 && (!boxes || !labels || !scratch)))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_ONEHOT, s);
+    HIP_TRY(hipMemsetAsync(index, 0, (size_t)n * ncls * sizeof(int32_t), s));
+    if (m == 0) return INSMOS_OK;
+    int32_t* first = scratch;
+    BoxVox* bv = (BoxVox*)(scratch + ((m + 3) & ~3));  // 16 ints per box
+    INSMOS_LAUNCH(k_inst_boxes, dim3(cdiv(m, 64)), dim3(64), 0, s, boxes, labels, m, ground_offset, first, bv);
+    dim3 grid((unsigned)cdiv(n, 256), (unsigned)cdiv(m, 64));
+    INSMOS_LAUNCH(k_inst_scan<0>, grid, dim3(256), 0, s, m, points, ld_pts, n, first, bv, ncls, quirk_exact, index);
+    INSMOS_LAUNCH(k_inst_scan<1>, grid, dim3(256), 0, s, m, points, ld_pts, n, first, bv, ncls, quirk_exact, index);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_instance_stats(const int32_t* index, int ncls, int col, const int32_t* mos, const float* conf,
+                                     int64_t n, int m, int32_t* stats, void* stream) {
+    if (m <= 0) return INSMOS_OK;
+    if (!index || !mos || !stats || col < 0 || col >= ncls) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(stats, 0, (size_t)m * 3 * sizeof(int32_t), s));
+    if (n > 0) INSMOS_LAUNCH(k_inst_stats, dim3(cdiv(n, 256)), dim3(256), 0, s, index, ncls, col, mos, conf, n, m, stats);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_instance_relabel(const int32_t* index, int ncls, int col, const int32_t* decision, int64_t n, int m,
+                                       int32_t* mos, void* stream) {
+    if (m <= 0 || n <= 0) return INSMOS_OK;
+    if (!index || !decision || !mos || col < 0 || col >= ncls) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    INSMOS_LAUNCH(k_inst_relabel, dim3(cdiv(n, 256)), dim3(256), 0, s, index, ncls, col, decision, n, m, mos);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -11,7 +11,8 @@ Same inputs and outputs as the reference:
     (predict_mos.py:421-461; stem = the 6 digits of the current scan's file name);
   * the first N-1 scans are predicted with shortened histories N' = 1 .. N-1 (predict_mos.py:308-383).
 What differs: scans are uploaded once and pose-aligned / stacked on the GPU (insmos_amd/data.py), the model is built
-once (the reference reloads the checkpoint for every warm-up length), the output stage runs on the device, and with
+once (the reference reloads the checkpoint for every warm-up length), the output stage runs on the device, windows go
+through forward() in groups the model keeps in flight concurrently, and with
 `torchrun --nproc-per-node N` the windows of a sequence are sharded over the ranks (window j -> rank j % N).
 """
 import argparse
@@ -74,22 +75,29 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
         jobs = jobs[:limit]
     readers = {n_full: full}
     done = 0
-    for idx in shard_indices(len(jobs), rank, world):
-        n_past, j = jobs[idx]
-        if n_past not in readers:
-            c2 = copy.deepcopy(cfg)
-            c2["MODEL"]["DELTA_T_PREDICTION"] = 0.1  # predict_mos.py:311
-            readers[n_past] = SequenceWindows(c2, seq_dir, n_past, device)
-        rd = readers[n_past]
-        if j >= len(rd):
+    mine = [jobs[idx] for idx in shard_indices(len(jobs), rank, world)]
+    group = max(1, int(getattr(model.model, "windows_in_flight", 1)))  # batch items the model keeps in flight
+    for g0 in range(0, len(mine), group):
+        batch, metas = [], []
+        for n_past, j in mine[g0:g0 + group]:
+            if n_past not in readers:
+                c2 = copy.deepcopy(cfg)
+                c2["MODEL"]["DELTA_T_PREDICTION"] = 0.1  # predict_mos.py:311
+                readers[n_past] = SequenceWindows(c2, seq_dir, n_past, device)
+            rd = readers[n_past]
+            if j >= len(rd):
+                continue
+            pts, meta = rd.window(j)
+            batch.append({"past_point_clouds": pts, "meta": meta, "batch_size_npast": n_past})
+            metas.append(meta)
+        if not batch:
             continue
-        pts, meta = rd.window(j)
-        pred_list, _, logits_list = model.forward([{"past_point_clouds": pts, "meta": meta, "batch_size_npast": n_past}],
-                                                  "test")
-        labels, conf = output_stage(logits_list[0], ignore_index, sem["learning_map_inv"])
-        stem = str(meta[2][-1])[-10:-4]
-        write_outputs(out_root, exp_id, seq, stem, labels, conf, pred_list[0][0])
-        done += 1
+        pred_list, _, logits_list = model.forward(batch, "test")
+        for meta, preds, logits in zip(metas, pred_list, logits_list):
+            labels, conf = output_stage(logits, ignore_index, sem["learning_map_inv"])
+            stem = str(meta[2][-1])[-10:-4]
+            write_outputs(out_root, exp_id, seq, stem, labels, conf, preds[0])
+            done += 1
     return done
 
 

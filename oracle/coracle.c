@@ -278,3 +278,40 @@ void co_boxes_to_onehot(const int32_t* coords, int64_t V, const float* boxes, in
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Array_Index.find_point_in_instance_bbox_with_yaw (models/utils/src/Array_Index.cpp:85-154), used by
+ * scripts/refine.py:196: points (N, ld >= 3) float xyz, boxes (M, 8) [x,y,z,dx,dy,dz,yaw,label]; a point inside box i
+ * gets index[j][label-1] = i+1.  Box z is lifted by `out_ground` (float add).  The same order-dependent early skip as
+ * find_features_by_bbox_with_yaw: once a box has a first inside point, later points farther than extend[d] from
+ * THAT POINT are skipped.  The reference walks the boxes in an OpenMP parallel-for (a write race when two boxes of
+ * one class share a point); restated sequentially, i.e. the LARGEST box index wins.
+ * ------------------------------------------------------------------------------------------ */
+void co_points_in_instance_boxes(const float* pts, int64_t N, int ld, const float* boxes, int M, int32_t* index, int C,
+                                 float out_ground, int quirk) {
+    for (int i = 0; i < M; ++i) {
+        const float* b = boxes + (int64_t)i * 8;
+        float center[3] = {b[0], b[1], b[2] + out_ground};
+        float extend[3] = {b[3], b[4], b[5]};
+        float theta = b[6];
+        float cos_t = (float)cos(theta), sin_t = (float)sin(theta);
+        int label = (int)b[7];
+        float first[3] = {0.f, 0.f, 0.f};
+        int have_first = 0;
+        for (int64_t j = 0; j < N; ++j) {
+            float x = pts[j * ld + 0], y = pts[j * ld + 1], z = pts[j * ld + 2];
+            if (quirk && have_first &&
+                (x > (first[0] + extend[0]) || x < (first[0] - extend[0]) || y > (first[1] + extend[1]) ||
+                 y < (first[1] - extend[1]) || z > (first[2] + extend[2]) || z < (first[2] - extend[2])))
+                continue;
+            float c0 = x - center[0], c1 = y - center[1], c2 = z - center[2];
+            float r0 = c0 * cos_t + c1 * sin_t;
+            float r1 = -c0 * sin_t + c1 * cos_t;
+            if ((r0 <= extend[0] / 2) && (r0 >= -extend[0] / 2) && (r1 <= extend[1] / 2) && (r1 >= -extend[1] / 2) &&
+                (c2 <= extend[2] / 2) && (c2 >= -extend[2] / 2)) {
+                if (label > 0 && label <= C) index[j * C + label - 1] = i + 1;
+                if (!have_first) { have_first = 1; first[0] = x; first[1] = y; first[2] = z; }
+            }
+        }
+    }
+}

@@ -47,6 +47,7 @@ def _lib():
         L.co_nms_bev.argtypes = [vp, i32, f32, vp]
         L.co_nms_bev.restype = i32
         L.co_boxes_to_onehot.argtypes = [vp, i64, vp, i32, vp, i32, i32]
+        L.co_points_in_instance_boxes.argtypes = [vp, i64, i32, vp, i32, vp, i32, f32, i32]
         L.co_num_threads.restype = i32
         _LIB = L
     return _LIB
@@ -415,6 +416,17 @@ def boxes_to_onehot(coords_xyz, boxes8, num_class, quirk=True):
     feat = np.zeros((len(c), num_class), dtype=np.int32)
     _lib().co_boxes_to_onehot(_p(c), len(c), _p(b), len(b), _p(feat), num_class, 1 if quirk else 0)
     return feat
+
+
+def points_in_instance_boxes(points, boxes8, num_class=3, out_ground=0.03, quirk=True):
+    """Array_Index.find_point_in_instance_bbox_with_yaw (Array_Index.cpp:85-154): (N, num_class) int32, the value is
+    the 1-based index of the box of that class containing the point (largest index wins, see coracle.c)."""
+    p = np.ascontiguousarray(points, dtype=np.float32)
+    b = np.ascontiguousarray(boxes8, dtype=np.float32).reshape(-1, 8)
+    idx = np.zeros((len(p), num_class), dtype=np.int32)
+    _lib().co_points_in_instance_boxes(_p(p), len(p), p.shape[1], _p(b), len(b), _p(idx), num_class,
+                                       ctypes.c_float(out_ground), 1 if quirk else 0)
+    return idx
 
 
 def confusion_matrix(logits, gt, n_classes=3, ignore_index=(0,)):

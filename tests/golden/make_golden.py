@@ -15,6 +15,9 @@ Sources exercised (all importable / compilable here):
                     iou3d_nms_cuda.nms_gpu stubbed by the compiled reference IoU + the greedy reduce
   height_compression.npz  models/backbones_2d/height_compression.py:24-31 view semantics (on a dense tensor)
   poses.npz         dataloader/utils.py:10-68 load_poses / load_calib / load_files on tiny hand-written files
+  refine.npz        scripts/refine.py:133-302 main() run as-is on a synthetic 12-frame sequence -> refined labels
+  instance_index.npz  models/utils/src/Array_Index.cpp:85-154 find_point_in_instance_bbox_with_yaw (compiled), the
+                    point -> instance-id map of scripts/refine.py:196 (yawed boxes, ground offset, label 0, orders)
 """
 import ctypes
 import os
@@ -264,7 +267,177 @@ def poses_golden():
              T_cam_velo=T_cam_velo, files=np.array(files))
 
 
+def instance_index_golden():
+    """Compiled reference find_point_in_instance_bbox_with_yaw on float points.  Boxes of one class never share a point
+    here: the reference's OpenMP loop over boxes races on such points, and a golden vector must not depend on it."""
+    import Array_Index
+    rng = np.random.default_rng(5)
+    boxes = np.array([[10.0, 5.0, -0.9, 4.2, 1.8, 1.6, 0.3, 1], [-6.0, 12.0, -1.0, 4.5, 1.9, 1.5, -1.2, 1],
+                      [22.0, -7.5, -0.8, 3.9, 1.7, 1.7, 2.8, 1], [3.0, -4.0, -0.7, 0.8, 0.7, 1.8, 0.5, 2],
+                      [10.3, 5.2, -0.9, 1.9, 0.8, 1.7, 1.0, 3],   # cyclist overlapping car 0: another column
+                      [-15.0, -15.0, -1.0, 4.0, 1.8, 1.5, 0.0, 0],  # label 0: never written, still takes a first point
+                      [80.0, 80.0, -1.0, 4.0, 1.8, 1.5, 0.4, 1]], np.float32)  # empty box
+    pts = []
+    for b in boxes[:6]:
+        u = rng.uniform(-0.75, 0.75, size=(300, 3)) * b[3:6]
+        c, s_ = np.cos(b[6]), np.sin(b[6])
+        pts.append(np.stack([b[0] + u[:, 0] * c - u[:, 1] * s_, b[1] + u[:, 0] * s_ + u[:, 1] * c, b[2] + u[:, 2]], 1))
+    pts.append(rng.uniform([-30, -30, -2.5], [30, 30, 1.0], size=(1500, 3)))
+    pts = np.concatenate(pts).astype(np.float32)
+    pts = np.hstack([pts, rng.uniform(0, 1, (len(pts), 1)).astype(np.float32)])  # (N, 4) like a .bin scan
+    cases = {"boxes": boxes}
+    for name, perm in (("a", rng.permutation(len(pts))), ("b", rng.permutation(len(pts))), ("sorted", np.argsort(pts[:, 0]))):
+        p = np.ascontiguousarray(pts[perm])
+        for og, tag in ((0.03, ""), (0.0, "_g0")):
+            out = Array_Index.find_point_in_instance_bbox_with_yaw(p, boxes, np.zeros((len(p), 3), dtype=int), og)
+            cases["index_" + name + tag] = np.asarray(out, np.int32)
+        cases["points_" + name] = p
+    np.savez(os.path.join(HERE, "instance_index.npz"), **cases)
+
+
+def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
+    """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
+    scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
+    threshold of refine.py:222-239) and confidences.  Returns plain arrays; poses are a straight drive along x."""
+    rng = np.random.default_rng(seed)
+    n_cars = 9
+    pos = np.stack([rng.uniform(-25, 25, n_cars), rng.uniform(-12, 12, n_cars), np.full(n_cars, -0.9)], 1)
+    pos[:, 0] += np.arange(n_cars) * 6.5 - 26  # keep cars apart: same-class boxes never share a point
+    dims = np.stack([rng.uniform(3.8, 4.6, n_cars), rng.uniform(1.6, 1.9, n_cars), rng.uniform(1.4, 1.7, n_cars)], 1)
+    yaw = rng.uniform(-0.3, 0.3, n_cars)
+    n_moving = 2 if low_dynamic else 5  # low dynamic: < 3 moving cars, so false positives on parked cars are pulled back
+    speed = np.where(np.arange(n_cars) < n_moving, rng.uniform(0.3, 0.6, n_cars), 0.0)  # world metres per frame along x
+    frames = []
+    for f in range(n_frames):
+        ego_x = 0.8 * f
+        boxes, labels, pts, mos, conf = [], [], [], [], []
+        present = np.ones(n_cars, bool)
+        if f in (3, 7):
+            present[6] = False  # a parked car missed by the detector in two frames: find_flag < 5 later
+        ratios = np.where(speed > 0, [0.9, 0.7, 0.45, 0.2, 0.0005][:5] + [0] * (n_cars - 5), 0.0)
+        ratios = np.asarray(ratios, float)
+        if f >= 8:
+            ratios[:5] = [0.95, 0.8, 0.65, 0.05, 0.0]
+        ratios[speed == 0] = 0.0
+        if low_dynamic:
+            ratios[4] = 0.25  # parked, a quarter of its points predicted moving
+            ratios[5] = 0.2
+        ratios[7] = (0.1 if low_dynamic else 0.35) if f % 2 else 0.0  # parked car with flickering false positives
+        for c in range(n_cars):
+            if not present[c]:
+                continue
+            ctr = pos[c] + np.array([speed[c] * f - ego_x, 0.0, 0.0]) + rng.normal(0, 0.03, 3)
+            d = dims[c] + rng.normal(0, 0.02, 3)
+            boxes.append(np.r_[ctr, d, yaw[c]])
+            labels.append(1)
+            npt = 60
+            u = rng.uniform(-0.45, 0.45, size=(npt, 3)) * d
+            cs, sn = np.cos(yaw[c]), np.sin(yaw[c])
+            p = np.stack([ctr[0] + u[:, 0] * cs - u[:, 1] * sn, ctr[1] + u[:, 0] * sn + u[:, 1] * cs, ctr[2] + 0.03 + u[:, 2]], 1)
+            m = rng.uniform(size=npt) < ratios[c]
+            pts.append(p)
+            mos.append(np.where(m, 251, 9))
+            cf = np.where(m | (rng.uniform(size=npt) < (0.7 if c in (0, 1, 3) else 0.1)), rng.uniform(0.2, 0.9, npt), 0.0)
+            conf.append(np.stack([1 - cf, cf], 1))
+        ctr = np.array([5.0 - ego_x, -6.0, -0.8])  # a pedestrian (class 2): ignored by the refinement
+        boxes.append(np.r_[ctr, 0.7, 0.7, 1.8, 0.2])
+        labels.append(2)
+        p = ctr + rng.uniform(-0.3, 0.3, size=(20, 3)) * [1, 1, 2.5]
+        pts.append(p)
+        mos.append(np.full(20, 251))
+        conf.append(np.stack([np.full(20, 0.2), np.full(20, 0.8)], 1))
+        nbg = 400
+        p = rng.uniform([-40, -20, -2.2], [40, 20, -1.75], size=(nbg, 3))  # ground clutter below the lifted boxes
+        pts.append(p)
+        mos.append(np.where(rng.uniform(size=nbg) < 0.02, 251, np.where(rng.uniform(size=nbg) < 0.05, 0, 9)))
+        conf.append(np.stack([np.full(nbg, 0.9), np.full(nbg, 0.1)], 1))
+        P = np.concatenate(pts).astype(np.float32)
+        perm = rng.permutation(len(P))
+        scan = np.hstack([P, rng.uniform(0, 1, (len(P), 1)).astype(np.float32)])[perm]
+        frames.append(dict(scan=np.ascontiguousarray(scan), boxes=np.asarray(boxes, np.float32),
+                           labels=np.asarray(labels, np.int64), mos=np.concatenate(mos).astype(np.uint32)[perm],
+                           conf=np.concatenate(conf).astype(np.float32)[perm]))
+    poses_txt = "".join("1 0 0 %.6f 0 1 0 0 0 0 1 0\n" % (0.8 * f) for f in range(n_frames))
+    calib_txt = "Tr: 1 0 0 0 0 1 0 0 0 0 1 0\n"
+    return frames, poses_txt, calib_txt
+
+
+def refine_golden():
+    """Runs the reference's scripts/refine.py main() itself on the synthetic sequence (in a scratch directory laid out
+    as the script expects) and stores inputs + its refined labels.  open3d / spconv are imported by the script but not
+    used on this path; they are absent here, so empty stand-in modules satisfy the import lines only.  The script's
+    `models.utils.Array_Index` is the compiled reference module (oracle/_ref)."""
+    data = {}
+    for tag, low in (("s0_", False), ("s1_", True)):
+        frames, poses_txt, calib_txt = synth_refine_sequence(seed=3 + int(low), low_dynamic=low)
+        _run_reference_refine(frames, poses_txt, calib_txt, tag, data)
+    np.savez_compressed(os.path.join(HERE, "refine.npz"), **data)
+
+
+def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
+    import importlib
+    import tempfile
+    import Array_Index
+    for name in ("open3d", "spconv", "spconv.pytorch", "spconv.pytorch.utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["spconv.pytorch.utils"].PointToVoxel = object
+    pkg = types.ModuleType("models.utils")
+    pkg.Array_Index = Array_Index
+    saved = {k: sys.modules.get(k) for k in ("models", "models.utils")}
+    sys.modules["models.utils"] = pkg
+    sys.modules.setdefault("models", types.ModuleType("models"))
+    sys.modules["models"].utils = pkg
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            os.makedirs("config")
+            os.symlink(os.path.join(REF, "config", "semantic-kitti-mos.yaml"), "config/semantic-kitti-mos.yaml")
+            seq = os.path.join(d, "data", "08")
+            os.makedirs(os.path.join(seq, "velodyne"))
+            open(os.path.join(seq, "poses.txt"), "w").write(poses_txt)
+            open(os.path.join(seq, "calib.txt"), "w").write(calib_txt)
+            for sub in ("bbox_preb", "mos_preb", "confidence"):
+                os.makedirs(os.path.join("preb_out", "InsMOS", sub, "sequences", "08", "predictions"))
+            for i, fr in enumerate(frames):
+                stem = "%06d" % i
+                fr["scan"].tofile(os.path.join(seq, "velodyne", stem + ".bin"))
+                np.save(os.path.join("preb_out/InsMOS/bbox_preb/sequences/08/predictions", stem + ".npy"),
+                        {"pred_boxes": fr["boxes"].copy(), "pred_scores": np.ones(len(fr["boxes"]), np.float32),
+                         "pred_labels": fr["labels"].copy()})
+                fr["mos"].astype(np.int32).tofile(os.path.join("preb_out/InsMOS/mos_preb/sequences/08/predictions", stem + ".label"))
+                np.save(os.path.join("preb_out/InsMOS/confidence/sequences/08/predictions", stem + ".npy"), fr["conf"])
+            refine = importlib.import_module("refine")
+            refine.main(os.path.join(d, "data"), "valid")
+            outs = [np.fromfile(os.path.join("preb_out_refine/mos_preb/sequences/08/predictions", "%06d.label" % i),
+                                dtype=np.int32) for i in range(len(frames))]
+        finally:
+            os.chdir(cwd)
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    data[tag + "poses_txt"], data[tag + "calib_txt"] = np.array(poses_txt), np.array(calib_txt)
+    data[tag + "n_frames"] = np.array(len(frames))
+    changed = 0
+    for i, (fr, o) in enumerate(zip(frames, outs)):
+        for k in ("scan", "boxes", "labels", "mos", "conf"):
+            data[tag + "f%02d_%s" % (i, k)] = fr[k]
+        data[tag + "f%02d_refined" % i] = o
+        changed += int((o != fr["mos"].astype(np.int32)).sum())
+    print("refine golden %s: %d frames, %d labels changed by the reference" % (tag, len(frames), changed))
+
+
 if __name__ == "__main__":
-    if "--poses-only" not in sys.argv:
+    if "--refine-only" in sys.argv:
+        refine_golden()
+        sys.exit(0)
+    if "--poses-only" not in sys.argv and "--instance-only" not in sys.argv:
         main()
-    poses_golden()
+    if "--instance-only" not in sys.argv:
+        poses_golden()
+    instance_index_golden()
+    if "--instance-only" not in sys.argv and "--poses-only" not in sys.argv:
+        refine_golden()
