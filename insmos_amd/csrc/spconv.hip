@@ -180,7 +180,15 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) acc[it][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        const uint32_t woff = ((cg * COT) * 256u + lane * 4u) * 4u;
+        // per-lane byte offset of this lane's A fragment in each channel tile.  Lanes whose output channel (lane & 15)
+        // lies beyond Cout hold packed ZEROS: point them past the end of the buffer instead, the hardware returns the
+        // same zeros without touching the L1 (Cout = 8 layers: half of every weight fragment)
+        uint32_t woffv[COT];
+#pragma unroll
+        for (int it = 0; it < COT; ++it) {
+            const uint32_t co = (cg * COT + it) * 16u + (uint32_t)(lane & 15);
+            woffv[it] = co < cout ? ((cg * COT + it) * 256u + lane * 4u) * 4u : 0x7FFFFFF0u;
+        }
 
         // raw neighbour indices of tap k (one dword per 16-row group and lane)
         auto load_idx = [&](int k, uint32_t (&idx)[JT]) {
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
                     if (k == 1000) a[it] = (f32x4){1.f, 1.f, 1.f, 1.f};
                 } else {
                     a[it] = __builtin_bit_cast(
-                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff + (uint32_t)it * 1024u, sw, 0));
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw, 0));
                 }
             }
         };
