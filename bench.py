@@ -175,7 +175,11 @@ def main():
         #      kernel is the UNION of its launches' event intervals; (b) one window at a time: plain per-launch durations
         lib = _lib.load()
         KK_CONV = next(k for k in range(64) if lib.insmos_prof_name(k) == b"sparse_conv_mfma")
-        eng.forward_window(pts, native=False)  # step path: fills the launch log the algorithmic work is counted from
+        eng.prune_dead_rows = False
+        eng.forward_window(pts, native=False)  # every row of every layer, as the reference computes them
+        work_ref = eng.algorithmic_work()
+        eng.prune_dead_rows = True
+        eng.forward_window(pts, native=False)  # step path: fills the launch log the EXECUTED work is counted from
         work = eng.algorithmic_work()
         nprof = 3
         lib.insmos_prof_reset()
@@ -203,6 +207,9 @@ def main():
             "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args),
             "algorithmic_gflop_per_window": round(work["flops"] / 1e9, 3),
+            "reference_gflop_per_window": round(work_ref["flops"] / 1e9, 3),
+            "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed); MotionNet rows "
+                         "nothing consumes are skipped (DESIGN.md 3.3), the reference computes reference_gflop_per_window",
             "method": f"{in_flight} windows in flight: achieved = algorithmic FLOP of the conv launches / UNION of their "
                       "HIP-event intervals (other kernels share the GPU during that time); single_stream = one window at a "
                       "time, plain per-launch durations (what a rocprof kernel trace of a sequential run shows)",

@@ -95,6 +95,11 @@ int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f, const int3
 /* First MotionNet layer (minkunet.py:55-60, kernel [5,5,5,1], 1 -> 8 channels) for a CONSTANT input feature
  * (motionnet.py:29-32 feeds 0.5 on every point): out[o, 0:8] = relu?(bias8 + sum over existing taps k of
  * w125x8[k, 0:8]) with w125x8 = value * BN-folded kernel.  No 125-tap table is built and nothing is gathered. */
+/* rows [row0, n_f) of the same table only (row0 rounded down to a multiple of 16; rows below are left untouched):
+ * the level-0 table of MotionNet is only read by block8, i.e. at the last two scans' voxels */
+int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                  int fine_shift, const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                  const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);
 int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
                                      const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                      const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
@@ -183,6 +188,16 @@ int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const 
 
 /* Tuning hook (tools/conv_tune.py): force generic non-identity layers onto tile shape (16*cot channels x
  * 16*jt rows) with an operand ring of depth `ring`; cot == 0 restores the built-in cost model. */
+/* insmos_sparse_conv on the output rows [row0, n_out) only (row0 is rounded down to a multiple of 16); pointers and
+ * n_out describe the FULL arrays / table.  Used to skip rows nothing consumes: MotionNet's features are read at the
+ * current scan's voxels only (motionnet.py:38-48), rows are ordered by time first, and a 3^4 convolution widens the
+ * needed time range by one scan per layer -- so the decoder-side layers of the finer levels run on a suffix of their
+ * rows.  insmos_tslice_starts: starts[d] = first row with t >= t_last - d of a sorted 4D key array. */
+int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16,
+                            int K, int64_t n_out, int64_t row0, const float* wpacked, const float* bias, float* out,
+                            int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
+                            void* stream);
+int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream);
 int insmos_debug_conv_force(int cot, int jt, int ring);
 
 /* ------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ SIGNATURES = {
     "insmos_level_down4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_nbr_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "insmos_nbr81_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_nbr81_from_coarse_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_const_conv125_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_int, c_int, c_vp]),
     "insmos_nbr_down_up": (c_int, [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -38,6 +39,9 @@ SIGNATURES = {
     "insmos_pack_weights_host": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "insmos_sparse_conv": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
                                    c_int, c_int, c_int, c_int, c_vp]),
+    "insmos_sparse_conv_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int,
+                                        c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),
     "insmos_sparse_to_bev": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),

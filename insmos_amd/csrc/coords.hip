@@ -410,13 +410,13 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
                                                       const uint32_t* __restrict__ child_mask,
                                                       int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int ld_out, int relu) {
+                                                      float* __restrict__ out, int ld_out, int relu, int64_t row0) {
     constexpr int NB = RANGE == 1 ? 2 : 3;       // candidate coarse blocks per axis
     constexpr int E = NB * NB * NB * NDT;        // cached coarse entries per voxel
     constexpr int W1 = 2 * RANGE + 1;
     __shared__ uint32_t sl[E][256];  // child_start (24 bits) << 8 | child_mask (8 bits)
     const int tid = threadIdx.x;
-    const int64_t o_raw = (int64_t)blockIdx.x * blockDim.x + tid;
+    const int64_t o_raw = row0 + (int64_t)blockIdx.x * blockDim.x + tid;  // rows [row0, n_f); row0 is a multiple of 16
     const bool live = o_raw < n_f;
     const int64_t o = live ? o_raw : n_f - 1;
     const int4 c = *(const int4*)(coords + o * 4);
@@ -487,6 +487,21 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
             op[i] = relu ? fmaxf(v, 0.f) : v;
         }
     }
+}
+
+
+// first row of each trailing time slice of a sorted 4D key array: starts[d] = first row with t >= t_last - d
+__global__ void k_tslice_starts(const uint64_t* __restrict__ keys, int64_t n, int max_d, int32_t* __restrict__ starts) {
+    const int d = threadIdx.x;
+    if (d >= max_d) return;
+    const uint64_t t_last = keys[n - 1] >> 48;
+    const uint64_t want = t_last >= (uint64_t)d ? (t_last - (uint64_t)d) << 48 : 0ull;
+    int64_t lo = 0, hi = n;  // lower_bound(keys, want)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    starts[d] = (int32_t)lo;
 }
 
 }  // namespace insmos
@@ -762,19 +777,29 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
     return INSMOS_OK;
 }
 
+extern "C" int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                             int fine_shift, const int32_t* coarse_nbr81, int64_t n_c,
+                                             const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr,
+                                             uint32_t* mask16, void* stream) {
+    if (n_f <= 0 || n_f >= (1 << 24) || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
+        !child_mask || !nbr || fine_shift < 0 || fine_shift > 14 || row0 < 0)
+        return INSMOS_EINVAL;
+    row0 &= ~(int64_t)15;
+    if (row0 >= n_f) return INSMOS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f - row0, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, 0, 0, row0);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
 extern "C" int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
                                         const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                         const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream) {
-    if (n_f <= 0 || n_f >= (1 << 24) || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
-        !child_mask || !nbr || fine_shift < 0 || fine_shift > 14)
-        return INSMOS_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps(KK_BUILD_NBR, s);
-    INSMOS_LAUNCH((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
-                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, 0, 0);
-    HIP_TRY(hipGetLastError());
-    return INSMOS_OK;
+    return insmos_nbr81_from_coarse_rows(fine_coords, n_f, 0, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask,
+                                         nbr, mask16, stream);
 }
 
 extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent,
@@ -789,7 +814,15 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
     ProfScope ps(KK_SPARSE_CONV, s);
     INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
-                       w125x8, bias8, out, ld_out, relu);
+                       w125x8, bias8, out, ld_out, relu, (int64_t)0);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream) {
+    if (!keys || n <= 0 || max_d <= 0 || max_d > 64 || !starts) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    INSMOS_LAUNCH(k_tslice_starts, dim3(1), dim3(64), 0, s, keys, n, max_d, starts);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -120,14 +120,14 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     // out[:, col_out : col_out + cout] = epilogue(conv(x[:, col_in : col_in + cin]))  (Engine.conv)
     auto conv = [&](const char* name, const float* x, int64_t n_in, int ld_in, int col_in, const Table* t, int64_t n_out,
                     float* o, int ld_out, int col_out, const float* res, int ld_res, int col_res, int res_mode,
-                    int relu_pre, int relu_post) -> int {
+                    int relu_pre, int relu_post, int64_t row0 = 0) -> int {
         const InsmosConvW* w = Lr(name);
         if (!w) return INSMOS_EINVAL;
         if (n_out == 0) return INSMOS_OK;
         if (t && (t->K != w->K || t->n != n_out)) return INSMOS_EINVAL;
-        return insmos_sparse_conv(x + col_in, n_in, ld_in, w->cin, t ? t->nbr : nullptr, t ? t->mask : nullptr, w->K, n_out,
-                                  w->w, w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr, ld_res, res_mode,
-                                  relu_pre, relu_post, s);
+        return insmos_sparse_conv_rows(x + col_in, n_in, ld_in, w->cin, t ? t->nbr : nullptr, t ? t->mask : nullptr, w->K,
+                                       n_out, row0, w->w, w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr,
+                                       ld_res, res_mode, relu_pre, relu_post, s);
     };
     auto table = [&](int K, int64_t n) {
         Table t;
@@ -184,6 +184,16 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     }
     for (int l = 0; l < 4; ++l) out->me_voxels[l] = n[l];
     out->n_cur = ncur;
+    // Dead-row elimination (same as Engine.motionnet): starts[l][d] = first level-l row with
+    // t >= t_last - d; a layer whose output is needed d scans back computes rows [starts[l][d], n[l]) only.
+    int32_t starts[4][16];
+    {
+        int32_t* sd = A.take<int32_t>(64);
+        NEED_ARENA();
+        for (int l = 0; l < 4; ++l) CK(insmos_tslice_starts(keys[l], n[l], 16, sd + 16 * l, s));
+        CK(read_counts(sd, &starts[0][0], 64, s));
+    }
+    auto row_from = [&](int l, int d) -> int64_t { return d < 16 ? starts[l][d] : 0; };
 
     // only the coarsest level is searched; every finer table is derived through the Morton hierarchy
     Table nbr81[4];
@@ -197,8 +207,9 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     for (int l = 2; l >= 0; --l) {
         nbr81[l] = table(81, n[l]);
         NEED_ARENA();
-        CK(insmos_nbr81_from_coarse(coords[l], n[l], parent[l], l, nbr81[l + 1].nbr, n[l + 1], cstart[l], cmask[l],
-                                    nbr81[l].nbr, nbr81[l].mask, s));
+        // (the level-0 table is read by block8 only: rows of the last two scans)
+        CK(insmos_nbr81_from_coarse_rows(coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1],
+                                         cstart[l], cmask[l], nbr81[l].nbr, nbr81[l].mask, s));
     }
     Table dn[3], up[3];
     for (int l = 0; l < 3; ++l) {
@@ -230,29 +241,32 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
                                         g.b0_const, cat8 + 8, 16, 1, s));
     CK(conv("conv1p1s2", cat8, n[0], 16, 8, &dn[0], n[1], x1, 8, 0, nullptr, 0, 0, 0, 0, 1));
     // BasicBlock (minkunet.py:63-124): conv1-bn-relu, conv2-bn, (+ downsample(x) | x), relu
+    // (output needed `depth` scans back: conv2 / downsample on those rows, conv1 one scan further; depth 99 = all rows)
     auto block = [&](const std::string& name, const float* x, int64_t nn, int ld_x, int col_x, const Table* nb, int cout,
-                     float* o, int ld_out, int col_out) -> int {
-        CK(conv((name + ".conv1").c_str(), x, nn, ld_x, col_x, nb, nn, tmp_t, cout, 0, nullptr, 0, 0, 0, 0, 1));
+                     float* o, int ld_out, int col_out, int lvl, int depth) -> int {
+        const int64_t r2 = row_from(lvl, depth), r1 = row_from(lvl, depth + 1);
+        CK(conv((name + ".conv1").c_str(), x, nn, ld_x, col_x, nb, nn, tmp_t, cout, 0, nullptr, 0, 0, 0, 0, 1, r1));
         if (Lr(name + ".ds")) {
-            CK(conv((name + ".ds").c_str(), x, nn, ld_x, col_x, nullptr, nn, tmp_r, cout, 0, nullptr, 0, 0, 0, 0, 0));
-            CK(conv((name + ".conv2").c_str(), tmp_t, nn, cout, 0, nb, nn, o, ld_out, col_out, tmp_r, cout, 0, 1, 0, 1));
+            CK(conv((name + ".ds").c_str(), x, nn, ld_x, col_x, nullptr, nn, tmp_r, cout, 0, nullptr, 0, 0, 0, 0, 0, r2));
+            CK(conv((name + ".conv2").c_str(), tmp_t, nn, cout, 0, nb, nn, o, ld_out, col_out, tmp_r, cout, 0, 1, 0, 1, r2));
         } else {
-            CK(conv((name + ".conv2").c_str(), tmp_t, nn, cout, 0, nb, nn, o, ld_out, col_out, x, ld_x, col_x, 1, 0, 1));
+            CK(conv((name + ".conv2").c_str(), tmp_t, nn, cout, 0, nb, nn, o, ld_out, col_out, x, ld_x, col_x, 1, 0, 1, r2));
         }
         return INSMOS_OK;
     };
-    CK(block("block1.0", x1, n[1], 8, 0, &nbr81[1], 8, cat7, 32, 16));
+    CK(block("block1.0", x1, n[1], 8, 0, &nbr81[1], 8, cat7, 32, 16, 1, 99));
     CK(conv("conv2p2s2", cat7, n[1], 32, 16, &dn[1], n[2], x2, 8, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(block("block2.0", x2, n[2], 8, 0, &nbr81[2], 16, cat6, 48, 32));
+    CK(block("block2.0", x2, n[2], 8, 0, &nbr81[2], 16, cat6, 48, 32, 2, 99));
     CK(conv("conv3p4s2", cat6, n[2], 48, 32, &dn[2], n[3], x3, 16, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(block("block3.0", x3, n[3], 16, 0, &nbr81[3], 32, b3, 32, 0));
-    CK(conv("convtr5p8s2", b3, n[3], 32, 0, &up[2], n[2], cat6, 48, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(block("block6.0", cat6, n[2], 48, 0, &nbr81[2], 32, b6, 32, 0));
-    CK(conv("convtr6p4s2", b6, n[2], 32, 0, &up[1], n[1], cat7, 32, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(block("block7.0", cat7, n[1], 32, 0, &nbr81[1], 16, b7, 16, 0));
-    CK(conv("convtr7p2s2", b7, n[1], 16, 0, &up[0], n[0], cat8, 16, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(block("block8.0", cat8, n[0], 16, 0, &nbr81[0], 8, b8, 8, 0));
-    CK(conv("final", b8, n[0], 8, 0, nullptr, n[0], motion, 4, 0, nullptr, 0, 0, 0, 0, 0));
+    // decoder side: needed time depth = 0 at `final`, +1 per 3^4 conv on the way back (a block holds two)
+    CK(block("block3.0", x3, n[3], 16, 0, &nbr81[3], 32, b3, 32, 0, 3, 6));
+    CK(conv("convtr5p8s2", b3, n[3], 32, 0, &up[2], n[2], cat6, 48, 0, nullptr, 0, 0, 0, 0, 1, row_from(2, 6)));
+    CK(block("block6.0", cat6, n[2], 48, 0, &nbr81[2], 32, b6, 32, 0, 2, 4));
+    CK(conv("convtr6p4s2", b6, n[2], 32, 0, &up[1], n[1], cat7, 32, 0, nullptr, 0, 0, 0, 0, 1, row_from(1, 4)));
+    CK(block("block7.0", cat7, n[1], 32, 0, &nbr81[1], 16, b7, 16, 0, 1, 2));
+    CK(conv("convtr7p2s2", b7, n[1], 16, 0, &up[0], n[0], cat8, 16, 0, nullptr, 0, 0, 0, 0, 1, row_from(0, 2)));
+    CK(block("block8.0", cat8, n[0], 16, 0, &nbr81[0], 8, b8, 8, 0, 0, 0));
+    CK(conv("final", b8, n[0], 8, 0, nullptr, n[0], motion, 4, 0, nullptr, 0, 0, 0, 0, 0, row_from(0, 0)));
     CK(insmos_build_current_points(pts, ld, motion, 4, inverse, cur_index, ncur, cur, 8, s));
 
     // =============================== UNetV2 (3D) ===============================

@@ -40,6 +40,7 @@ struct ConvP {
     float* out;
     const float* res;
     uint32_t n_out;
+    uint32_t row0;  // first output row computed (multiple of 16): rows [row0, n_out) -- insmos_sparse_conv_rows
     uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
     int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         uint32_t orow[JT], rowoff[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            orow[jt] = ot * (16 * JT) + jt * 16 + j;
+            orow[jt] = P.row0 + ot * (16 * JT) + jt * 16 + j;
             rowoff[jt] = (orow[jt] < n_out ? orow[jt] : n_out - 1) * 4u;  // byte offset inside one tap row of nbr
         }
 
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
             if (P.mask16) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
-                    const uint32_t grp = ot * JT + jt;
+                    const uint32_t grp = (P.row0 >> 4) + ot * JT + jt;
                     const uint32_t* mp = P.mask16 + (size_t)(grp < ngrp ? grp : ngrp - 1) * 4;
                     uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
                     uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
@@ -503,11 +504,14 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
-                                  const uint32_t* mask16, int K, int64_t n_out, const float* wpacked, const float* bias,
-                                  float* out, int ld_out, int cout, const float* res, int ld_res, int res_mode,
-                                  int relu_pre, int relu_post, void* stream) {
-    if (n_out <= 0) return INSMOS_OK;
+static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
+                            const uint32_t* mask16, int K, int64_t n_out, int64_t row0, const float* wpacked,
+                            const float* bias, float* out, int ld_out, int cout, const float* res, int ld_res, int res_mode,
+                            int relu_pre, int relu_post, void* stream) {
+    if (n_out <= 0 || row0 >= n_out) return INSMOS_OK;
+    if (row0 < 0) return INSMOS_EINVAL;
+    row0 &= ~(int64_t)15;  // whole 16-row groups: a few rows below the requested start are computed too
+    const int64_t n_rows = n_out - row0;
     if (!in || n_in <= 0 || !wpacked || !bias || !out || cin <= 0 || ld_in % 4 != 0 || ld_in < cin || K <= 0 || K > 128 ||
         (!nbr && (K != 1 || n_in < n_out)) || cout <= 0 || ld_out < cout || (res_mode != 0 && !res) ||
         ((uintptr_t)in & 15) || n_out * (int64_t)K * 4 >= (1ll << 31) || n_in * (int64_t)ld_in * 4 >= (1ll << 31))
@@ -516,6 +520,7 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     ConvP P;
     P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
     P.n_out = (uint32_t)n_out;
+    P.row0 = (uint32_t)row0;
     P.in_bytes = (uint32_t)((n_in - 1) * (int64_t)ld_in * 4 + (int64_t)cin * 4);
     P.ld_in = ld_in; P.cin = cin; P.K = K; P.ld_out = ld_out; P.cout = cout; P.ld_res = ld_res; P.res_mode = res_mode;
     P.relu_pre = relu_pre; P.relu_post = relu_post;
@@ -535,14 +540,14 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     static int ck_jt = 0;
     if (!ck_jt) { ck_jt = env_int("INSMOS_CK_JT", 1); if (ck_jt != 2 && ck_jt != 4) ck_jt = 1; }
     Cfg best = {1, ck ? ck_jt : 1};
-    const long groups = (long)((n_out + 15) / 16);
+    const long groups = (long)((n_rows + 15) / 16);
     if (!ck) {
         if (P.ntile_co % 4 == 0 && groups * (P.ntile_co / 4) >= 2048) best.cot = 4;
         else if (P.ntile_co % 2 == 0) best.cot = 2;
     } else if (P.ntile_co % 2 == 0) {
         best.cot = 2;
     }
-    P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
+    P.n_otiles = (int)((n_rows + 16 * best.jt - 1) / (16 * best.jt));
     const bool ident = (nbr == nullptr);
     ConvKernel kern = nullptr;
     if (ck == 4) kern = ident ? pick_kernel<4, true>(best.cot, best.jt) : pick_kernel<4, false>(best.cot, best.jt);
@@ -580,7 +585,7 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
             by_chunk = false;
             kern = fk;
             best = {g_force_cot, g_force_jt};
-            P.n_otiles = (int)((n_out + 16 * best.jt - 1) / (16 * best.jt));
+            P.n_otiles = (int)((n_rows + 16 * best.jt - 1) / (16 * best.jt));
         }
     }
     if (g_dbg && !ident) {
@@ -605,6 +610,22 @@ extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int 
     INSMOS_LAUNCH(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_sparse_conv(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
+                                  const uint32_t* mask16, int K, int64_t n_out, const float* wpacked, const float* bias,
+                                  float* out, int ld_out, int cout, const float* res, int ld_res, int res_mode,
+                                  int relu_pre, int relu_post, void* stream) {
+    return sparse_conv_impl(in, n_in, ld_in, cin, nbr, mask16, K, n_out, 0, wpacked, bias, out, ld_out, cout, res, ld_res,
+                            res_mode, relu_pre, relu_post, stream);
+}
+
+extern "C" int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
+                                       const uint32_t* mask16, int K, int64_t n_out, int64_t row0, const float* wpacked,
+                                       const float* bias, float* out, int ld_out, int cout, const float* res, int ld_res,
+                                       int res_mode, int relu_pre, int relu_post, void* stream) {
+    return sparse_conv_impl(in, n_in, ld_in, cin, nbr, mask16, K, n_out, row0, wpacked, bias, out, ld_out, cout, res,
+                            ld_res, res_mode, relu_pre, relu_post, stream);
 }
 
 extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {

@@ -96,6 +96,7 @@ class Engine:
     def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5, native=False):
         self.lib = _lib.load()
         self.native = native      # default path of forward_window (see there)
+        self.prune_dead_rows = True  # MotionNet decoder layers skip rows nothing consumes
         self._ctx_box = [None]    # native context, shared with clones
         self._arena = None
         self.cfg = cfg
@@ -235,8 +236,8 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------
     def conv(self, layer, x, ld_in, nbr, n_out, out, ld_out, col_out=0, col_in=0, res=None, ld_res=0, col_res=0,
-             res_mode=0, relu_pre=0, relu_post=0, n_in=None):
-        """out[:, col_out:col_out+cout] = epilogue(conv(x[:, col_in:col_in+cin]))."""
+             res_mode=0, relu_pre=0, relu_post=0, n_in=None, row0=0):
+        """out[row0:, col_out:col_out+cout] = epilogue(conv(x[:, col_in:col_in+cin])) (rows below row0 are not computed)."""
         if n_out == 0:
             return
         K = layer.K
@@ -248,14 +249,15 @@ class Engine:
         if self.layer_timing is not None:
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record(torch.cuda.current_stream(self.device))
-        rc = self.lib.insmos_sparse_conv(
+        row0 = int(row0) & ~15
+        rc = self.lib.insmos_sparse_conv_rows(
             x.data_ptr() + 4 * col_in, x.shape[0] if n_in is None else n_in, ld_in, layer.cin, nbr.data_ptr() if nbr is not None else None,
-            mask.data_ptr() if mask is not None else None, K, n_out,
+            mask.data_ptr() if mask is not None else None, K, n_out, row0,
             layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr() + 4 * col_out, ld_out, layer.cout,
             (res.data_ptr() + 4 * col_res) if res is not None else None, ld_res, res_mode, relu_pre, relu_post,
             self._stream())
-        _lib.check(rc, "insmos_sparse_conv")
-        self._conv_log.append((nbr, n_out, layer))
+        _lib.check(rc, "insmos_sparse_conv_rows")
+        self._conv_log.append((nbr, n_out, layer, row0))
         if self.layer_timing is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
@@ -321,6 +323,22 @@ class Engine:
             child_mask.append(cmk)
         self.last_counts["me_voxels"] = list(n)
         self.last_counts["n_cur"] = ncur
+        # Dead-row elimination: only the current scan's voxels of the final feature map are read
+        # (motionnet.py:38-48), rows are ordered by time first, and a 3^4 convolution widens the needed time range by
+        # one scan per layer.  starts[l][d] = first level-l row with t >= t_last - d; row_from(l, d) = where a layer whose
+        # output is needed `d` scans back starts computing.
+        if self.prune_dead_rows:
+            starts_d = self._empty((4, 16), torch.int32)
+            for l in range(4):
+                _lib.check(lib.insmos_tslice_starts(keys[l].data_ptr(), n[l], 16, starts_d[l].data_ptr(), st),
+                           "insmos_tslice_starts")
+            starts = starts_d.cpu().numpy()
+        else:
+            starts = np.zeros((4, 16), np.int32)
+
+        def row_from(l, d):
+            return int(starts[l][d]) if d < 16 else 0
+        self.last_counts["me_row_starts"] = [[row_from(l, d) for d in range(10)] for l in range(4)]
 
         def table(K, n_out):
             return (self._empty((K, n_out), torch.int32), self._empty(((n_out + 15) // 16, 4), torch.int32))
@@ -338,10 +356,11 @@ class Engine:
         nbr81 = [None, None, None, self.build_nbr(coords[3], n[3], keys[3], None, n[3], 0, None, self.off81[3])]
         for l in (2, 1, 0):
             nb, mk = table(81, n[l])
-            _lib.check(lib.insmos_nbr81_from_coarse(coords[l].data_ptr(), n[l], parent[l].data_ptr(), l,
-                                                    nbr81[l + 1].nbr.data_ptr(), n[l + 1], child_start[l].data_ptr(),
-                                                    child_mask[l].data_ptr(), nb.data_ptr(), mk.data_ptr(), st),
-                       "insmos_nbr81_from_coarse")
+            # the level-0 table is read by block8 only: rows of the last two scans (dead-row elimination, see above)
+            _lib.check(lib.insmos_nbr81_from_coarse_rows(coords[l].data_ptr(), n[l], row_from(0, 1) if l == 0 else 0,
+                                                         parent[l].data_ptr(), l, nbr81[l + 1].nbr.data_ptr(), n[l + 1],
+                                                         child_start[l].data_ptr(), child_mask[l].data_ptr(), nb.data_ptr(),
+                                                         mk.data_ptr(), st), "insmos_nbr81_from_coarse_rows")
             nbr81[l] = NbrTable(nb, mk)
         # the 125-tap table is only materialised when the first layer's input is not constant (generic path)
         nbr125 = from_coarse(0, self.off125, nbr81[1]) if not self.const_input else None
@@ -374,23 +393,26 @@ class Engine:
                                                             child_mask[0].data_ptr(), self.w0_const.data_ptr(),
                                                             self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1, st),
                        "insmos_const_conv125_from_coarse")
-            self._conv_log.append((None, n[0], L["conv0p1s1"]))
+            self._conv_log.append((None, n[0], L["conv0p1s1"], 0))
         else:
             self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
         x1 = E((n[1], 8))
         self.conv(L["conv1p1s2"], cat8, 16, dn[0], n[1], x1, 8, col_in=8, relu_post=1)
 
-        def block(name, x, ld_x, col_x, nb, nn, cout, out, ld_out, col_out):
+        def block(name, x, ld_x, col_x, nb, nn, cout, out, ld_out, col_out, lvl=0, depth=99):
+            """BasicBlock whose output is needed `depth` scans back: conv2 / downsample run on those rows, conv1 one
+            scan further back (conv2 reads it through a 3^4 window)."""
+            r2, r1 = row_from(lvl, depth), row_from(lvl, depth + 1)
             t = E((nn, cout))
-            self.conv(L[name + ".conv1"], x, ld_x, nb, nn, t, cout, col_in=col_x, relu_post=1)
+            self.conv(L[name + ".conv1"], x, ld_x, nb, nn, t, cout, col_in=col_x, relu_post=1, row0=r1)
             if (name + ".ds") in L:
                 r = E((nn, cout))
-                self.conv(L[name + ".ds"], x, ld_x, None, nn, r, cout, col_in=col_x)
+                self.conv(L[name + ".ds"], x, ld_x, None, nn, r, cout, col_in=col_x, row0=r2)
                 self.conv(L[name + ".conv2"], t, cout, nb, nn, out, ld_out, col_out=col_out, res=r, ld_res=cout,
-                          res_mode=1, relu_post=1)
+                          res_mode=1, relu_post=1, row0=r2)
             else:
                 self.conv(L[name + ".conv2"], t, cout, nb, nn, out, ld_out, col_out=col_out, res=x, ld_res=ld_x,
-                          col_res=col_x, res_mode=1, relu_post=1)
+                          col_res=col_x, res_mode=1, relu_post=1, row0=r2)
 
         block("block1.0", x1, 8, 0, nbr81[1], n[1], 8, cat7, 32, 16)
         x2 = E((n[2], 8))
@@ -399,18 +421,19 @@ class Engine:
         x3 = E((n[3], 16))
         self.conv(L["conv3p4s2"], cat6, 48, dn[2], n[3], x3, 16, col_in=32, relu_post=1)
         b3 = E((n[3], 32))
-        block("block3.0", x3, 16, 0, nbr81[3], n[3], 32, b3, 32, 0)
-        self.conv(L["convtr5p8s2"], b3, 32, up[2], n[2], cat6, 48, col_out=0, relu_post=1)
+        # decoder side: needed time depth per layer = 0 at `final`, +1 per 3^4 conv on the way back (block = 2 convs)
+        block("block3.0", x3, 16, 0, nbr81[3], n[3], 32, b3, 32, 0, lvl=3, depth=6)
+        self.conv(L["convtr5p8s2"], b3, 32, up[2], n[2], cat6, 48, col_out=0, relu_post=1, row0=row_from(2, 6))
         b6 = E((n[2], 32))
-        block("block6.0", cat6, 48, 0, nbr81[2], n[2], 32, b6, 32, 0)
-        self.conv(L["convtr6p4s2"], b6, 32, up[1], n[1], cat7, 32, col_out=0, relu_post=1)
+        block("block6.0", cat6, 48, 0, nbr81[2], n[2], 32, b6, 32, 0, lvl=2, depth=4)
+        self.conv(L["convtr6p4s2"], b6, 32, up[1], n[1], cat7, 32, col_out=0, relu_post=1, row0=row_from(1, 4))
         b7 = E((n[1], 16))
-        block("block7.0", cat7, 32, 0, nbr81[1], n[1], 16, b7, 16, 0)
-        self.conv(L["convtr7p2s2"], b7, 16, up[0], n[0], cat8, 16, col_out=0, relu_post=1)
+        block("block7.0", cat7, 32, 0, nbr81[1], n[1], 16, b7, 16, 0, lvl=1, depth=2)
+        self.conv(L["convtr7p2s2"], b7, 16, up[0], n[0], cat8, 16, col_out=0, relu_post=1, row0=row_from(0, 2))
         b8 = E((n[0], 8))
-        block("block8.0", cat8, 16, 0, nbr81[0], n[0], 8, b8, 8, 0)
+        block("block8.0", cat8, 16, 0, nbr81[0], n[0], 8, b8, 8, 0, lvl=0, depth=0)
         motion = E((n[0], 4))
-        self.conv(L["final"], b8, 8, None, n[0], motion, 4)
+        self.conv(L["final"], b8, 8, None, n[0], motion, 4, row0=row_from(0, 0))
         cur = E((ncur, 8))
         _lib.check(lib.insmos_build_current_points(pts.data_ptr(), ld, motion.data_ptr(), 4, inverse.data_ptr(),
                                                    cur_index.data_ptr(), ncur, cur.data_ptr(), 8, st),
@@ -709,13 +732,14 @@ class Engine:
         distinct table: bench/profiling only."""
         cache = {}
         flops = gather = pairs_total = 0
-        for nbr, n_out, layer in self._conv_log:
+        for nbr, n_out, layer, row0 in self._conv_log:
             if nbr is None:
-                pairs = n_out
+                pairs = n_out - row0
             else:
-                key = nbr.data_ptr()
+                key = (nbr.data_ptr(), row0)
                 if key not in cache:
-                    cache[key] = int((nbr >= 0).sum().item())
+                    tab = nbr.nbr if isinstance(nbr, NbrTable) else nbr
+                    cache[key] = int((tab[:, row0:] >= 0).sum().item())
                 pairs = cache[key]
             cin = layer.flops_per_pair // (2 * layer.cout_real)
             flops += pairs * layer.flops_per_pair

@@ -30,12 +30,20 @@ def test_quantize_levels_and_tables(window, engine):
     engine.motionnet(pts)
     torch.cuda.synchronize()
     out_p1_const = engine._me_debug["cat8"][:, 8:16].clone()
+    r1 = engine.last_counts["me_row_starts"][0][1] & ~15  # dead-row elimination: level-0 table rows of the last 2 scans
+    assert r1 > 0
+    tab0_pruned = engine._me_tables["nbr81"][0].nbr[:, r1:].clone()
+    mask0_pruned = engine._me_tables["nbr81"][0].mask16[r1 // 16:].clone()
     engine.const_input = False  # generic path: materialises the 125-tap table and gathers the 0.5 features
+    engine.prune_dead_rows = False  # ... and every row of every table, as the reference's libraries do
     try:
         cur = engine.motionnet(pts)
         torch.cuda.synchronize()
     finally:
         engine.const_input = True
+        engine.prune_dead_rows = True
+    assert torch.equal(tab0_pruned, engine._me_tables["nbr81"][0].nbr[:, r1:])
+    assert torch.equal(mask0_pruned, engine._me_tables["nbr81"][0].mask16[r1 // 16:])
     # the constant-input first layer is bitwise the generic MFMA path (same tap order, 0.5*w exact)
     assert torch.equal(out_p1_const, engine._me_debug["cat8"][:, 8:16])
     T = engine._me_tables

@@ -18,8 +18,11 @@ def s0_run():
     cfg = P.default_cfg()
     eng = Engine(cfg, P.random_state_dict(cfg, 0))
     w = make_window(0, 10, 1886)
+    logits_pruned, _ = eng.forward_window(torch.from_numpy(w).cuda())
+    eng.prune_dead_rows = False  # every row of every table and layer, as the reference computes them (known pair counts)
     logits, pred = eng.forward_window(torch.from_numpy(w).cuda())
     torch.cuda.synchronize()
+    assert torch.equal(logits, logits_pruned)  # dead-row elimination changes no output bit at full size either
     return eng, w, logits, pred
 
 

@@ -55,8 +55,17 @@ def test_forward_signature_and_parity(setup):
     # --- stage checks (sharper diagnostics than the end result)
     cur_ref = dbg["current_point"]
     assert logits.shape == ref_logits.shape == (len(cur_ref), 3)
-    np.testing.assert_allclose(eng._me_debug["motion"].cpu().numpy()[:, :3], dbg["motion"]["voxel_motion"], atol=2e-4,
+    r0 = eng.last_counts["me_row_starts"][0][0]  # dead-row elimination: only the current scan's rows are computed
+    assert 0 < r0 < len(dbg["motion"]["voxel_motion"])
+    np.testing.assert_allclose(eng._me_debug["motion"].cpu().numpy()[r0:, :3], dbg["motion"]["voxel_motion"][r0:], atol=2e-4,
                                rtol=1e-3)
+    # ... and computing every row (as the reference does) gives the same bits where it matters
+    eng.prune_dead_rows = False
+    logits_full, _ = eng.forward_window(batch[0]["past_point_clouds"], native=False)
+    eng.prune_dead_rows = True
+    assert torch.equal(logits_full, logits_list[0])
+    np.testing.assert_allclose(eng._me_debug["motion"].cpu().numpy()[:, :3], dbg["motion"]["voxel_motion"], atol=2e-4, rtol=1e-3)
+    eng.forward_window(batch[0]["past_point_clouds"], native=False)  # restore the pruned intermediates for the checks below
     np.testing.assert_allclose(eng._un_debug["enc"].cpu().numpy(), dbg["unet"]["encoded"], atol=2e-4, rtol=1e-3)
     head = eng._head_debug["head"].cpu().numpy()
     H2, W2 = 2 * eng.bevH, 2 * eng.bevW

@@ -29,7 +29,7 @@ bench.calibrate_head(model, pts, 1500)
 eng = model.model.engine
 model.forward([{"past_point_clouds": pts}], "test")
 torch.cuda.synchronize()
-log = {l.name: (nbr, n, l) for (nbr, n, l) in eng._conv_log if nbr is not None}
+log = {l.name: (nbr, n, l) for (nbr, n, l, _r0) in eng._conv_log if nbr is not None}
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 print("%-18s %3s %4s %4s %7s | " % ("layer", "K", "cin", "cout", "n_out") + " ".join("%8s" % s for s in
       ("full", "noW", "noB", "mfma", "noMFMA", "idx", "allK", "allKmfma", "unif", "unifmfma")))

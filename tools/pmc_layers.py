@@ -23,7 +23,7 @@ eng = model.model.engine
 for _ in range(3):
     model.forward([{"past_point_clouds": pts}], "test")
 torch.cuda.synchronize()
-order = [(l.name, l.K, l.cin, l.cout, int(n)) for (_, n, l) in eng._conv_log]
+order = [(l.name, l.K, l.cin, l.cout, int(n)) for (_, n, l, _r0) in eng._conv_log]
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(order, open("gpurun_out/conv_order.json", "w"))
 print("conv launches per window:", len(order))
