@@ -164,7 +164,9 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     n[0] = hc[0];
     const int64_t ncur = hc[1];
     if (hc[2] != 0) { out->n_out_of_window = hc[2]; return INSMOS_EINVAL; }
-    if (ncur == 0 || n[0] == 0) return INSMOS_EINVAL;
+    out->me_voxels[0] = n[0];
+    out->n_cur = ncur;
+    if (ncur == 0 || n[0] == 0) return INSMOS_EINVAL;  // (the caller tells the two apart by the counts above)
     for (int l = 1; l <= 3; ++l) {
         const int64_t np = n[l - 1];
         keys[l] = A.take<uint64_t>(np);

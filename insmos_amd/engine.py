@@ -698,7 +698,7 @@ class Engine:
             self._arena = torch.empty(max(int(out.arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
         if rc == -1 and out.n_out_of_window:
             raise ValueError(f"{int(out.n_out_of_window)} points fall outside the +-32768-voxel key window")
-        if rc == -1 and out.n_cur == 0 and out.me_voxels[0] > 0:
+        if rc == -1 and out.n_cur == 0 and out.me_voxels[0] > 0 and not out.n_out_of_window:
             raise ValueError("window has no current-scan points (t == 0)")
         _lib.check(rc, "insmos_forward_window")
         ncur, K = int(out.n_cur), int(out.n_boxes)

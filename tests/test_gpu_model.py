@@ -125,6 +125,34 @@ def test_windows_in_flight_match_sequential(setup):
             assert torch.equal(p1[0][0][k], pr[k]), k
 
 
+def test_native_runner_arena_growth_and_errors(setup):
+    """The native runner grows its arena on INSMOS_EWORKSPACE and reports the reference-visible input errors."""
+    from insmos_amd.engine import Engine
+    from insmos_amd.synth import make_window
+    eng = Engine(setup["cfg"], setup["sd"], native=True)
+    w = torch.from_numpy(make_window(seed=31, n_scans=3, n_az=128)).cuda()
+    ref_logits, ref_pred = eng.forward_window(w, native=False)
+    eng._arena = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")  # far too small: several growth rounds
+    logits, pred = eng.forward_window(w)
+    assert eng._arena.numel() > (1 << 20)
+    assert torch.equal(logits, ref_logits) and torch.equal(pred["pred_boxes"], ref_pred["pred_boxes"])
+    past_only = w[w[:, 4] < 0].contiguous()  # no current scan
+    for native in (True, False):
+        with pytest.raises(ValueError):
+            eng.forward_window(past_only, native=native)
+        with pytest.raises(ValueError):
+            eng.forward_window(w.double(), native=native)
+        with pytest.raises(ValueError):
+            eng.forward_window(w[:, :4].contiguous(), native=native)
+    far = w.clone()
+    far[0, 0] = 1e6  # beyond the +-32768-voxel key window
+    for native in (True, False):
+        with pytest.raises(ValueError):
+            eng.forward_window(far, native=native)
+    logits2, _ = eng.forward_window(w)  # the engine is still usable afterwards
+    assert torch.equal(logits2, ref_logits)
+
+
 def test_n1_window_and_no_detection_checkpoint(setup):
     """cfg-1 shape: a single scan (N=1, t==0 only) and the default head bias (no detections)."""
     from insmos_amd import params as P
