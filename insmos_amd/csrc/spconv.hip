@@ -2,21 +2,17 @@
 //
 //   out[o, :] = epilogue( sum_k  in[nbr[k][o], :] @ W[k]  + bias )
 //
-// One wave owns 16*JT consecutive output rows x 16*COT output channels (tile shape picked per layer
-// so that the launch keeps >= 2 waves per SIMD whenever the layer is big enough).  Taps are walked
-// through a per-16-row-group ACTIVE-TAP BITMASK produced when the neighbour table is built
-// (insmos_build_nbr): a tap none of the tile's rows uses is never touched, and inside a tile each
-// 16-row group skips its own empty taps (rows are Morton-/raster-ordered, so occupancy is spatially
-// coherent: ~50 % of (64-row tile, tap) slots and ~60 % of (16-row group, tap) slots are empty on
-// LiDAR data).  Because the active-tap list is known up front the loop is software-pipelined:
-// neighbour indices are fetched two taps ahead, the gathered rows (B fragments: one 16-byte load
-// per lane per 16-channel chunk; four 16-lane groups cover one 64-byte sector of a row) and the
-// pre-packed weight A fragments (one coalesced 16-byte load per lane, L1/L2 resident) one step
-// ahead of the MFMAs that consume them.  All offsets are 32-bit so loads use SGPR-base + VGPR-offset
-// addressing.  The contraction runs on v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain),
-// i = output channel, j = output row, so lane (g, j) ends up with 4 consecutive channels of row j and
-// the epilogue (folded-BN bias, ReLU, residual / channel-pair residual) is one float4 store per tile.
-// No atomics, no scatter: results are deterministic.
+// One wave owns 16*JT consecutive output rows x 16*COT output channels (tile shape picked per layer, see
+// insmos_sparse_conv).  Taps are walked through a per-16-row-group ACTIVE-TAP BITMASK produced when the neighbour
+// table is built: a tap none of the tile's rows uses is never touched (rows are Morton-/raster-ordered, so occupancy is
+// spatially coherent: ~60 % of (16-row group, tap) slots are empty on LiDAR data).  Because the active-tap list is known
+// up front the loop is software-pipelined: neighbour indices are fetched two taps ahead, the gathered rows (B
+// fragments: one 16-byte load per lane per 16-channel chunk; four 16-lane groups cover one 64-byte sector of a row)
+// and the pre-packed weight A fragments (one coalesced 16-byte load per lane, L1/L2 resident) one or two work items
+// ahead of the MFMAs that consume them.  All offsets are 32-bit so loads use SGPR-base + VGPR-offset addressing.  The
+// contraction runs on v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain), i = output channel, j = output row,
+// so lane (g, j) ends up with 4 consecutive channels of row j and the epilogue (folded-BN bias, ReLU, residual /
+// channel-pair residual) is one float4 store per tile.  No atomics, no scatter: results are deterministic.
 //
 // Fragment maps (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
 // B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4) + reg][j = lane&15].  The contraction index of MFMA

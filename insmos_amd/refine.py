@@ -36,7 +36,7 @@ class InstanceRefiner:
     """One sequence; call frame() in scan order."""
 
     def __init__(self, poses_lidar, learning_map_inv=None, device="cuda:0", ground_offset=0.03, quirk_exact=True):
-        self.lib = _lib.load()
+        self.lib = None  # loaded on first frame(): the decision logic alone (decide()) needs no GPU
         self.poses = np.asarray(poses_lidar, dtype=np.float64)
         self.inv = dict(learning_map_inv or {0: 0, 1: 9, 2: 251})
         self.device = torch.device(device)
@@ -48,7 +48,7 @@ class InstanceRefiner:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _decide(self, boxes, labels, stats):
+    def decide(self, boxes, labels, stats):
         """Host part of refine.py:205-293 for one frame -> per-box label override (0 = keep, 1 = static, 2 = moving)."""
         f = self.frame_idx
         car = (labels == 1) & (stats[:, 0] > 0)
@@ -102,6 +102,8 @@ class InstanceRefiner:
     def frame(self, scan, boxes, labels, mos_raw, conf):
         """scan (N, >=3) fp32 device; boxes (K,7), labels (K,) host or device; mos_raw (N,) predicted .label values
         (device, any integer dtype); conf (N,2) device or None.  Returns refined labels (N,) int32 on the device."""
+        if self.lib is None:
+            self.lib = _lib.load()
         dev, lib, st = self.device, self.lib, self._stream()
         scan = scan.to(dev, torch.float32)
         if scan.stride(1) != 1:
@@ -129,13 +131,13 @@ class InstanceRefiner:
             _lib.check(lib.insmos_instance_stats(index.data_ptr(), 3, 0, mos.data_ptr(),
                                                  conf_d.data_ptr() if conf_d is not None else None, N, K,
                                                  stats.data_ptr(), st), "insmos_instance_stats")
-            decision = self._decide(boxes_h, labels_h, stats.cpu().numpy())
+            decision = self.decide(boxes_h, labels_h, stats.cpu().numpy())
             if decision.any():
                 dec_d = torch.from_numpy(decision).to(dev)
                 _lib.check(lib.insmos_instance_relabel(index.data_ptr(), 3, 0, dec_d.data_ptr(), N, K, mos.data_ptr(), st),
                            "insmos_instance_relabel")
         else:
-            self._decide(boxes_h, labels_h, np.zeros((K, 3), np.int32))
+            self.decide(boxes_h, labels_h, np.zeros((K, 3), np.int32))
         self.frame_idx += 1
         out = mos.clone()  # refine.py:129-133
         for k, v in self.inv.items():

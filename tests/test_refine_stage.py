@@ -44,6 +44,34 @@ def test_oracle_refine_vs_reference_script(golden_dir):
     assert (9, 251) in both and (251, 9) in both  # ... in both directions
 
 
+def test_host_decisions_vs_reference_script(golden_dir):
+    """InstanceRefiner.decide (the vectorised host part of the product) fed with oracle-computed instance statistics
+    reproduces the reference script's labels -- the GPU kernels only supply index / stats / relabel around it."""
+    from insmos_amd.refine import InstanceRefiner
+    g = np.load(os.path.join(golden_dir, "refine.npz"))
+    for tag in SEQS:
+        ref = InstanceRefiner(_poses(g, tag), device="cpu")
+        for i in range(int(g[tag + "n_frames"])):
+            k = tag + "f%02d_" % i
+            boxes, labels = g[k + "boxes"], g[k + "labels"]
+            sem = (g[k + "mos"] & 0xFFFF).astype(np.int32)
+            mos = np.where(sem == 251, 2, np.where(sem == 9, 1, sem)).astype(np.int32)
+            conf = g[k + "conf"] if i >= 9 else np.zeros((len(mos), 2), np.float32)
+            index = R.points_in_instance_boxes(g[k + "scan"], np.hstack([boxes, labels[:, None].astype(np.float32)]), 3, 0.03)
+            stats = np.zeros((len(labels), 3), np.int32)
+            for b in range(len(labels)):
+                sel = index[:, 0] == b + 1
+                stats[b] = [sel.sum(), (mos[sel] == 2).sum(), (conf[sel, 1] >= 0.00001).sum()]
+            dec = ref.decide(boxes, labels, stats)
+            ref.frame_idx += 1
+            for b in np.nonzero(dec)[0]:
+                mos[index[:, 0] == b + 1] = dec[b]
+            out = mos.copy()
+            for kk, v in {0: 0, 1: 9, 2: 251}.items():
+                out[mos == kk] = v
+            np.testing.assert_array_equal(out, g[k + "refined"], err_msg=k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("quirk", [1, 0])
 def test_points_in_instance_boxes_kernel(golden_dir, quirk):
