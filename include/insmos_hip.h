@@ -261,8 +261,10 @@ int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const
  *   coords (n,4) [b,z,y,x] int voxel indices of the level; the test uses the integer index (no +0.5).
  *   quirk_exact != 0 reproduces the order-dependent early-skip of Array_Index.cpp:48-51.
  *   onehot: fp32 written into out[i*ld_out + c], c < ncls (+ zero pad up to pad_to columns).
- *   scratch: (20*max_boxes + n) i32 device scratch (per-box first-hit voxel + box in voxel units).
+ *   scratch: insmos_boxes_to_onehot_scratch_ints(max_boxes, n) i32 device scratch (per-box first-hit voxel, box in voxel
+ *   units, per-voxel class bits, per-voxel inside masks of each 64-box chunk).
  * ---------------------------------------------------------------------------------------------- */
+size_t insmos_boxes_to_onehot_scratch_ints(int max_boxes, int64_t n);
 int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
                            int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
                            float mult, const int32_t* coords, int64_t n, int ncls, int pad_to, int quirk_exact,
@@ -282,6 +284,9 @@ int insmos_build_current_points(const float* points, int ld_pts, const float* mo
                                 int ld_cur, void* stream);
 /* fill rows: dst[i*ld + c0 .. c0+c) = value  (constant input features 0.5, motionnet.py:29-32) */
 int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, float value, void* stream);
+/* dst[i][0:c] = src[i][0:c] for n rows (column-slice copy: the stride-1 instance one-hots feed two layers,
+ * spconv_unet.py:388,401) */
+int insmos_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t n, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Caller-side stages ("next" rows of the scope table; scripts/predict_mos.py).

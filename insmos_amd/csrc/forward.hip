@@ -422,7 +422,7 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     // ---- upsample fusion (spconv_unet.py:319-402)
     int64_t nvmax = 0;
     for (int l = 1; l <= 5; ++l) nvmax = std::max(nvmax, nv[l]);
-    int32_t* scratch = A.take<int32_t>((size_t)20 * g.post_max + nvmax);
+    int32_t* scratch = A.take<int32_t>(insmos_boxes_to_onehot_scratch_ints(g.post_max, nvmax));
     auto onehot = [&](int level, float mult, float* o, int ldo, int col) -> int {
         if (nv[level] == 0) return INSMOS_OK;
         return insmos_boxes_to_onehot(pb, pl, cnt_k, g.post_max, g.range, g.vs, 8.0f, mult, co[level], nv[level], ncls, 16,
@@ -472,7 +472,8 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     CK(conv("conv_up_instance_block_up2.0", ci1, V, 32, 0, &subm[1], V, catm1, 32, 0, nullptr, 0, 0, 0, 0, 1));
     CK(ur_block(1, 16, xc[1], 16, catm1, m1));
     CK(conv("conv_up_out.0.0", m1, V, 16, 0, &subm[1], V, ci0, 32, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(onehot(1, 8.0f, ci0, 32, 16));  // spconv_unet.py:401 re-uses the stride-1 instance features
+    // spconv_unet.py:401 re-uses the stride-1 instance features: same one-hots, copied instead of recomputed
+    CK(insmos_copy_cols(ci1 + 16, 32, ci0 + 16, 32, V, 16, s));
     CK(conv("conv_up_instance_block_up1.0", ci0, V, 32, 0, &subm[1], V, seg, 16, 0, nullptr, 0, 0, 0, 0, 1));
     CK(conv("mos_seg", seg, V, 16, 0, nullptr, V, vox_logits, 4, 0, nullptr, 0, 0, 0, 0, 0));
     CK(insmos_gather_rows(vox_logits, 4, 3, pcid, ncur, logits, 3, s));

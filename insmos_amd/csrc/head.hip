@@ -344,7 +344,8 @@ template <int PASS>
 __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__ m_dev, int max_boxes,
                                                      const int32_t* __restrict__ coords, int64_t n,
                                                      int32_t* __restrict__ first, const BoxVox* __restrict__ bv, int ncls,
-                                                     int quirk, uint32_t* __restrict__ vbits) {
+                                                     int quirk, uint32_t* __restrict__ vbits,
+                                                     unsigned long long* __restrict__ inside) {
     const int m = min(m_dev[0], max_boxes);
     const int b0 = blockIdx.y * 64;
     if (b0 >= m) return;
@@ -368,26 +369,37 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
     if (j >= n) return;
     const int4 q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
     const int x = q.w, y = q.z, z = q.y;
-    unsigned bits = 0;
-    for (int i = 0; i < nb; ++i) {
-        const BoxVox& bb = sb[i];
-        if (PASS == 0) {
-            if (inside_box(bb, x, y, z)) atomicMin(&first[b0 + i], (int)j);
-        } else {
+    // PASS 0 does the geometry once and leaves, per voxel and 64-box chunk, the bitmask of boxes containing it;
+    // PASS 1 only walks those bits (typically none) and applies the order-dependent rule.
+    unsigned long long* im = inside + (size_t)blockIdx.y * (size_t)n + j;
+    if (PASS == 0) {
+        unsigned long long hit = 0ull;
+        for (int i = 0; i < nb; ++i) {
+            if (inside_box(sb[i], x, y, z)) {
+                hit |= 1ull << i;
+                atomicMin(&first[b0 + i], (int)j);
+            }
+        }
+        *im = hit;
+    } else {
+        unsigned long long hit = *im;
+        unsigned bits = 0;
+        while (hit) {
+            const int i = __ffsll(hit) - 1;
+            hit &= hit - 1;
+            const BoxVox& bb = sb[i];
             const int f = sfirst[i];
-            if (f == 0x7fffffff) continue;  // box contains no voxel at all
             if (quirk && j != f) {
                 // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
-                // extend[d] from the first-hit voxel.  Rows before the first hit are not inside by definition.
-                if (j < f) continue;
+                // extend[d] from the first-hit voxel.  (f <= j here: f is the smallest inside row.)
                 if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
                     z > (sfz[i] + bb.e[2]) || z < (sfz[i] - bb.e[2]))
                     continue;
             }
-            if (bb.label > 0 && bb.label <= ncls && inside_box(bb, x, y, z)) bits |= 1u << (bb.label - 1);
+            if (bb.label > 0 && bb.label <= ncls) bits |= 1u << (bb.label - 1);
         }
+        if (bits) atomicOr(&vbits[j], bits);
     }
-    if (PASS == 1 && bits) atomicOr(&vbits[j], bits);
 }
 
 __global__ void k_onehot_write(const uint32_t* __restrict__ vbits, int64_t n, int ncls, int pad_to,
@@ -585,6 +597,11 @@ extern "C" int insmos_gather_preds(const float* cand_boxes, const float* cand_sc
     return INSMOS_OK;
 }
 
+extern "C" size_t insmos_boxes_to_onehot_scratch_ints(int max_boxes, int64_t n) {
+    if (max_boxes <= 0 || n < 0) return 0;
+    return 20 * (size_t)max_boxes + (((size_t)n + 1) & ~(size_t)1) + 2 * (size_t)n * (size_t)cdiv(max_boxes, 64);
+}
+
 extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
                                       int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
                                       float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
@@ -604,15 +621,16 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     int32_t* first = scratch;
     BoxVox* bv = (BoxVox*)(scratch + ((max_boxes + 3) & ~3));  // 16 ints per box
     uint32_t* vbits = (uint32_t*)(scratch + 20 * (size_t)max_boxes);
+    unsigned long long* inside = (unsigned long long*)(scratch + 20 * (size_t)max_boxes + (((size_t)n + 1) & ~(size_t)1));
     ProfScope ps(KK_ONEHOT, s);
     HIP_TRY(hipMemsetAsync(vbits, 0, (size_t)n * sizeof(uint32_t), s));
     INSMOS_LAUNCH(k_onehot_boxes, dim3(cdiv(max_boxes, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
                        max_boxes, P, first, bv);
     dim3 grid(cdiv(n, 256), cdiv(max_boxes, 64));
     INSMOS_LAUNCH(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
-                       quirk_exact, vbits);
+                       quirk_exact, vbits, inside);
     INSMOS_LAUNCH(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
-                       quirk_exact, vbits);
+                       quirk_exact, vbits, inside);
     INSMOS_LAUNCH(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;

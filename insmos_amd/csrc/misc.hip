@@ -97,6 +97,15 @@ __global__ void k_output_stage(const float* __restrict__ logits, int ld, int64_t
     labels[i] = lut[best];
 }
 
+
+__global__ void k_copy_cols(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int64_t n, int c) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t i = t / c;
+    const int k = (int)(t % c);
+    dst[i * ld_dst + k] = src[i * ld_src + k];
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -170,6 +179,16 @@ extern "C" int insmos_output_stage(const float* logits, int ld, int64_t n, int n
     ProfScope ps(KK_GATHER_ROWS, s);
     INSMOS_LAUNCH(k_output_stage, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, ld, n, ncls, ignore_mask, lut, labels,
                        confidence);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t n, int c, void* stream) {
+    if (n <= 0 || c <= 0) return INSMOS_OK;
+    if (!src || !dst || ld_src < c || ld_dst < c) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_FILL, s);
+    INSMOS_LAUNCH(k_copy_cols, dim3(cdiv(n * c, 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, n, c);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

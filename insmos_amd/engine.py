@@ -571,7 +571,7 @@ class Engine:
                                 keep=keep, spatial_features_2d=upf, bev=bev)
 
         # ---- upsample fusion (spconv_unet.py:319-402)
-        scratch = E((20 * self.post_max + max(nv.values()),), torch.int32)
+        scratch = E((int(lib.insmos_boxes_to_onehot_scratch_ints(self.post_max, max(nv.values()))),), torch.int32)
         lo = np.array(self.range[0:3], dtype=np.float32)
 
         def onehot(level, mult, out, ld, col):
@@ -617,7 +617,8 @@ class Engine:
         m1 = ur_block(1, 16, xc[1], 16, catm1)
         ci0 = E((V, 32))
         self.conv(L["conv_up_out.0.0"], m1, 16, subm[1], V, ci0, 32, relu_post=1)
-        onehot(1, 8.0, ci0, 32, 16)  # spconv_unet.py:401 re-uses the stride-1 instance features
+        # spconv_unet.py:401 re-uses the stride-1 instance features: same one-hots, copied instead of recomputed
+        _lib.check(lib.insmos_copy_cols(ci1.data_ptr() + 4 * 16, 32, ci0.data_ptr() + 4 * 16, 32, V, 16, st), "insmos_copy_cols")
         seg = E((V, 16))
         self.conv(L["conv_up_instance_block_up1.0"], ci0, 32, subm[1], V, seg, 16, relu_post=1)
         vox_logits = E((V, 4))

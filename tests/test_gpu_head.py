@@ -127,7 +127,7 @@ def _onehot(coords_xyz, boxes8, quirk=True):
     pl = torch.zeros(mb, dtype=torch.int64, device=D); pl[:m] = dev(boxes8[:, 7].astype(np.int64))
     nd = torch.tensor([m, 0, 0, 0], dtype=torch.int32, device=D)
     out = torch.full((n, 16), -1.0, device=D)
-    scratch = torch.empty(20 * mb + n, dtype=torch.int32, device=D)
+    scratch = torch.empty(int(lib().insmos_boxes_to_onehot_scratch_ints(mb, n)), dtype=torch.int32, device=D)
     lo = np.zeros(3, np.float32); vs = np.ones(3, np.float32)
     dc4 = dev(c4)
     _lib.check(lib().insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), nd.data_ptr(), mb, hp(lo), hp(vs), 1.0, 1.0,
