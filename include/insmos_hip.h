@@ -244,6 +244,9 @@ int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, int max_n, 
                            int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 /* pairwise rotated BEV IoU (a: na x 7, b: nb x 7) -> out (na, nb); parity probe for the predicate. */
 int insmos_iou_bev(const float* a, int na, const float* b, int nb, float* out, void* stream);
+/* pairwise 3D IoU (iou3d_nms_utils.boxes_iou3d_gpu, iou3d_nms_utils.py:28-61: BEV overlap x height overlap over the
+ * union volume) -- the eval-only kernel behind generate_recall_record (post_process.py:67-110). */
+int insmos_iou3d(const float* a, int na, const float* b, int nb, float* out, void* stream);
 
 /* Gather the kept candidates into the final prediction arrays (post_process.py:204-216):
  * pred_boxes (post_max,7) fp32, pred_scores (post_max) fp32, pred_labels (post_max) i64. */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "insmos_nms_ws_bytes": (c_sz, [c_int]),
     "insmos_nms_rotated_bev": (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_iou_bev": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_iou3d": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_gather_preds": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "insmos_boxes_to_onehot_scratch_ints": (c_sz, [c_int, c_i64]),
     "insmos_copy_cols": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp]),

@@ -188,6 +188,20 @@ __global__ void k_iou_bev(const float* __restrict__ a, int na, const float* __re
     out[t] = iou_bev_dev(A, B);
 }
 
+// boxes_iou3d_gpu (iou3d_nms_utils.py:28-61), fp32 op for op: BEV overlap x height overlap / union volume
+__global__ void k_iou3d(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float* __restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)na * nb) return;
+    int i = (int)(t / nb), j = (int)(t % nb);
+    float A[7], B[7];
+    for (int d = 0; d < 7; ++d) { A[d] = a[i * 7 + d]; B[d] = b[j * 7 + d]; }
+    const float a_max = A[2] + A[5] / 2, a_min = A[2] - A[5] / 2, b_max = B[2] + B[5] / 2, b_min = B[2] - B[5] / 2;
+    const float ov_h = fmaxf(fminf(a_max, b_max) - fmaxf(a_min, b_min), 0.f);
+    const float ov3 = box_overlap_bev(A, B) * ov_h;
+    const float vol_a = A[3] * A[4] * A[5], vol_b = B[3] * B[4] * B[5];
+    out[t] = ov3 / fmaxf(vol_a + vol_b - ov3, 1e-6f);
+}
+
 // 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed).
 // 256 threads: wave w owns rows rb*64 + 16w .. +15, lane = column; the 64-bit mask word of a row is the
 // wave ballot.  Pairs whose circumscribed circles (grown by the corner MARGIN of check_in_box2d) are
@@ -582,6 +596,16 @@ extern "C" int insmos_iou_bev(const float* a, int na, const float* b, int nb, fl
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_IOU, s);
     INSMOS_LAUNCH(k_iou_bev, dim3(cdiv((int64_t)na * nb, 128)), dim3(128), 0, s, a, na, b, nb, out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_iou3d(const float* a, int na, const float* b, int nb, float* out, void* stream) {
+    if (na <= 0 || nb <= 0) return INSMOS_OK;
+    if (!a || !b || !out) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(KK_IOU, s);
+    INSMOS_LAUNCH(k_iou3d, dim3(cdiv((int64_t)na * nb, 128)), dim3(128), 0, s, a, na, b, nb, out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

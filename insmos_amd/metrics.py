@@ -62,3 +62,43 @@ def all_gather_confusion(cm):
 def shard_indices(n_items, rank, world_size):
     """Window i goes to rank i % world_size (predict_mos.py:103-106 windows are independent)."""
     return list(range(rank, n_items, world_size))
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_iou3d_gpu (models/bbox_post_process/iou3d_nms_utils.py:28-61): (N,7) x (M,7) CUDA fp32 ->
+    (N, M) 3D IoU, one HIP kernel (insmos_iou3d)."""
+    a = boxes_a[:, :7].contiguous().float()
+    b = boxes_b[:, :7].contiguous().float()
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if a.shape[0] and b.shape[0]:
+        st = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        _lib.check(_lib.load().insmos_iou3d(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), st), "insmos_iou3d")
+    return out
+
+
+def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+    """models/post_process.py:67-110: how many ground-truth boxes have a prediction (and, if present, a ROI) above each
+    3D-IoU threshold.  Needs data_dict['gt_boxes'] (B, G, >=7) with trailing all-zero padding rows; accumulates into and
+    returns `recall_dict` like the reference."""
+    if data_dict is None or "gt_boxes" not in data_dict:
+        return recall_dict
+    rois = data_dict["rois"][batch_index] if "rois" in data_dict else None
+    gt = data_dict["gt_boxes"][batch_index]
+    if len(recall_dict) == 0:
+        recall_dict = {"gt": 0}
+        for t in thresh_list:
+            recall_dict["roi_%s" % str(t)] = 0
+            recall_dict["rcnn_%s" % str(t)] = 0
+    nz = (gt.sum(dim=1) != 0).nonzero()  # the reference walks back over all-zero padding rows (never past row 0)
+    k = int(nz[-1]) if len(nz) else 0
+    gt = gt[:k + 1]
+    if gt.shape[0] > 0:
+        iou_rcnn = boxes_iou3d(box_preds, gt) if box_preds.shape[0] > 0 else None
+        iou_roi = boxes_iou3d(rois, gt) if rois is not None else None
+        for t in thresh_list:
+            if iou_rcnn is not None:
+                recall_dict["rcnn_%s" % str(t)] += int((iou_rcnn.max(dim=0)[0] > t).sum().item())
+            if iou_roi is not None:
+                recall_dict["roi_%s" % str(t)] += int((iou_roi.max(dim=0)[0] > t).sum().item())
+        recall_dict["gt"] += int(gt.shape[0])
+    return recall_dict

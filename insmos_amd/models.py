@@ -19,6 +19,7 @@ import torch
 import yaml
 
 from .engine import Engine
+from .metrics import generate_recall_record
 from . import params as P
 
 _DEFAULT_SEMANTIC = {
@@ -110,9 +111,11 @@ class InsMOS_Model:
                 for t in (logits, *pred.values()):
                     t.record_stream(cur)  # allocated on a worker stream, consumed on the caller's
         preb_dict_list, recall_dict_list, preb_mos_lable_list = [], [], []
-        for logits, pred in results:
+        thresh = self.cfg["MODEL"]["POST_PROCESSING"].get("RECALL_THRESH_LIST", [0.3, 0.5, 0.7])
+        for b, (logits, pred) in zip(list_batch_dict, results):
             preb_dict_list.append([pred])
-            recall_dict_list.append({})
+            # post_process.py:216-220: recall bookkeeping only when the batch carries ground-truth boxes (validation)
+            recall_dict_list.append(generate_recall_record(pred["pred_boxes"], {}, 0, b, thresh) if "gt_boxes" in b else {})
             preb_mos_lable_list.append(logits)
         return preb_dict_list, recall_dict_list, preb_mos_lable_list
 

@@ -315,3 +315,11 @@ void co_points_in_instance_boxes(const float* pts, int64_t N, int ld, const floa
         }
     }
 }
+
+/* pairwise rotated-rectangle overlap AREA (iou3d_cpu.cpp:128-206 box_overlap; the CUDA twin is
+ * iou3d_nms_kernel.cu:105-196) -- the `boxes_overlap_bev_gpu` half of boxes_iou3d_gpu (iou3d_nms_utils.py:28-61) */
+void co_overlap_bev_matrix(const float* a, int na, const float* b, int nb, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[(int64_t)i * nb + j] = co_box_overlap(a + i * 7, b + j * 7);
+}

@@ -4,7 +4,8 @@ box like any built .so).  Never copies reference sources into the repo.
 
   * models/utils/src/Array_Index.cpp              -> oracle/_ref/Array_Index<ext>.so (pybind11 module;
                                                      built WITHOUT -fopenmp, as the shipped setup.py:49-55 does)
-  * models/bbox_post_process/src/iou3d_cpu.cpp    -> oracle/_ref/libref_iou3d.so (+ oracle/ref_bind.cpp shim)
+  * models/bbox_post_process/src/iou3d_cpu.cpp    -> oracle/_ref/libref_iou3d.so (+ oracle/ref_bind.cpp shim) and
+                                                     oracle/_ref/libref_overlap.so (+ ref_bind_overlap.cpp: box_overlap)
     needs <cuda.h>/<cuda_runtime_api.h>: the genuine NVIDIA headers shipped inside this image's
     triton wheel are used (no stand-in headers are written).
 TEST INFRASTRUCTURE ONLY.
@@ -47,6 +48,21 @@ def build(verbose=True):
             torch._C._GLIBCXX_USE_CXX11_ABI)] + incs + [
             os.path.join(REF, "models/bbox_post_process/src/iou3d_cpu.cpp"), os.path.join(HERE, "ref_bind.cpp"),
             "-L" + libdir, "-Wl,-rpath," + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-o", i_out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    o_out = os.path.join(OUT, "libref_overlap.so")
+    if not os.path.exists(o_out):
+        import triton
+        cuda_inc = os.path.join(os.path.dirname(triton.__file__), "backends", "nvidia", "include")
+        incs = ["-I" + p for p in cpp_extension.include_paths()] + ["-I" + py_inc, "-I" + cuda_inc]
+        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+        # the shim and the reference file form one translation unit (box_overlap is `inline` there)
+        cmd = ["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-w", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(
+            torch._C._GLIBCXX_USE_CXX11_ABI)] + incs + [
+            "-include", os.path.join(REF, "models/bbox_post_process/src/iou3d_cpu.cpp"),
+            os.path.join(HERE, "ref_bind_overlap.cpp"), "-L" + libdir, "-Wl,-rpath," + libdir, "-ltorch", "-ltorch_cpu",
+            "-lc10", "-o", o_out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

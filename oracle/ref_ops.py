@@ -44,6 +44,7 @@ def _lib():
         L.co_nbr_lookup.argtypes = [vp, i64, vp, vp, i64, vp]
         L.co_sparse_conv.argtypes = [vp, i64, i32, vp, i32, i64, vp, i32, vp, i64]
         L.co_iou_bev_matrix.argtypes = [vp, i32, vp, i32, vp]
+        L.co_overlap_bev_matrix.argtypes = [vp, i32, vp, i32, vp]
         L.co_nms_bev.argtypes = [vp, i32, f32, vp]
         L.co_nms_bev.restype = i32
         L.co_boxes_to_onehot.argtypes = [vp, i64, vp, i32, vp, i32, i32]
@@ -379,6 +380,53 @@ def iou_bev_matrix(a, b):
     out = np.empty((len(a), len(b)), dtype=np.float32)
     _lib().co_iou_bev_matrix(_p(a), len(a), _p(b), len(b), _p(out))
     return out
+
+
+def overlap_bev_matrix(a, b):
+    a = np.ascontiguousarray(a[:, :7], dtype=np.float32)
+    b = np.ascontiguousarray(b[:, :7], dtype=np.float32)
+    out = np.empty((len(a), len(b)), dtype=np.float32)
+    _lib().co_overlap_bev_matrix(_p(a), len(a), _p(b), len(b), _p(out))
+    return out
+
+
+def iou3d_matrix(a, b):
+    """iou3d_nms_utils.boxes_iou3d_gpu (models/bbox_post_process/iou3d_nms_utils.py:28-61), fp32 op for op."""
+    a = np.ascontiguousarray(a[:, :7], dtype=np.float32)
+    b = np.ascontiguousarray(b[:, :7], dtype=np.float32)
+    two = np.float32(2)
+    a_max, a_min = (a[:, 2] + a[:, 5] / two)[:, None], (a[:, 2] - a[:, 5] / two)[:, None]
+    b_max, b_min = (b[:, 2] + b[:, 5] / two)[None, :], (b[:, 2] - b[:, 5] / two)[None, :]
+    ov_h = np.maximum(np.minimum(a_max, b_max) - np.maximum(a_min, b_min), np.float32(0))
+    ov3 = overlap_bev_matrix(a, b) * ov_h
+    vol_a = (a[:, 3] * a[:, 4] * a[:, 5])[:, None]
+    vol_b = (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return (ov3 / np.maximum(vol_a + vol_b - ov3, np.float32(1e-6))).astype(np.float32)
+
+
+def generate_recall_record(box_preds, recall_dict, gt_boxes, thresh_list, rois=None):
+    """models/post_process.py:67-110 for one batch item (gt_boxes: (G, >=7), trailing all-zero rows are padding)."""
+    recall_dict = dict(recall_dict)
+    if len(recall_dict) == 0:
+        recall_dict = {"gt": 0}
+        for t in thresh_list:
+            recall_dict["roi_%s" % str(t)] = 0
+            recall_dict["rcnn_%s" % str(t)] = 0
+    gt = np.asarray(gt_boxes, dtype=np.float32)
+    k = len(gt) - 1
+    while k > 0 and gt[k].sum() == 0:
+        k -= 1
+    gt = gt[:k + 1]
+    if gt.shape[0] > 0:
+        iou_rcnn = iou3d_matrix(box_preds[:, :7], gt[:, :7]) if len(box_preds) > 0 else np.zeros((0, len(gt)), np.float32)
+        iou_roi = iou3d_matrix(rois[:, :7], gt[:, :7]) if rois is not None else None
+        for t in thresh_list:
+            if iou_rcnn.shape[0] > 0:
+                recall_dict["rcnn_%s" % str(t)] += int((iou_rcnn.max(0) > t).sum())
+            if iou_roi is not None:
+                recall_dict["roi_%s" % str(t)] += int((iou_roi.max(0) > t).sum())
+        recall_dict["gt"] += int(gt.shape[0])
+    return recall_dict
 
 
 def nms_bev(boxes_sorted, thresh):

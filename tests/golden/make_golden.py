@@ -15,6 +15,8 @@ Sources exercised (all importable / compilable here):
                     iou3d_nms_cuda.nms_gpu stubbed by the compiled reference IoU + the greedy reduce
   height_compression.npz  models/backbones_2d/height_compression.py:24-31 view semantics (on a dense tensor)
   poses.npz         dataloader/utils.py:10-68 load_poses / load_calib / load_files on tiny hand-written files
+  recall.npz        models/bbox_post_process/iou3d_nms_utils.py:28-61 boxes_iou3d_gpu + models/post_process.py:67-110
+                    generate_recall_record, as written (BEV overlap from the compiled reference box_overlap)
   refine.npz        scripts/refine.py:133-302 main() run as-is on a synthetic 12-frame sequence -> refined labels
   instance_index.npz  models/utils/src/Array_Index.cpp:85-154 find_point_in_instance_bbox_with_yaw (compiled), the
                     point -> instance-id map of scripts/refine.py:196 (yawed boxes, ground offset, label 0, orders)
@@ -295,6 +297,51 @@ def instance_index_golden():
     np.savez(os.path.join(HERE, "instance_index.npz"), **cases)
 
 
+def recall_golden():
+    """boxes_iou3d_gpu (iou3d_nms_utils.py:28-61) and generate_recall_record (post_process.py:67-110) run as written, with
+    the CUDA extension's boxes_overlap_bev_gpu answered by the reference's own CPU box_overlap (oracle/_ref/libref_overlap.so)
+    and torch.cuda.FloatTensor mapped to the CPU tensor type for the duration of the call (no GPU in this container)."""
+    ov = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_overlap.so"))
+    ov.ref_boxes_overlap_bev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+
+    def overlap_stub(a, b, out):
+        a = np.ascontiguousarray(a.numpy(), np.float32)
+        b = np.ascontiguousarray(b.numpy(), np.float32)
+        o = np.zeros((len(a), len(b)), np.float32)
+        ov.ref_boxes_overlap_bev(a.ctypes.data, len(a), b.ctypes.data, len(b), o.ctypes.data)
+        out.copy_(torch.from_numpy(o))
+        return 1
+
+    stub = types.ModuleType("models.bbox_post_process.iou3d_nms_cuda")
+    stub.boxes_overlap_bev_gpu = overlap_stub
+    stub.boxes_iou_bev_gpu = lambda a, b, out: out.copy_(torch.from_numpy(ref_iou(a.numpy(), b.numpy())))
+    stub.nms_gpu = stub.nms_normal_gpu = None
+    sys.modules["models.bbox_post_process.iou3d_nms_cuda"] = stub
+    import importlib
+    saved_ft = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    try:
+        utils = importlib.import_module("models.bbox_post_process.iou3d_nms_utils")
+        pp = importlib.import_module("models.post_process")
+        rng = np.random.default_rng(21)
+        gt = rand_boxes(rng, 25, spread=25.0)
+        pred = np.concatenate([gt[:18] + rng.normal(0, 0.15, (18, 7)).astype(np.float32), rand_boxes(rng, 30, spread=25.0)])
+        pred[:, 3:6] = np.abs(pred[:, 3:6])
+        gt_pad = np.concatenate([np.hstack([gt, rng.integers(1, 4, (25, 1)).astype(np.float32)]), np.zeros((7, 8), np.float32)])
+        iou = utils.boxes_iou3d_gpu(torch.from_numpy(pred), torch.from_numpy(gt)).numpy()
+        thr = [0.3, 0.5, 0.7]
+        rd = dict(pp.generate_recall_record(torch.from_numpy(pred), {}, 0, {"gt_boxes": torch.from_numpy(gt_pad)[None]}, thr))
+        # (the reference accumulates into the dict it is given: hand it a copy to keep the first result)
+        rd2 = pp.generate_recall_record(torch.from_numpy(pred[:5]), dict(rd), 0, {"gt_boxes": torch.from_numpy(gt_pad)[None]}, thr)
+        rd0 = pp.generate_recall_record(torch.zeros((0, 7)), {}, 0, {"gt_boxes": torch.from_numpy(gt_pad)[None]}, thr)
+    finally:
+        torch.cuda.FloatTensor = saved_ft
+    np.savez(os.path.join(HERE, "recall.npz"), pred=pred, gt=gt, gt_pad=gt_pad, iou3d=iou, thresh=np.array(thr),
+             rd_keys=np.array(sorted(rd)), rd_vals=np.array([rd[k] for k in sorted(rd)]),
+             rd2_vals=np.array([rd2[k] for k in sorted(rd2)]), rd0_vals=np.array([rd0[k] for k in sorted(rd0)]))
+    print("recall golden:", rd, rd2, rd0)
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -431,6 +478,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 
 
 if __name__ == "__main__":
+    if "--recall-only" in sys.argv:
+        recall_golden()
+        sys.exit(0)
     if "--refine-only" in sys.argv:
         refine_golden()
         sys.exit(0)
@@ -441,3 +491,4 @@ if __name__ == "__main__":
     instance_index_golden()
     if "--instance-only" not in sys.argv and "--poses-only" not in sys.argv:
         refine_golden()
+        recall_golden()

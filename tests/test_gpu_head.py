@@ -169,3 +169,21 @@ def test_confusion_and_gather(golden_dir):
     _lib.check(lib().insmos_gather_rows(src.data_ptr(), 4, 3, idx.data_ptr(), 5, out.data_ptr(), 3, stream()), "gather")
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), [[12, 13, 14], [0, 0, 0], [0, 1, 2], [36, 37, 38], [0, 0, 0]])
+
+
+def test_iou3d_kernel_and_recall_record(golden_dir):
+    """insmos_iou3d vs the reference's boxes_iou3d_gpu values; generate_recall_record counts equal the reference's."""
+    import os
+    from insmos_amd.metrics import boxes_iou3d, generate_recall_record
+    g = np.load(os.path.join(golden_dir, "recall.npz"))
+    pred, gt, gt_pad = (torch.from_numpy(g[k]).cuda() for k in ("pred", "gt", "gt_pad"))
+    np.testing.assert_allclose(boxes_iou3d(pred, gt).cpu().numpy(), g["iou3d"], rtol=1e-5, atol=1e-6)
+    thr = [float(t) for t in g["thresh"]]
+    keys = list(g["rd_keys"])
+    rd = generate_recall_record(pred, {}, 0, {"gt_boxes": gt_pad[None]}, thr)
+    assert [rd[k] for k in keys] == g["rd_vals"].tolist()
+    rd2 = generate_recall_record(pred[:5], dict(rd), 0, {"gt_boxes": gt_pad[None]}, thr)
+    assert [rd2[k] for k in keys] == g["rd2_vals"].tolist()
+    rd0 = generate_recall_record(torch.zeros((0, 7), device="cuda"), {}, 0, {"gt_boxes": gt_pad[None]}, thr)
+    assert [rd0[k] for k in keys] == g["rd0_vals"].tolist()
+    assert generate_recall_record(pred, {}, 0, {}, thr) == {}

@@ -97,3 +97,17 @@ def test_bev_backbone_torch_reference(golden_dir):
     c, b = R.center_decode(cls, box, 4, [0.1, 0.1, 0.1], [-60, -50])
     np.testing.assert_allclose(c, g["cls"][0], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(b, g["boxes"][0], rtol=1e-4, atol=1e-4)
+
+
+def test_iou3d_and_recall_record(golden_dir):
+    """boxes_iou3d_gpu / generate_recall_record restated vs the reference functions themselves (make_golden.recall_golden)."""
+    g = G(golden_dir, "recall.npz")
+    np.testing.assert_array_equal(R.iou3d_matrix(g["pred"], g["gt"]), g["iou3d"])
+    assert int((g["iou3d"] > 0.3).sum()) > 10
+    thr = [float(t) for t in g["thresh"]]
+    rd = R.generate_recall_record(g["pred"], {}, g["gt_pad"], thr)
+    assert [rd[k] for k in sorted(rd)] == g["rd_vals"].tolist() and sorted(rd) == list(g["rd_keys"])
+    rd2 = R.generate_recall_record(g["pred"][:5], rd, g["gt_pad"], thr)
+    assert [rd2[k] for k in sorted(rd2)] == g["rd2_vals"].tolist()
+    rd0 = R.generate_recall_record(np.zeros((0, 7), np.float32), {}, g["gt_pad"], thr)
+    assert [rd0[k] for k in sorted(rd0)] == g["rd0_vals"].tolist()
