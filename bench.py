@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- scans/sec of the InsMOS inference hot path on MI355X.
 
-A "step" is one full forward of one window (N=10 pose-aligned scans, ~1.2 M points in, per-point MOS
-logits + boxes out) with the input already resident in HBM: BASELINE.json configs[1] (synthetic S0,
-SURVEY.md Appendix A).  One process per GPU; ranks hold different windows (seed = rank) and there is
-no data-path collective -- the only exchange is the all_gather of the 3x3 confusion counters at the
+A "step" is one forward() over a batch of `--windows-per-step` different windows (each N=10 pose-aligned
+scans, ~1.2 M points in, per-point MOS logits + boxes out) with the inputs already resident in HBM:
+BASELINE.json configs[1] (synthetic S0); the model keeps several of them in flight.
+One process per GPU; ranks hold different windows (seeds rank*W ..) and there is no data-path collective -- the only exchange is the all_gather of the 3x3 confusion counters at the
 end of the timed region.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -19,12 +19,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per window in flight (see insmos_amd/__init__.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBS = 8000.0
@@ -87,7 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-az", type=int, default=472)
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
-    ap.add_argument("--windows-per-step", type=int, default=6, help="batch items of one forward() = one step")
+    ap.add_argument("--windows-per-step", type=int, default=8, help="batch items of one forward() = one step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

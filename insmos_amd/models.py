@@ -40,7 +40,7 @@ def load_semantic_config(cfg):
 class InsMOS_Model:
     """models/models.py:269-376 (test mode).
 
-    The reference walks the batch list sequentially (models/models.py:313).  Here up to `windows_in_flight` batch items
+    The reference walks the batch list sequentially (models/models.py:313).  Here up to `windows_in_flight` (4) batch items
     are processed concurrently -- one host thread, HIP stream and arena each, all sharing the device weights -- because
     one window leaves a large part of an MI355X idle (few tiles per SIMD in the deep layers, count read-backs).  The
     results are the same bits as the sequential walk; the caller's current stream waits for all of them."""
@@ -54,7 +54,7 @@ class InsMOS_Model:
         self.device = device
         self.quirk_exact = quirk_exact
         if windows_in_flight is None:
-            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "3"))
+            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "4"))
         self.windows_in_flight = max(1, int(windows_in_flight))
         self._engine = None
         self._workers = None  # (engines, streams, executor)
