@@ -55,6 +55,12 @@ int insmos_prof_read_union(int kind_id, double* union_ms_host, double* sum_ms_ho
  *          +-32768-voxel key window (must be 0).
  * ---------------------------------------------------------------------------------------------- */
 size_t insmos_quantize4d_ws_bytes(int64_t n);
+/* insmos_quantize4d_ex: compact_keys != 0 sorts 40-bit keys (5 radix passes instead of 8) that order exactly like the
+ * canonical ones when every point lies within +-2048 voxels and 16 time steps; counts[3] = #points outside that box --
+ * if it is not 0 the outputs are invalid and the call must be repeated with compact_keys = 0. */
+int insmos_quantize4d_ex(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
+                         int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                         size_t ws_bytes, int compact_keys, void* stream);
 int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
                       int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
                       size_t ws_bytes, void* stream);

@@ -21,6 +21,7 @@ SIGNATURES = {
     "insmos_prof_read_union": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "insmos_quantize4d_ws_bytes": (c_sz, [c_i64]),
     "insmos_quantize4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_quantize4d_ex": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "insmos_level_down4d_ws_bytes": (c_sz, [c_i64]),
     "insmos_level_down4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_nbr_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),

@@ -60,6 +60,21 @@ static inline int bits_for(uint64_t maxval) {
 // ---------------------------------------------------------------------------------------------------
 // 4D quantise (motionnet.py:22-36)
 // ---------------------------------------------------------------------------------------------------
+// COMPACT SORT KEYS.  A LiDAR window lives within +-2048 voxels and 16 time steps, where the 64-bit canonical key has
+// only 40 informative bits: bits 15..11 of a biased coordinate are a function of its sign.  ckey = (t+15) << 36 |
+// (z>=0, y>=0, x>=0) << 33 | morton3(low 11 bits) orders exactly like the canonical key, so the radix sort runs 5 byte
+// passes instead of 8; the canonical key is rebuilt after the sort.  Points outside that box are counted (counts[3]):
+// the caller then repeats the call with the full-width sort.
+__host__ __device__ __forceinline__ uint64_t ckey_expand(uint64_t c) {
+    const uint64_t bt = (c >> 36) - 15 + INSMOS_KEY_BIAS;
+    const uint64_t m = c & 0x1FFFFFFFFull;
+    const uint64_t ux = (((c >> 33) & 1) ? 0x8000u : 0x7800u) | compact3(m);
+    const uint64_t uy = (((c >> 34) & 1) ? 0x8000u : 0x7800u) | compact3(m >> 1);
+    const uint64_t uz = (((c >> 35) & 1) ? 0x8000u : 0x7800u) | compact3(m >> 2);
+    return (bt << 48) | spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+}
+
+template <bool COMPACT>
 __global__ void k_quant_keys(const float* __restrict__ pts, int64_t n, int ld, float q0, float q1, float q2, float q3,
                              uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int32_t* __restrict__ tflag,
                              int32_t* __restrict__ counts) {
@@ -68,8 +83,20 @@ __global__ void k_quant_keys(const float* __restrict__ pts, int64_t n, int ld, f
     const float* p = pts + i * ld;
     // IEEE fp32 division then floor -- exactly torch.div(point_cloud, quantization) + ME's floor
     float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;
-    uint64_t k = key4_encode((int)floorf(fx), (int)floorf(fy), (int)floorf(fz), (int)floorf(ft));
+    const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz), t = (int)floorf(ft);
+    uint64_t k = key4_encode(x, y, z, t);
     if (k == INSMOS_INVALID_KEY) atomicAdd(&counts[2], 1);
+    if (COMPACT && k != INSMOS_INVALID_KEY) {
+        if (x < -2048 || x > 2047 || y < -2048 || y > 2047 || z < -2048 || z > 2047 || t < -15 || t > 0) {
+            atomicAdd(&counts[3], 1);
+            k = INSMOS_INVALID_KEY;
+        } else {
+            const uint64_t lx = (uint64_t)(x + INSMOS_KEY_BIAS) & 0x7FF, ly = (uint64_t)(y + INSMOS_KEY_BIAS) & 0x7FF,
+                           lz = (uint64_t)(z + INSMOS_KEY_BIAS) & 0x7FF;
+            k = ((uint64_t)(t + 15) << 36) | ((uint64_t)(z >= 0) << 35) | ((uint64_t)(y >= 0) << 34) |
+                ((uint64_t)(x >= 0) << 33) | spread3(lx) | (spread3(ly) << 1) | (spread3(lz) << 2);
+        }
+    }
     keys[i] = k;
     idx[i] = (uint32_t)i;
     tflag[i] = (ft == 0.0f) ? 1 : 0;
@@ -84,6 +111,7 @@ __global__ void k_head_flags(const uint64_t* __restrict__ keys, int64_t n, int s
     flag[i] = f;
 }
 
+template <bool COMPACT>
 __global__ void k_quant_scatter(const uint64_t* __restrict__ keys_s, const uint32_t* __restrict__ idx_s,
                                 const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, int64_t n,
                                 uint64_t* __restrict__ vkeys, int32_t* __restrict__ vcoords,
@@ -94,6 +122,7 @@ __global__ void k_quant_scatter(const uint64_t* __restrict__ keys_s, const uint3
     int vid = scan[i] - 1;
     if (k != INSMOS_INVALID_KEY) {
         if (flag[i]) {
+            if (COMPACT) k = ckey_expand(k);
             vkeys[vid] = k;
             int x, y, z, t;
             key4_decode(k, x, y, z, t);
@@ -516,9 +545,9 @@ extern "C" size_t insmos_quantize4d_ws_bytes(int64_t n) {
     return pad256(N * 8) * 2 + pad256(N * 4) * 6 + (st > sc ? st : sc) + 1024;
 }
 
-extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
-                                 int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
-                                 size_t ws_bytes, void* stream) {
+extern "C" int insmos_quantize4d_ex(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
+                                    int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                                    size_t ws_bytes, int compact_keys, void* stream) {
     if (n <= 0 || ld_pts < 5 || !points || !quant_host) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     Bump b(ws, ws_bytes);
@@ -539,10 +568,16 @@ extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, con
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_QUANT_KEYS, s);
-        INSMOS_LAUNCH(k_quant_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
-                           quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
+        if (compact_keys)
+            INSMOS_LAUNCH(k_quant_keys<true>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
+        else
+            INSMOS_LAUNCH(k_quant_keys<false>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
     }
-    int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, 64, s);
+    // (invalid keys are all-ones: they sort last in either width as long as no valid compact key is 2^40 - 1, and a
+    //  window with invalid keys is rejected by the caller anyway)
+    int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, compact_keys ? 40 : 64, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
@@ -552,8 +587,12 @@ extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, con
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
-        INSMOS_LAUNCH(k_quant_scatter, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
-                           counts);
+        if (compact_keys)
+            INSMOS_LAUNCH(k_quant_scatter<true>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
+                          counts);
+        else
+            INSMOS_LAUNCH(k_quant_scatter<false>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, keys, coords, inverse,
+                          counts);
     }
     rc = inclusive_scan_i32(tmp, sc, tflag, tscan, N, s);
     if (rc) return rc;
@@ -563,6 +602,13 @@ extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, con
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* quant_host, uint64_t* keys,
+                                 int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    return insmos_quantize4d_ex(points, n, ld_pts, quant_host, keys, coords, inverse, cur_index, counts, ws, ws_bytes, 0,
+                                stream);
 }
 
 extern "C" size_t insmos_level_down4d_ws_bytes(int64_t n) {

@@ -157,8 +157,13 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
         const float quant[4] = {g.vs[0], g.vs[0], g.vs[0], g.dt};
-        CK(insmos_quantize4d(pts, N, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb, s));
+        // 40-bit sort keys first; the full-width sort only for windows wider than +-2048 voxels / 16 time steps
+        CK(insmos_quantize4d_ex(pts, N, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb, 1, s));
         CK(read_counts(counts, hc, 4, s));
+        if (hc[3] != 0) {
+            CK(insmos_quantize4d_ex(pts, N, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb, 0, s));
+            CK(read_counts(counts, hc, 4, s));
+        }
         A.off = mark;  // the sort workspace is dead once the counts are back
     }
     n[0] = hc[0];

@@ -292,10 +292,13 @@ class Engine:
         cur_index = self._empty((N,), torch.int32)
         counts = self._empty((4,), torch.int32)
         quant = np.array([self.vs[0], self.vs[0], self.vs[0], self.dt], dtype=np.float32)
-        _lib.check(lib.insmos_quantize4d(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
-                                         inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
-                                         ws.numel(), st), "insmos_quantize4d")
-        c = counts.cpu().numpy()
+        for compact in (1, 0):  # 40-bit sort keys first; the full-width sort only for windows wider than +-2048 voxels
+            _lib.check(lib.insmos_quantize4d_ex(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
+                                                inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), compact, st), "insmos_quantize4d_ex")
+            c = counts.cpu().numpy()
+            if int(c[3]) == 0:
+                break
         n0, ncur = int(c[0]), int(c[1])
         if int(c[2]) != 0:
             raise ValueError(f"{int(c[2])} points fall outside the +-32768-voxel key window")

@@ -78,6 +78,52 @@ def test_quantize_levels_and_tables(window, engine):
     np.testing.assert_array_equal(cur[:, :4].cpu().numpy(), window[window[:, 4] == 0][:, :4])
 
 
+def test_quantize_compact_and_full_width_keys(window, engine):
+    """The 40-bit sort keys order exactly like the canonical 64-bit ones; windows beyond +-2048 voxels / 16 time steps
+    fall back to the full-width sort.  Both against the oracle."""
+    from gpu_util import dev, u64
+    import ctypes
+    from insmos_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    base = window[rng.permutation(len(window))[:60000]].copy()
+    wide = base.copy()
+    wide[:3, 0] = [250.0, -230.5, 1000.0]   # 2500 / -2305 / 10000 voxels
+    wide[3:6, 4] = [-1.7, -2.0, -3.1]         # t = -17, -20, -31
+    corner = base.copy()
+    corner[:4, :3] = [[204.79, 204.79, 204.79], [-204.8, -204.8, -204.8], [204.79, -204.8, 0.0], [-0.05, 0.05, -0.05]]
+    corner[4:6, 4] = [-1.5, -1.45]            # t = -15 (inside the compact box)
+    for name, w, expect_fallback in (("base", base, False), ("corner", corner, False), ("wide", wide, True)):
+        pts = dev(w)
+        N = len(w)
+        c_ref, k_ref, inv_ref = R.me_quantize(np.concatenate([w[:, :3], w[:, 4:5]], 1), [0.1, 0.1, 0.1, 0.1])
+        ws = torch.empty(int(lib.insmos_quantize4d_ws_bytes(N)), dtype=torch.uint8, device="cuda")
+        quant = np.array([0.1, 0.1, 0.1, 0.1], np.float32)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for compact in (1, 0):
+            keys = torch.empty(N, dtype=torch.int64, device="cuda")
+            coords = torch.empty((N, 4), dtype=torch.int32, device="cuda")
+            inverse = torch.empty(N, dtype=torch.int32, device="cuda")
+            cur = torch.empty(N, dtype=torch.int32, device="cuda")
+            counts = torch.empty(4, dtype=torch.int32, device="cuda")
+            _lib.check(lib.insmos_quantize4d_ex(pts.data_ptr(), N, 5, quant.ctypes.data_as(ctypes.c_void_p), keys.data_ptr(),
+                                                coords.data_ptr(), inverse.data_ptr(), cur.data_ptr(), counts.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), compact, st), "quantize")
+            c = counts.cpu().numpy()
+            assert c[2] == 0
+            if compact and expect_fallback:
+                assert c[3] == 6, (name, c)
+                continue
+            assert c[3] == 0 and c[0] == len(k_ref), (name, compact, c)
+            np.testing.assert_array_equal(u64(keys[:c[0]]), k_ref, err_msg=f"{name} compact={compact}")
+            np.testing.assert_array_equal(coords[:c[0]].cpu().numpy(), c_ref)
+            np.testing.assert_array_equal(inverse.cpu().numpy(), inv_ref)
+    # and through the engine: the wide window takes the fallback transparently
+    engine.motionnet(dev(wide))
+    c_ref, k_ref, _ = R.me_quantize(np.concatenate([wide[:, :3], wide[:, 4:5]], 1), [0.1, 0.1, 0.1, 0.1])
+    np.testing.assert_array_equal(u64(engine._me_tables["keys"][0]), k_ref)
+
+
 @pytest.mark.parametrize("max_voxels", [100000, 1500])
 def test_voxelize_and_3d_tables(window, engine, max_voxels):
     from gpu_util import dev
