@@ -339,6 +339,33 @@ int insmos_instance_relabel(const int32_t* index, int ncls, int col, const int32
                             int32_t* mos, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training-step pieces (models/models.py:61-98 training_step, models/loss.py:20-34) -- the
+ * gradients behind `loss.backward()` for the sparse convolutions and the MOS loss.  A FIRST SLICE: BatchNorm in
+ * training mode, the CenterHead losses / target assignment and the optimiser are not here yet.
+ *   insmos_pack_weights_device: insmos_pack_weights_host on the device, from taps (K, cin_real, cout_real) that change
+ *     every step; transpose = 1 packs W[k]^T (a layer mapping cout_real-wide rows to cin_real-wide ones: pass
+ *     cin = padded cout_real, cout = cin_real) and mirror_taps = 1 reads tap K-1-k -- together the d/dx layer of a
+ *     submanifold convolution on its own table; strided layers pass their transposed table (down <-> inverse) instead.
+ *   insmos_sparse_conv_backward_weight: dW[k] = sum_o x[nbr[k][o]]^T (x) dy[o]  (K, cin, cout) fp32, deterministic
+ *     (slab partial sums + fixed-order reduction; ws from *_ws_floats); accumulate != 0 adds to dW.
+ *   insmos_col_sum: out[c] (+)= sum_rows a[row][c] (bias gradient), fixed order.
+ *   insmos_mos_loss: MOSLoss.compute_loss -- ignored classes -> -inf, softmax, log(clamp(., 1e-8)), weighted NLL:
+ *     loss_sums[0] = sum_i w[gt_i] * -log p_i, loss_sums[1] = sum_i w[gt_i] (loss = [0] / [1], device floats);
+ *     grad (n, ncls) = d loss / d logits (already divided by loss_sums[1]) or null.
+ * ---------------------------------------------------------------------------------------------- */
+int insmos_pack_weights_device(const float* taps, int K, int cin_real, int cout_real, int cin, int cout, int transpose,
+                               int mirror_taps, float* packed, void* stream);
+size_t insmos_sparse_conv_backward_weight_ws_floats(int64_t n_out, int K, int cin, int cout);
+int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, int ld_x, int cin, const float* dy, int ld_dy, int cout,
+                                       const int32_t* nbr, int K, int64_t n_out, float* dw, int accumulate, float* ws,
+                                       void* stream);
+size_t insmos_col_sum_ws_floats(int64_t n, int c);
+int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* out, int accumulate, float* ws, void* stream);
+size_t insmos_mos_loss_ws_floats(int64_t n);
+int insmos_mos_loss(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
+                    const float* class_weights, float* loss_sums, float* grad, int ld_grad, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native window runner -- InsMOS_Model.forward(list, 'test') for ONE batch item (models/models.py:313-364) as one
  * foreign call: the same operator sequence insmos_amd/engine.py issues step by step (MotionNet -> voxelise ->
  * UNetV2 encoder -> BEV CenterHead -> NMS -> instance-fused decoder -> per-point logits), driven from C++ so that

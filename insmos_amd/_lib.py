@@ -67,6 +67,14 @@ SIGNATURES = {
     "insmos_points_in_instance_boxes": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_int, c_int, c_vp, c_vp, c_vp]),
     "insmos_instance_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     "insmos_instance_relabel": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "insmos_pack_weights_device": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "insmos_sparse_conv_backward_weight_ws_floats": (c_sz, [c_i64, c_int, c_int, c_int]),
+    "insmos_sparse_conv_backward_weight": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_int,
+                                                   c_vp, c_vp]),
+    "insmos_col_sum_ws_floats": (c_sz, [c_i64, c_int]),
+    "insmos_col_sum": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp]),
+    "insmos_mos_loss_ws_floats": (c_sz, [c_i64]),
+    "insmos_mos_loss": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "insmos_ctx_create": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "insmos_ctx_destroy": (c_int, [c_vp]),
     "insmos_forward_window": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp]),

@@ -1,0 +1,144 @@
+"""Training-step building blocks on MI355X (SURVEY.md 8f rank 2 -- a FIRST SLICE, see include/insmos_hip.h):
+
+  * SparseConvFunction / sparse_conv(): the output-stationary sparse convolution as a torch.autograd.Function whose
+    forward AND backward are HIP kernels -- d/dx is the same MFMA kernel on the transposed table with transposed taps,
+    d/dW a slab-reduction kernel, d/db a column sum.  Deterministic: no atomics anywhere (the reference's libraries
+    scatter-add their gradients with atomics).
+  * mos_loss(): MOSLoss.compute_loss (models/loss.py:20-34) with its gradient from one kernel.
+
+torch is used for what it is here for -- device memory, streams and the autograd tape that chains these nodes
+(models/models.py:61-98 calls loss.backward() on such a tape).  BatchNorm in training mode, the CenterHead losses /
+target assignment and the optimiser step are NOT part of this slice.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .engine import _padc
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _packed(lib, taps, cin_pad, cout_store, transpose, mirror, st):
+    """Device-packed MFMA A fragments of `taps` (K, cin_real, cout_real) (or of their transpose)."""
+    K, ci, co = taps.shape
+    cr_in, cr_out = (co, ci) if transpose else (ci, co)
+    assert cin_pad >= cr_in and cout_store >= cr_out
+    n = int(lib.insmos_packed_weight_floats(K, cin_pad, cout_store))
+    packed = torch.empty(n, dtype=torch.float32, device=taps.device)
+    _lib.check(lib.insmos_pack_weights_device(taps.data_ptr(), K, ci, co, cin_pad, cout_store, 1 if transpose else 0,
+                                              1 if mirror else 0, packed.data_ptr(), st), "insmos_pack_weights_device")
+    return packed
+
+
+def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st):
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
+                                      None, K, n_out, packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
+                                      0, 0, 0, 0, st), "insmos_sparse_conv")
+    return out
+
+
+def _pad_cols(x, c):
+    """Rows padded to the channel widths the conv kernel accepts (4, 8, multiple of 16); zero columns are neutral."""
+    if x.shape[1] == c and x.stride(1) == 1 and x.stride(0) % 4 == 0:
+        return x
+    y = torch.zeros((x.shape[0], c), dtype=torch.float32, device=x.device)
+    y[:, :x.shape[1]] = x
+    return y
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """y[o] = sum_k x[nbr[k][o]] @ taps[k] + bias.  nbr (K, n_out) int32 (-1 = no neighbour); nbr_t (K, n_in) int32 is the
+    TRANSPOSED table (nbr_t[k][i] = o  <=>  nbr[k][o] = i); for a submanifold layer pass nbr_t=None and the layer's own
+    table is used with mirrored taps (nbr_t[k] = nbr[K-1-k])."""
+
+    @staticmethod
+    def forward(ctx, x, taps, bias, nbr, nbr_t):
+        lib = _lib.load()
+        st = _stream(x.device)
+        K, cin, cout = taps.shape
+        n_in, n_out = x.shape[0], (nbr.shape[1] if nbr is not None else x.shape[0])
+        taps = taps.contiguous().float()
+        cin_pad = _padc(cin)
+        xp = _pad_cols(x.float(), cin_pad)
+        bias_pad = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=x.device)
+        if bias is not None:
+            bias_pad[:cout] = bias
+        y = _conv(lib, xp, n_in, cin_pad, nbr, K, n_out, _packed(lib, taps, cin_pad, cout, False, False, st), bias_pad, cout, st)
+        ctx.save_for_backward(xp, taps, nbr if nbr is not None else torch.empty(0), nbr_t if nbr_t is not None else torch.empty(0))
+        ctx.meta = (K, cin, cout, n_in, n_out, nbr is not None, nbr_t is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xp, taps, nbr, nbr_t = ctx.saved_tensors
+        K, cin, cout, n_in, n_out, has_nbr, has_t, has_bias = ctx.meta
+        st = _stream(dy.device)
+        dy = dy.contiguous().float()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[i] = sum_k dy[nbr_t[k][i]] @ taps[k]^T : the forward kernel, transposed taps, transposed table
+            cp = _padc(cout)
+            dyp = _pad_cols(dy, cp)
+            zero_b = torch.zeros((cin + 15) // 16 * 16, dtype=torch.float32, device=dy.device)
+            if not has_nbr:      # 1x1 / Linear
+                dx = _conv(lib, dyp, n_out, cp, None, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st)
+            elif has_t:
+                dx = _conv(lib, dyp, n_out, cp, nbr_t, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st)
+            else:                # submanifold: the layer's own table, taps mirrored
+                assert n_in == n_out
+                dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
+            ws = torch.empty(int(lib.insmos_sparse_conv_backward_weight_ws_floats(n_out, K, cin, cout)), dtype=torch.float32,
+                             device=dy.device)
+            _lib.check(lib.insmos_sparse_conv_backward_weight(xp.data_ptr(), n_in, xp.stride(0), cin, dy.data_ptr(), dy.stride(0),
+                                                              cout, nbr.data_ptr() if has_nbr else None, K, n_out, dw.data_ptr(),
+                                                              0, ws.data_ptr(), st), "insmos_sparse_conv_backward_weight")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+            ws = torch.empty(int(lib.insmos_col_sum_ws_floats(n_out, cout)) + 1, dtype=torch.float32, device=dy.device)
+            _lib.check(lib.insmos_col_sum(dy.data_ptr(), dy.stride(0), cout, n_out, db.data_ptr(), 0, ws.data_ptr(), st),
+                       "insmos_col_sum")
+        return dx, dw, db, None, None
+
+
+def sparse_conv(x, taps, bias, nbr, nbr_t=None):
+    return SparseConvFunction.apply(x, taps, bias, nbr, nbr_t)
+
+
+class MosLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt, class_weights, ignore_mask):
+        lib = _lib.load()
+        st = _stream(logits.device)
+        lg = logits.contiguous().float()
+        n, ncls = lg.shape
+        sums = torch.empty(2, dtype=torch.float32, device=lg.device)
+        grad = torch.empty((n, ncls), dtype=torch.float32, device=lg.device)
+        ws = torch.empty(int(lib.insmos_mos_loss_ws_floats(n)), dtype=torch.float32, device=lg.device)
+        _lib.check(lib.insmos_mos_loss(lg.data_ptr(), lg.stride(0), gt.contiguous().long().data_ptr(), n, ncls, int(ignore_mask),
+                                       class_weights.contiguous().float().data_ptr(), sums.data_ptr(), grad.data_ptr(), ncls,
+                                       ws.data_ptr(), st), "insmos_mos_loss")
+        ctx.save_for_backward(grad)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def mos_loss(logits, gt_labels, n_classes=3, ignore_index=(0,)):
+    """MOSLoss(n_classes, ignore_index).compute_loss(logits, gt_labels) (models/loss.py:10-34), differentiable."""
+    w = [0.0 if i in ignore_index else 1.0 for i in range(n_classes)]
+    w = torch.tensor([v / sum(w) for v in w], dtype=torch.float32, device=logits.device)
+    mask = 0
+    for c in ignore_index:
+        mask |= 1 << int(c)
+    return MosLossFunction.apply(logits, gt_labels, w, mask)

@@ -1,0 +1,251 @@
+// insmos_amd/csrc/train.hip -- first pieces of the training step (BASELINE.json configs[4]):
+// the gradients of the output-stationary sparse convolution and the MOS loss with its gradient.
+//
+//   forward   y[o]  = sum_k x[nbr[k][o]] @ W[k] + b                         (spconv.hip)
+//   d/dx      dx[i] = sum_k dy[nbrT[k][i]] @ W[k]^T   -- the SAME kernel on the transposed table with transposed taps
+//                     (for a submanifold layer nbrT[k] = nbr[K-1-k]; for strided layers the engine already builds the
+//                     transposed table: down <-> inverse, dn <-> up), packed on the device by insmos_pack_weights_device
+//   d/dW      dW[k] = sum_o x[nbr[k][o]]^T (x) dy[o]  -- k_conv_dw below: per (row chunk, tap, channel tile) partial sums
+//                     in LDS-staged 64-row slabs, then a fixed-order reduction over the chunks (deterministic, no atomics:
+//                     the reference's libraries scatter-add with atomics)
+//   d/db      db    = sum_o dy[o]                     -- k_col_sum (two stages, fixed order)
+//   loss      MOSLoss.compute_loss (models/loss.py:20-34): ignored classes -> -inf, softmax, log(clamp(., 1e-8)),
+//             class-weighted NLL; k_mos_loss writes the per-point terms and d loss / d logits, reduced in fixed order.
+#include "common.h"
+
+namespace insmos {
+
+// ---- device-side weight packing (the host twin is insmos_pack_weights_host; training repacks every step) ----
+__global__ void k_pack_weights(const float* __restrict__ taps, int K, int cin_real, int cout_real, int cin, int cout, int nblk,
+                               int ntile, int n16, int has8, int transpose, int mirror, float* __restrict__ packed) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)K * nblk * ntile * 256;
+    if (t >= total) return;
+    const int s = (int)(t & 3), l = (int)((t >> 2) & 63);
+    int64_t r = t >> 8;
+    const int tile = (int)(r % ntile);
+    r /= ntile;
+    const int blk = (int)(r % nblk);
+    const int k = (int)(r / nblk);
+    const int g = l >> 4, i = l & 15;
+    int c0, width;
+    if (blk < n16) { c0 = blk * 16; width = 4; }
+    else if (has8 && blk == n16) { c0 = n16 * 16; width = 2; }
+    else { c0 = n16 * 16 + (has8 ? 8 : 0); width = 1; }
+    float v = 0.f;
+    if (s < width) {
+        const int ci = c0 + width * g + s, co = tile * 16 + i;  // channel in / out of the PACKED layer
+        const int ks = mirror ? K - 1 - k : k;
+        if (!transpose) {
+            if (ci < cin_real && co < cout_real) v = taps[((int64_t)ks * cin_real + ci) * cout_real + co];
+        } else if (ci < cout_real && co < cin_real) {
+            // the packed layer maps cout_real-wide rows back to cin_real-wide ones: its W'[ci][co] = taps[ks][co][ci]
+            v = taps[((int64_t)ks * cin_real + co) * cout_real + ci];
+        }
+    }
+    packed[t] = v;
+}
+
+// ---- dW: block = 256 threads = 16 x 16 (ci, co) pairs of a 16 x 16 channel tile, one tap, one chunk of rows ----
+constexpr int DW_SLAB = 64;
+__global__ void __launch_bounds__(256) k_conv_dw(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
+                                                  const int32_t* __restrict__ nbr, int64_t n_out, int cin, int cout,
+                                                  int rows_per_chunk, int n_co_tiles, float* __restrict__ partial, int K) {
+    __shared__ float xs[DW_SLAB][17], ds[DW_SLAB][17];
+    const int chunk = blockIdx.x, k = blockIdx.y;
+    const int ci_t = blockIdx.z / n_co_tiles, co_t = blockIdx.z % n_co_tiles;
+    const int tid = threadIdx.x, ci = tid >> 4, co = tid & 15;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    const int64_t r_end = min(r_begin + rows_per_chunk, n_out);
+    float acc = 0.f;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += DW_SLAB) {
+        // stage: thread (row = tid >> 2, quarter = tid & 3) loads 4 channels of x (gathered) and of dy
+        const int rr = tid >> 2, q = tid & 3;
+        const int64_t o = r0 + rr;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < r_end) {
+            const int idx = nbr ? nbr[(int64_t)k * n_out + o] : (int)o;
+            const int c = ci_t * 16 + q * 4, d = co_t * 16 + q * 4;
+            if (idx >= 0) {
+                const float* xp = x + (int64_t)idx * ld_x + c;
+                xv.x = c + 0 < cin ? xp[0] : 0.f; xv.y = c + 1 < cin ? xp[1] : 0.f;
+                xv.z = c + 2 < cin ? xp[2] : 0.f; xv.w = c + 3 < cin ? xp[3] : 0.f;
+                const float* dp = dy + o * ld_dy + d;
+                dv.x = d + 0 < cout ? dp[0] : 0.f; dv.y = d + 1 < cout ? dp[1] : 0.f;
+                dv.z = d + 2 < cout ? dp[2] : 0.f; dv.w = d + 3 < cout ? dp[3] : 0.f;
+            }
+        }
+        xs[rr][q * 4 + 0] = xv.x; xs[rr][q * 4 + 1] = xv.y; xs[rr][q * 4 + 2] = xv.z; xs[rr][q * 4 + 3] = xv.w;
+        ds[rr][q * 4 + 0] = dv.x; ds[rr][q * 4 + 1] = dv.y; ds[rr][q * 4 + 2] = dv.z; ds[rr][q * 4 + 3] = dv.w;
+        __syncthreads();
+#pragma unroll 16
+        for (int j = 0; j < DW_SLAB; ++j) acc = fmaf(xs[j][ci], ds[j][co], acc);  // rows in ascending order: deterministic
+        __syncthreads();
+    }
+    const int gci = ci_t * 16 + ci, gco = co_t * 16 + co;
+    if (gci < cin && gco < cout) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + gco] = acc;
+}
+
+__global__ void k_conv_dw_reduce(const float* __restrict__ partial, int n_chunks, int64_t per_chunk, float* __restrict__ dw,
+                                 int accumulate) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_chunk) return;
+    float acc = accumulate ? dw[t] : 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += partial[(int64_t)c * per_chunk + t];  // fixed order
+    dw[t] = acc;
+}
+
+// ---- column sums (bias gradient): stage 1 per 1024-row block, stage 2 over the blocks ----
+__global__ void __launch_bounds__(256) k_col_sum(const float* __restrict__ a, int ld, int c, int64_t n, int rows_per_block,
+                                                  float* __restrict__ partial) {
+    __shared__ float sm[256];
+    const int col = blockIdx.y, tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n);
+    float acc = 0.f;
+    for (int64_t r = r0 + tid; r < r1; r += 256) acc += a[r * ld + col];
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] += sm[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) partial[(int64_t)blockIdx.x * c + col] = sm[0];
+}
+
+// ---- MOSLoss (models/loss.py:20-34) ----
+// term[i] = -w[g] * log(max(softmax_g, 1e-8)), wsum[i] = w[g]; grad[i][c] = d(sum term)/d logit[i][c] (unnormalised)
+__global__ void k_mos_loss(const float* __restrict__ logits, int ld, const int64_t* __restrict__ gt, int64_t n, int ncls,
+                           unsigned ignore_mask, const float* __restrict__ w, float* __restrict__ term,
+                           float* __restrict__ wsum, float* __restrict__ grad, int ld_grad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* z = logits + i * ld;
+    float m = -INFINITY;
+    for (int c = 0; c < ncls; ++c)
+        if (!((ignore_mask >> c) & 1u)) m = fmaxf(m, z[c]);
+    float den = 0.f;
+    for (int c = 0; c < ncls; ++c)
+        if (!((ignore_mask >> c) & 1u)) den += expf(z[c] - m);
+    const int g = (int)gt[i];
+    const bool g_live = g >= 0 && g < ncls && !((ignore_mask >> g) & 1u);
+    const float pg = g_live ? expf(z[g] - m) / den : 0.f;   // softmax of an ignored class is exactly 0
+    const float wg = (g >= 0 && g < ncls) ? w[g] : 0.f;
+    term[i] = -wg * logf(fmaxf(pg, 1e-8f));
+    wsum[i] = wg;
+    if (grad) {
+        // d term / d z_c = -wg * [pg >= 1e-8] * (1/pg) * pg * (delta_gc - p_c) = -wg * [pg >= 1e-8] * (delta_gc - p_c)
+        const float live = (g_live && pg >= 1e-8f) ? wg : 0.f;
+        for (int c = 0; c < ncls; ++c) {
+            float v = 0.f;
+            if (!((ignore_mask >> c) & 1u)) {
+                const float pc = expf(z[c] - m) / den;
+                v = -live * ((c == g ? 1.f : 0.f) - pc);
+            }
+            grad[i * ld_grad + c] = v;
+        }
+    }
+}
+
+__global__ void k_scale_rows(float* __restrict__ a, int ld, int c, int64_t n, const float* __restrict__ sums) {
+    // grad /= sum of weights (sums[1]); loss = sums[0] / sums[1] is finished on the host side of the call
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    const float inv = 1.0f / sums[1];
+    a[(t / c) * ld + (t % c)] *= inv;
+}
+
+}  // namespace insmos
+
+using namespace insmos;
+
+static void chunking_dev(int cin, int& n16, int& has8, int& has4) {
+    n16 = cin / 16;
+    int rem = cin % 16;
+    has8 = (rem & 8) ? 1 : 0;
+    has4 = (rem & 4) ? 1 : 0;
+}
+
+extern "C" int insmos_pack_weights_device(const float* taps, int K, int cin_real, int cout_real, int cin, int cout,
+                                          int transpose, int mirror_taps, float* packed, void* stream) {
+    if (!taps || !packed || K <= 0 || cin % 4 != 0 || cin < (transpose ? cout_real : cin_real) ||
+        cout < (transpose ? cin_real : cout_real))
+        return INSMOS_EINVAL;
+    int n16, h8, h4;
+    chunking_dev(cin, n16, h8, h4);
+    const int nblk = n16 + h8 + h4, ntile = (cout + 15) / 16;
+    const int64_t total = (int64_t)K * nblk * ntile * 256;
+    hipStream_t s = (hipStream_t)stream;
+    INSMOS_LAUNCH(k_pack_weights, dim3(cdiv(total, 256)), dim3(256), 0, s, taps, K, cin_real, cout_real, cin, cout, nblk, ntile,
+                  n16, h8, transpose, mirror_taps, packed);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+static int dw_chunks(int64_t n_out, int* rows_per_chunk) {
+    int rpc = 4096;
+    int64_t nch = (n_out + rpc - 1) / rpc;
+    *rows_per_chunk = rpc;
+    return (int)nch;
+}
+
+extern "C" size_t insmos_sparse_conv_backward_weight_ws_floats(int64_t n_out, int K, int cin, int cout) {
+    int rpc;
+    return (size_t)dw_chunks(n_out, &rpc) * (size_t)K * (size_t)cin * (size_t)cout;
+}
+
+extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, int ld_x, int cin, const float* dy, int ld_dy,
+                                                  int cout, const int32_t* nbr, int K, int64_t n_out, float* dw,
+                                                  int accumulate, float* ws, void* stream) {
+    if (n_out <= 0) return INSMOS_OK;
+    if (!x || !dy || !dw || !ws || cin <= 0 || cout <= 0 || K <= 0 || ld_x < cin || ld_dy < cout || n_in <= 0 ||
+        (!nbr && (K != 1 || n_in < n_out)))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int rpc;
+    const int nch = dw_chunks(n_out, &rpc);
+    const int n_ci = (cin + 15) / 16, n_co = (cout + 15) / 16;
+    ProfScope ps(KK_SPARSE_CONV, s);
+    INSMOS_LAUNCH(k_conv_dw, dim3(nch, K, n_ci * n_co), dim3(256), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_co, ws,
+                  K);
+    const int64_t per = (int64_t)K * cin * cout;
+    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(per, 256)), dim3(256), 0, s, ws, nch, per, dw, accumulate);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_col_sum_ws_floats(int64_t n, int c) { return (size_t)((n + 1023) / 1024) * (size_t)c; }
+
+extern "C" int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* out, int accumulate, float* ws, void* stream) {
+    if (c <= 0) return INSMOS_OK;
+    if (!a || !out || !ws || ld < c || n < 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 1023) / 1024);
+    if (nb > 0) INSMOS_LAUNCH(k_col_sum, dim3(nb, c), dim3(256), 0, s, a, ld, c, n, 1024, ws);
+    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(c, 256)), dim3(256), 0, s, ws, nb, (int64_t)c, out, accumulate);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_mos_loss_ws_floats(int64_t n) { return (size_t)2 * (size_t)n + 2 * (size_t)((n + 1023) / 1024) + 16; }
+
+extern "C" int insmos_mos_loss(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
+                               const float* class_weights, float* loss_sums, float* grad, int ld_grad, float* ws,
+                               void* stream) {
+    if (n <= 0 || !logits || !gt || !class_weights || !loss_sums || !ws || ncls <= 0 || ncls > 32 || ld < ncls ||
+        (grad && ld_grad < ncls))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* term = ws;            // (n) then wsum (n): column-summed as an (n, 2)-strided pair via two calls
+    float* wsum = ws + n;
+    float* cs = ws + 2 * n;
+    ProfScope ps(KK_CONFUSION, s);
+    INSMOS_LAUNCH(k_mos_loss, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, ld, gt, n, ncls, ignore_mask, class_weights, term,
+                  wsum, grad, ld_grad);
+    int rc = insmos_col_sum(term, 1, 1, n, loss_sums, 0, cs, stream);       // loss_sums[0] = sum of weighted terms
+    if (rc) return rc;
+    rc = insmos_col_sum(wsum, 1, 1, n, loss_sums + 1, 0, cs, stream);       // loss_sums[1] = sum of weights
+    if (rc) return rc;
+    if (grad) INSMOS_LAUNCH(k_scale_rows, dim3(cdiv(n * ncls, 256)), dim3(256), 0, s, grad, ld_grad, ncls, n, loss_sums);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}

@@ -382,6 +382,43 @@ def iou_bev_matrix(a, b):
     return out
 
 
+def sparse_conv_backward(x, nbr, taps, dy):
+    """Gradients of y[o] = sum_k x[nbr[k][o]] @ taps[k] (float64 accumulation): (dx, dtaps, dbias)."""
+    x = np.asarray(x, np.float64)
+    dy = np.asarray(dy, np.float64)
+    taps = np.asarray(taps, np.float64)
+    K = taps.shape[0]
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(taps)
+    for k in range(K):
+        idx = np.arange(len(dy)) if nbr is None else np.asarray(nbr[k])
+        o = np.nonzero(idx >= 0)[0]
+        i = idx[o]
+        np.add.at(dx, i, dy[o] @ taps[k].T)
+        dw[k] = x[i].T @ dy[o]
+    return dx, dw, dy.sum(0)
+
+
+def mos_loss(logits, gt, n_classes=3, ignore_index=(0,)):
+    """models/loss.py:20-34 in float64 numpy: (loss, d loss / d logits)."""
+    z = np.asarray(logits, np.float64).copy()
+    g = np.asarray(gt, np.int64)
+    w = np.array([0.0 if c in ignore_index else 1.0 for c in range(n_classes)])
+    w = w / w.sum()
+    live = np.array([c not in ignore_index for c in range(n_classes)])
+    zl = np.where(live[None, :], z, -np.inf)
+    m = zl.max(1, keepdims=True)
+    e = np.where(live[None, :], np.exp(zl - m), 0.0)
+    p = e / e.sum(1, keepdims=True)
+    pg = p[np.arange(len(g)), g]
+    wg = w[g]
+    loss = float((-wg * np.log(np.maximum(pg, 1e-8))).sum() / wg.sum())
+    onehot = np.zeros_like(p)
+    onehot[np.arange(len(g)), g] = 1.0
+    grad = -(wg * (pg >= 1e-8))[:, None] * (onehot - p) * live[None, :] / wg.sum()
+    return loss, grad
+
+
 def overlap_bev_matrix(a, b):
     a = np.ascontiguousarray(a[:, :7], dtype=np.float32)
     b = np.ascontiguousarray(b[:, :7], dtype=np.float32)

@@ -15,6 +15,7 @@ Sources exercised (all importable / compilable here):
                     iou3d_nms_cuda.nms_gpu stubbed by the compiled reference IoU + the greedy reduce
   height_compression.npz  models/backbones_2d/height_compression.py:24-31 view semantics (on a dense tensor)
   poses.npz         dataloader/utils.py:10-68 load_poses / load_calib / load_files on tiny hand-written files
+  mos_loss.npz      models/loss.py:10-34 MOSLoss.compute_loss + its autograd gradient (pure torch, CPU)
   recall.npz        models/bbox_post_process/iou3d_nms_utils.py:28-61 boxes_iou3d_gpu + models/post_process.py:67-110
                     generate_recall_record, as written (BEV overlap from the compiled reference box_overlap)
   refine.npz        scripts/refine.py:133-302 main() run as-is on a synthetic 12-frame sequence -> refined labels
@@ -342,6 +343,23 @@ def recall_golden():
     print("recall golden:", rd, rd2, rd0)
 
 
+def mos_loss_golden():
+    """models/loss.py MOSLoss as written (pure torch, CPU) + autograd for d loss / d logits."""
+    from models.loss import MOSLoss
+    rng = np.random.default_rng(12)
+    n = 4000
+    logits = (rng.normal(size=(n, 3)) * 3).astype(np.float32)
+    logits[:50, 2] -= 40.0   # softmax of the true class underflows below the 1e-8 clamp for some of these
+    gt = rng.integers(0, 3, n)
+    gt[:50] = 2
+    lg = torch.from_numpy(logits.copy()).requires_grad_(True)
+    crit = MOSLoss(3, [0])
+    loss = crit.compute_loss(lg * 1.0, torch.from_numpy(gt))  # (* 1.0: the module overwrites its input's ignored column in place)
+    loss.backward()
+    np.savez(os.path.join(HERE, "mos_loss.npz"), logits=logits, gt=gt, loss=np.float32(loss.item()), grad=lg.grad.numpy())
+    print("mos_loss golden:", float(loss))
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -478,6 +496,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 
 
 if __name__ == "__main__":
+    if "--mosloss-only" in sys.argv:
+        mos_loss_golden()
+        sys.exit(0)
     if "--recall-only" in sys.argv:
         recall_golden()
         sys.exit(0)
@@ -492,3 +513,4 @@ if __name__ == "__main__":
     if "--instance-only" not in sys.argv and "--poses-only" not in sys.argv:
         refine_golden()
         recall_golden()
+        mos_loss_golden()

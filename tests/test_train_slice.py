@@ -1,0 +1,152 @@
+"""Training-step slice ("next" row 2): gradients of the sparse convolution and the MOS loss.  CPU: the oracle against the
+reference's MOSLoss + torch autograd (golden); GPU: the HIP kernels behind insmos_amd.autograd against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_ops as R
+
+
+def test_oracle_mos_loss_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mos_loss.npz"))
+    loss, grad = R.mos_loss(g["logits"], g["gt"])
+    assert abs(loss - float(g["loss"])) < 1e-6
+    np.testing.assert_allclose(grad, g["grad"], atol=1e-9)
+    assert (g["grad"][:50] == 0).all()  # the 1e-8 clamp is exercised
+
+
+def test_oracle_conv_backward_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    n_in, n_out, K, ci, co = 40, 30, 5, 3, 4
+    nbr = rng.integers(-1, n_in, size=(K, n_out)).astype(np.int32)
+    x, taps, dy = rng.normal(size=(n_in, ci)), rng.normal(size=(K, ci, co)), rng.normal(size=(n_out, co))
+    def f(xx, ww):  # float64 forward (the oracle's forward helpers work in fp32: too coarse for finite differences)
+        y = np.zeros((n_out, co))
+        for k in range(K):
+            o = np.nonzero(nbr[k] >= 0)[0]
+            y[o] += xx[nbr[k][o]] @ ww[k]
+        return float((y * dy).sum())
+    dx, dw, db = R.sparse_conv_backward(x, nbr, taps, dy)
+    eps = 1e-5
+    for _ in range(10):
+        i, c = rng.integers(n_in), rng.integers(ci)
+        xp = x.copy(); xp[i, c] += eps
+        xm = x.copy(); xm[i, c] -= eps
+        assert abs((f(xp, taps) - f(xm, taps)) / (2 * eps) - dx[i, c]) < 1e-4
+        k, c2 = rng.integers(K), rng.integers(co)
+        wp = taps.copy(); wp[k, c, c2] += eps
+        wm = taps.copy(); wm[k, c, c2] -= eps
+        assert abs((f(x, wp) - f(x, wm)) / (2 * eps) - dw[k, c, c2]) < 1e-4
+    np.testing.assert_allclose(db, dy.sum(0))
+
+
+def _subm_table(rng, n, shape=(12, 40, 40)):
+    """A real submanifold table (symmetric: tap k of o is i  <=>  tap K-1-k of i is o) from random voxels."""
+    cells = rng.choice(shape[0] * shape[1] * shape[2], size=n, replace=False)
+    coords = np.stack(np.unravel_index(cells, shape), 1).astype(np.int32)
+    keys = R.key3(coords, shape)
+    perm = np.argsort(keys).astype(np.int32)
+    return R.spconv_nbr_subm(coords, keys[perm], perm, shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,K", [(8, 8, 27), (16, 32, 27), (32, 16, 27), (5, 3, 27), (64, 64, 27), (16, 16, 1)])
+def test_sparse_conv_autograd_submanifold(cin, cout, K):
+    import torch
+    from insmos_amd.autograd import sparse_conv
+    rng = np.random.default_rng(cin * 31 + cout)
+    n = 3000
+    nbr = None if K == 1 else _subm_table(rng, n)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) * 0.2).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    gy = rng.normal(size=(n, cout)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    wt = torch.from_numpy(taps).cuda().requires_grad_(True)
+    bt = torch.from_numpy(bias).cuda().requires_grad_(True)
+    nb = torch.from_numpy(nbr).cuda() if nbr is not None else None
+    y = sparse_conv(xt, wt, bt, nb)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), R.sparse_conv_numpy(x, nbr, taps) + bias if nbr is not None else x @ taps[0] + bias,
+                               rtol=2e-4, atol=2e-4)
+    (y * torch.from_numpy(gy).cuda()).sum().backward()
+    dx, dw, db = R.sparse_conv_backward(x, nbr, taps, gy)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), dx, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), dw, rtol=2e-4, atol=5e-4)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), db, rtol=2e-4, atol=5e-4)
+    # deterministic: a second backward gives the same bits
+    xt.grad = None; wt.grad = None; bt.grad = None
+    y2 = sparse_conv(xt, wt, bt, nb)
+    (y2 * torch.from_numpy(gy).cuda()).sum().backward()
+    assert torch.equal(wt.grad, torch.from_numpy(wt.grad.cpu().numpy()).cuda())
+    g1 = wt.grad.clone()
+    xt.grad = None; wt.grad = None; bt.grad = None
+    (sparse_conv(xt, wt, bt, nb) * torch.from_numpy(gy).cuda()).sum().backward()
+    assert torch.equal(g1, wt.grad)
+
+
+@pytest.mark.gpu
+def test_sparse_conv_autograd_strided_pair():
+    """A stride-2 layer: its transposed table is the inverse-conv table of the same pairs (down <-> inverse)."""
+    import torch
+    from insmos_amd.autograd import sparse_conv
+    rng = np.random.default_rng(5)
+    shape = (9, 33, 33)
+    cells = rng.choice(shape[0] * shape[1] * shape[2], size=2500, replace=False)
+    fine = np.stack(np.unravel_index(np.sort(cells), shape), 1).astype(np.int32)
+    fkeys = R.key3(fine, shape)
+    ocoords, okeys, oshape = R.spconv_down_coords(fine, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    down = R.spconv_nbr_down(ocoords, fkeys, None, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))          # (27, n_coarse) -> fine rows
+    inv = R.spconv_nbr_inverse(fine, okeys, None, oshape, (3, 3, 3), (2, 2, 2), (1, 1, 1))           # (27, n_fine) -> coarse rows
+    cin, cout = 16, 32
+    x = rng.normal(size=(len(fine), cin)).astype(np.float32)
+    taps = (rng.normal(size=(27, cin, cout)) * 0.2).astype(np.float32)
+    gy = rng.normal(size=(len(ocoords), cout)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    wt = torch.from_numpy(taps).cuda().requires_grad_(True)
+    y = sparse_conv(xt, wt, None, torch.from_numpy(down).cuda(), torch.from_numpy(inv).cuda())
+    (y * torch.from_numpy(gy).cuda()).sum().backward()
+    dx, dw, _ = R.sparse_conv_backward(x, down, taps, gy)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), dx, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), dw, rtol=2e-4, atol=5e-4)
+
+
+@pytest.mark.gpu
+def test_mos_loss_kernel_vs_reference(golden_dir):
+    import torch
+    from insmos_amd.autograd import mos_loss
+    g = np.load(os.path.join(golden_dir, "mos_loss.npz"))
+    lg = torch.from_numpy(g["logits"]).cuda().requires_grad_(True)
+    loss = mos_loss(lg, torch.from_numpy(g["gt"]).cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-6
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g["grad"], atol=1e-8, rtol=1e-4)
+    assert bool((lg.grad[:50] == 0).all())
+
+
+@pytest.mark.gpu
+def test_two_layer_training_steps_reduce_the_loss():
+    """conv -> ReLU -> conv -> MOS loss chained on torch's autograd tape; plain SGD brings the loss down."""
+    import torch
+    from insmos_amd.autograd import mos_loss, sparse_conv
+    rng = np.random.default_rng(1)
+    n = 4000
+    nbr = torch.from_numpy(_subm_table(rng, n)).cuda()
+    x = torch.from_numpy(rng.normal(size=(n, 8)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(np.where(x[:, 0].cpu().numpy() > 0.3, 2, 1)).cuda()  # learnable from the input
+    w1 = torch.from_numpy((rng.normal(size=(27, 8, 16)) * 0.1).astype(np.float32)).cuda().requires_grad_(True)
+    b1 = torch.zeros(16, device="cuda", requires_grad=True)
+    w2 = torch.from_numpy((rng.normal(size=(27, 16, 3)) * 0.1).astype(np.float32)).cuda().requires_grad_(True)
+    b2 = torch.zeros(3, device="cuda", requires_grad=True)
+    losses = []
+    for step in range(30):
+        h = torch.relu(sparse_conv(x, w1, b1, nbr))
+        loss = mos_loss(sparse_conv(h, w2, b2, nbr), gt)
+        for p in (w1, b1, w2, b2):
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for p in (w1, b1, w2, b2):
+                p -= 0.5 * p.grad
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.6 * losses[0] and all(b <= a + 1e-4 for a, b in zip(losses, losses[1:])), losses
