@@ -361,6 +361,16 @@ int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, int ld_x, i
                                        void* stream);
 size_t insmos_col_sum_ws_floats(int64_t n, int c);
 int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* out, int accumulate, float* ws, void* stream);
+/* BatchNorm1d over rows in TRAINING mode (the nn.BatchNorm1d / MinkowskiBatchNorm layers of spconv_unet.py and
+ * minkunet.py under model.train()): batch mean / biased variance per channel, y = relu?(xhat * gamma + beta);
+ * stats = [mean | invstd | biased var] (3c floats); xhat (n, c) is kept for the backward, which returns dx, dgamma,
+ * dbeta (through the ReLU when relu != 0).  Running-statistics updates stay with the caller (two axpys). */
+size_t insmos_batchnorm_ws_floats(int64_t n, int c);
+int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, int64_t n, const float* gamma, const float* beta, float eps,
+                                   int relu, float* y, int ld_y, float* xhat, float* stats, float* ws, void* stream);
+int insmos_batchnorm_train_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* xhat, int c, int64_t n,
+                                    const float* gamma, const float* stats, int relu, float* dx, int ld_dx, float* dgamma,
+                                    float* dbeta, float* g_ws, float* ws, void* stream);
 size_t insmos_mos_loss_ws_floats(int64_t n);
 int insmos_mos_loss(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
                     const float* class_weights, float* loss_sums, float* grad, int ld_grad, float* ws, void* stream);

@@ -112,6 +112,61 @@ def sparse_conv(x, taps, bias, nbr, nbr_t=None):
     return SparseConvFunction.apply(x, taps, bias, nbr, nbr_t)
 
 
+class BatchNormTrainFunction(torch.autograd.Function):
+    """nn.BatchNorm1d over rows in training mode (+ optional fused ReLU): batch statistics, HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        lib = _lib.load()
+        st = _stream(x.device)
+        x = x.float()
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n, c = x.shape
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        xhat = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        stats = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.insmos_batchnorm_ws_floats(n, c)), dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.contiguous().float(), beta.contiguous().float()
+        _lib.check(lib.insmos_batchnorm_train_forward(x.data_ptr(), x.stride(0), c, n, g32.data_ptr(), b32.data_ptr(), float(eps),
+                                                      1 if relu else 0, y.data_ptr(), c, xhat.data_ptr(), stats.data_ptr(),
+                                                      ws.data_ptr(), st), "insmos_batchnorm_train_forward")
+        ctx.save_for_backward(y, xhat, g32, stats)
+        ctx.relu = bool(relu)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        lib = _lib.load()
+        y, xhat, gamma, stats = ctx.saved_tensors
+        st = _stream(dy.device)
+        dy = dy.contiguous().float()
+        n, c = dy.shape
+        dx = torch.empty((n, c), dtype=torch.float32, device=dy.device)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+        gws = torch.empty((n, c), dtype=torch.float32, device=dy.device)
+        ws = torch.empty(int(lib.insmos_batchnorm_ws_floats(n, c)), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.insmos_batchnorm_train_backward(dy.data_ptr(), c, y.data_ptr(), c, xhat.data_ptr(), c, n, gamma.data_ptr(),
+                                                       stats.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), c, dgamma.data_ptr(),
+                                                       dbeta.data_ptr(), gws.data_ptr(), ws.data_ptr(), st),
+                   "insmos_batchnorm_train_backward")
+        return dx, dgamma, dbeta, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=False):
+    """F.batch_norm(x, running_mean, running_var, gamma, beta, training=True, momentum, eps) (+ ReLU) on the rows of x;
+    the running statistics are updated in place like torch does (unbiased variance)."""
+    y, stats = BatchNormTrainFunction.apply(x, gamma, beta, eps, relu)
+    if running_mean is not None:
+        n, c = x.shape
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(stats[:c], alpha=momentum)
+            running_var.mul_(1 - momentum).add_(stats[2 * c:] * (n / max(n - 1, 1)), alpha=momentum)
+    return y
+
+
 class MosLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, gt, class_weights, ignore_mask):

@@ -154,6 +154,77 @@ __global__ void k_scale_rows(float* __restrict__ a, int ld, int c, int64_t n, co
     a[(t / c) * ld + (t % c)] *= inv;
 }
 
+
+// ---- BatchNorm1d over sparse rows, training mode (spconv_unet.py:36-60 / minkunet.py blocks use nn.BatchNorm1d /
+// MinkowskiBatchNorm in train()): per-channel batch statistics, normalise + affine (+ ReLU), and the backward ----
+// stage 1: per 1024-row block and channel: sum(x), sum((x - shift)^2 ...) is avoided: two passes (mean first) keep fp32 exact enough
+__global__ void __launch_bounds__(256) k_bn_partial(const float* __restrict__ a, int ld, const float* __restrict__ b, int ld_b,
+                                                     const float* __restrict__ sub, int c, int64_t n, int mode,
+                                                     float* __restrict__ partial) {
+    // mode 0: sum a            mode 1: sum (a - sub[col])^2          mode 2: sum a*b (b = normalised x)
+    __shared__ float sm[256];
+    const int col = blockIdx.y, tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = min(r0 + 1024, n);
+    const float sh = (mode == 1) ? sub[col] : 0.f;
+    float acc = 0.f;
+    for (int64_t r = r0 + tid; r < r1; r += 256) {
+        const float v = a[r * ld + col];
+        acc += mode == 0 ? v : mode == 1 ? (v - sh) * (v - sh) : v * b[r * ld_b + col];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sm[tid] += sm[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) partial[(int64_t)blockIdx.x * c + col] = sm[0];
+}
+
+__global__ void k_bn_finish_stats(const float* __restrict__ part, int nb, int c, int64_t n, float* __restrict__ out, int mode,
+                                  float eps) {
+    // mode 0: out[col] = mean = sum / n      mode 1: out[col] = invstd = 1/sqrt(sum/n + eps), out[c + col] = biased var
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    float acc = 0.f;
+    for (int b = 0; b < nb; ++b) acc += part[(int64_t)b * c + col];
+    if (mode == 0) out[col] = acc / (float)n;
+    else { const float var = acc / (float)n; out[col] = 1.0f / sqrtf(var + eps); out[c + col] = var; }
+}
+
+__global__ void k_bn_apply(const float* __restrict__ x, int ld_x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int c, int64_t n, int relu,
+                           float* __restrict__ xhat, float* __restrict__ y, int ld_y) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t r = t / c;
+    const int col = (int)(t % c);
+    const float h = (x[r * ld_x + col] - mean[col]) * invstd[col];
+    if (xhat) xhat[r * c + col] = h;
+    const float v = h * gamma[col] + beta[col];
+    y[r * ld_y + col] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); dy is first masked by the ReLU (y > 0) when relu != 0
+__global__ void k_bn_mask_relu(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, int c, int64_t n,
+                               float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t r = t / c;
+    const int col = (int)(t % c);
+    out[t] = y[r * ld_y + col] > 0.f ? dy[r * ld_dy + col] : 0.f;
+}
+
+__global__ void k_bn_backward_dx(const float* __restrict__ g, const float* __restrict__ xhat, const float* __restrict__ gamma,
+                                 const float* __restrict__ invstd, const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                 int c, int64_t n, float* __restrict__ dx, int ld_dx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t r = t / c;
+    const int col = (int)(t % c);
+    const float inv_n = 1.0f / (float)n;
+    dx[r * ld_dx + col] = gamma[col] * invstd[col] * (g[t] - dbeta[col] * inv_n - xhat[t] * (dgamma[col] * inv_n));
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -246,6 +317,54 @@ extern "C" int insmos_mos_loss(const float* logits, int ld, const int64_t* gt, i
     rc = insmos_col_sum(wsum, 1, 1, n, loss_sums + 1, 0, cs, stream);       // loss_sums[1] = sum of weights
     if (rc) return rc;
     if (grad) INSMOS_LAUNCH(k_scale_rows, dim3(cdiv(n * ncls, 256)), dim3(256), 0, s, grad, ld_grad, ncls, n, loss_sums);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// stats: [mean (c) | invstd (c) | biased var (c)]; xhat (n, c) dense; ws: (n/1024 + 1) * c floats
+extern "C" size_t insmos_batchnorm_ws_floats(int64_t n, int c) { return (size_t)((n + 1023) / 1024 + 1) * (size_t)c; }
+
+extern "C" int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, int64_t n, const float* gamma, const float* beta,
+                                              float eps, int relu, float* y, int ld_y, float* xhat, float* stats, float* ws,
+                                              void* stream) {
+    if (n <= 0 || c <= 0) return INSMOS_OK;
+    if (!x || !gamma || !beta || !y || !stats || !ws || ld_x < c || ld_y < c) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 1023) / 1024);
+    float *mean = stats, *invstd = stats + c;
+    ProfScope ps(KK_FILL, s);
+    INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, (const float*)nullptr, c, n, 0, ws);
+    INSMOS_LAUNCH(k_bn_finish_stats, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, nb, c, n, mean, 0, eps);
+    INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, mean, c, n, 1, ws);
+    INSMOS_LAUNCH(k_bn_finish_stats, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, nb, c, n, invstd, 1, eps);
+    INSMOS_LAUNCH(k_bn_apply, dim3(cdiv(n * c, 256)), dim3(256), 0, s, x, ld_x, mean, invstd, gamma, beta, c, n, relu, xhat, y, ld_y);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// g_ws: (n, c) floats (the ReLU-masked upstream gradient); dgamma, dbeta (c) out; dx (n, ld_dx) out
+extern "C" int insmos_batchnorm_train_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* xhat, int c,
+                                               int64_t n, const float* gamma, const float* stats, int relu, float* dx, int ld_dx,
+                                               float* dgamma, float* dbeta, float* g_ws, float* ws, void* stream) {
+    if (n <= 0 || c <= 0) return INSMOS_OK;
+    if (!dy || !xhat || !gamma || !stats || !dx || !dgamma || !dbeta || !g_ws || !ws || (relu && !y)) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 1023) / 1024);
+    ProfScope ps(KK_FILL, s);
+    const float* g = dy;
+    int ld_g = ld_dy;
+    if (relu || ld_dy != c) {
+        if (relu) INSMOS_LAUNCH(k_bn_mask_relu, dim3(cdiv(n * c, 256)), dim3(256), 0, s, dy, ld_dy, y, ld_y, c, n, g_ws);
+        else HIP_TRY(hipMemcpy2DAsync(g_ws, (size_t)c * 4, dy, (size_t)ld_dy * 4, (size_t)c * 4, (size_t)n, hipMemcpyDeviceToDevice, s));
+        g = g_ws;
+        ld_g = c;
+    }
+    INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, g, ld_g, (const float*)nullptr, 0, (const float*)nullptr, c, n, 0, ws);
+    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(c, 256)), dim3(256), 0, s, ws, nb, (int64_t)c, dbeta, 0);
+    INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, g, ld_g, xhat, c, (const float*)nullptr, c, n, 2, ws);
+    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(c, 256)), dim3(256), 0, s, ws, nb, (int64_t)c, dgamma, 0);
+    if (ld_g != c) return INSMOS_EINVAL;
+    INSMOS_LAUNCH(k_bn_backward_dx, dim3(cdiv(n * c, 256)), dim3(256), 0, s, g, xhat, gamma, stats + c, dbeta, dgamma, c, n, dx, ld_dx);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -150,3 +150,80 @@ def test_two_layer_training_steps_reduce_the_loss():
                 p -= 0.5 * p.grad
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.6 * losses[0] and all(b <= a + 1e-4 for a, b in zip(losses, losses[1:])), losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_train_vs_torch(relu):
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd.autograd import batch_norm_train
+    rng = np.random.default_rng(3)
+    n, c = 5000, 24
+    x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 3, c) + rng.normal(size=c)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(size=c).astype(np.float32)
+    gy = rng.normal(size=(n, c)).astype(np.float32)
+    # reference: torch CPU float64
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    gr, br = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    yr = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-3)
+    if relu:
+        yr = torch.relu(yr)
+    (yr * torch.from_numpy(gy).double()).sum().backward()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt_, bt = torch.from_numpy(gamma).cuda().requires_grad_(True), torch.from_numpy(beta).cuda().requires_grad_(True)
+    rm2, rv2 = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    y = batch_norm_train(xt, gt_, bt, rm2, rv2, momentum=0.1, eps=1e-3, relu=relu)
+    (y * torch.from_numpy(gy).cuda()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rm2.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv2.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(gt_.grad.cpu().numpy(), gr.grad.numpy(), rtol=1e-3, atol=5e-3)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=5e-3)
+
+
+@pytest.mark.gpu
+def test_conv_bn_relu_conv_loss_graph_vs_torch_reference():
+    """One trainable block (SubMConv3d -> BatchNorm1d -> ReLU -> SubMConv3d -> MOSLoss, train mode) on the HIP autograd
+    nodes vs the same graph written with torch index ops in float64 on the CPU: loss and every parameter gradient."""
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd.autograd import batch_norm_train, mos_loss, sparse_conv
+    rng = np.random.default_rng(8)
+    n = 3500
+    nbr = _subm_table(rng, n)
+    x = rng.normal(size=(n, 8)).astype(np.float32)
+    gt = rng.integers(0, 3, n)
+    P0 = dict(w1=(rng.normal(size=(27, 8, 16)) * 0.2).astype(np.float32), g1=rng.uniform(0.5, 1.5, 16).astype(np.float32),
+              b1=rng.normal(size=16).astype(np.float32) * 0.1, w2=(rng.normal(size=(27, 16, 3)) * 0.2).astype(np.float32),
+              c2=rng.normal(size=3).astype(np.float32) * 0.1)
+
+    def ref_conv(xx, ww, bias):
+        y = torch.zeros((n, ww.shape[2]), dtype=torch.float64)
+        for k in range(27):
+            o = torch.from_numpy(np.nonzero(nbr[k] >= 0)[0])
+            i = torch.from_numpy(nbr[k][nbr[k] >= 0].astype(np.int64))
+            y = y.index_add(0, o, xx[i] @ ww[k])
+        return y if bias is None else y + bias
+
+    pr = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in P0.items()}
+    h = ref_conv(torch.from_numpy(x).double(), pr["w1"], None)
+    h = torch.relu(F.batch_norm(h, None, None, pr["g1"], pr["b1"], training=True, eps=1e-3))
+    z = ref_conv(h, pr["w2"], pr["c2"])
+    lw = torch.tensor([0.0, 0.5, 0.5], dtype=torch.float64)
+    zz = z.clone()
+    zz[:, 0] = -float("inf")
+    loss_r = F.nll_loss(torch.log(torch.softmax(zz, 1).clamp(min=1e-8)), torch.from_numpy(gt), weight=lw)
+    loss_r.backward()
+
+    pg = {k: torch.from_numpy(v).cuda().requires_grad_(True) for k, v in P0.items()}
+    nb = torch.from_numpy(nbr).cuda()
+    h = sparse_conv(torch.from_numpy(x).cuda(), pg["w1"], None, nb)
+    h = batch_norm_train(h, pg["g1"], pg["b1"], eps=1e-3, relu=True)
+    loss = mos_loss(sparse_conv(h, pg["w2"], pg["c2"], nb), torch.from_numpy(gt).cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5
+    for k in P0:
+        np.testing.assert_allclose(pg[k].grad.cpu().numpy(), pr[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
