@@ -227,3 +227,86 @@ def test_conv_bn_relu_conv_loss_graph_vs_torch_reference():
     assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5
     for k in P0:
         np.testing.assert_allclose(pg[k].grad.cpu().numpy(), pr[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_motionnet_training_step_vs_torch_reference():
+    """MotionNet in train mode (batch-stat BN) + loss_motion_encoder: loss and the gradients of ALL parameters against the
+    same graph written with torch index ops in float64 on the CPU over the same kernel maps; then SGD lowers the loss."""
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd import params as P
+    from insmos_amd.synth import make_labels, make_window
+    from insmos_amd.train_motionnet import MotionNetTrainer
+    cfg = P.default_cfg()
+    sd = P.random_state_dict(cfg, 6)
+    w = make_window(seed=8, n_scans=3, n_az=72)
+    gt = make_labels(w[w[:, 4] == 0], seed=8)
+    tr = MotionNetTrainer(cfg, sd)
+    pts = torch.from_numpy(w).cuda()
+    loss = tr.loss(pts, torch.from_numpy(gt).cuda())
+    loss.backward()
+    T = tr.engine._me_tables
+    tabs = dict(n125=T["nbr125"].nbr.cpu().numpy(), n81=[t.nbr.cpu().numpy() for t in T["nbr81"]],
+                dn=[t.nbr.cpu().numpy() for t in T["dn"]], up=[t.nbr.cpu().numpy() for t in T["up"]])
+    inverse = T["inverse"].cpu().numpy()
+
+    pr = {k: v.detach().cpu().double().requires_grad_(True) for k, v in tr.params.items()}
+
+    def conv(x, wname, nbr, bias=None):
+        ww = pr[wname]
+        if nbr is None:
+            y = x @ ww[0]
+        else:
+            y = torch.zeros((nbr.shape[1], ww.shape[2]), dtype=torch.float64)
+            for k in range(nbr.shape[0]):
+                o = np.nonzero(nbr[k] >= 0)[0]
+                if len(o):
+                    y = y.index_add(0, torch.from_numpy(o), x[torch.from_numpy(nbr[k][o].astype(np.int64))] @ ww[k])
+        return y if bias is None else y + pr[bias]
+
+    def bn(x, name, relu):
+        y = F.batch_norm(x, None, None, pr[name + ".weight"], pr[name + ".bias"], training=True, eps=1e-5)
+        return torch.relu(y) if relu else y
+
+    def block(name, x, nbr):
+        out = bn(conv(x, name + ".conv1.kernel", nbr), name + ".norm1", True)
+        out = bn(conv(out, name + ".conv2.kernel", nbr), name + ".norm2", False)
+        res = bn(conv(x, name + ".downsample.0.kernel", None), name + ".downsample.1", False) if (name + ".downsample.0.kernel") in pr else x
+        return torch.relu(out + res)
+
+    n0 = tabs["n81"][0].shape[1]
+    out_p1 = bn(conv(torch.full((n0, 1), 0.5, dtype=torch.float64), "conv0p1s1.kernel", tabs["n125"]), "bn0", True)
+    out = bn(conv(out_p1, "conv1p1s2.kernel", tabs["dn"][0]), "bn1", True)
+    b1 = block("block1.0", out, tabs["n81"][1])
+    out = bn(conv(b1, "conv2p2s2.kernel", tabs["dn"][1]), "bn2", True)
+    b2 = block("block2.0", out, tabs["n81"][2])
+    out = bn(conv(b2, "conv3p4s2.kernel", tabs["dn"][2]), "bn3", True)
+    out = block("block3.0", out, tabs["n81"][3])
+    out = bn(conv(out, "convtr5p8s2.kernel", tabs["up"][2]), "bntr5", True)
+    out = block("block6.0", torch.cat([out, b2], 1), tabs["n81"][2])
+    out = bn(conv(out, "convtr6p4s2.kernel", tabs["up"][1]), "bntr6", True)
+    out = block("block7.0", torch.cat([out, b1], 1), tabs["n81"][1])
+    out = bn(conv(out, "convtr7p2s2.kernel", tabs["up"][0]), "bntr7", True)
+    out = block("block8.0", torch.cat([out, out_p1], 1), tabs["n81"][0])
+    motion = conv(out, "final.kernel", None, "final.bias")
+    cur = np.nonzero(np.floor(w[:, 4] / np.float32(0.1)) == 0)[0]
+    z = motion[torch.from_numpy(inverse[cur].astype(np.int64))].clone()
+    z[:, 0] = -float("inf")
+    loss_r = F.nll_loss(torch.log(torch.softmax(z, 1).clamp(min=1e-8)), torch.from_numpy(gt).long(),
+                        weight=torch.tensor([0.0, 0.5, 0.5], dtype=torch.float64))
+    loss_r.backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 2e-4, (float(loss.detach()), float(loss_r.detach()))
+    worst = 0.0
+    for k, v in tr.params.items():
+        g, r = v.grad.cpu().numpy(), pr[k].grad.numpy()
+        scale = max(np.abs(r).max(), 1e-6)
+        worst = max(worst, float(np.abs(g - r).max() / scale))
+        assert np.abs(g - r).max() <= 5e-3 * scale + 1e-6, (k, float(np.abs(g - r).max()), float(scale))
+    print("worst relative gradient error", worst)
+    l0 = float(loss.detach())
+    for _ in range(8):
+        tr.sgd_step(0.05)
+        loss = tr.loss(pts, torch.from_numpy(gt).cuda())
+        loss.backward()
+    assert float(loss.detach()) < l0
