@@ -103,6 +103,11 @@ class MotionNetTrainer:
         """loss_motion_encoder of models/models.py:324."""
         return mos_loss(self.forward(pts), gt_labels_cur)
 
+    def make_reducer(self, bucket_bytes=8 << 20):
+        """Data-parallel gradient exchange (insmos_amd/ddp.py): call .reduce() between backward() and the update."""
+        from .ddp import BucketedGradReducer
+        return BucketedGradReducer(self.params, bucket_bytes)
+
     def sgd_step(self, lr):
         with torch.no_grad():
             for v in self.params.values():

@@ -157,3 +157,40 @@ def test_confusion_all_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from insmos_amd.ddp import BucketedGradReducer
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+params = {"w%02d" % i: torch.zeros(s, requires_grad=True) for i, s in enumerate([(81, 8, 8), (8,), (27, 16, 32), (3,), (125, 1, 8), (1, 8, 3)])}
+grads = {r: {k: torch.randn(v.shape, generator=torch.Generator().manual_seed(100 * r + i)) for i, (k, v) in enumerate(sorted(params.items()))}
+         for r in range(world)}
+for k, v in params.items():
+    if not (k == "w03" and rank == 1):          # a parameter without a gradient on one rank counts as zero
+        v.grad = grads[rank][k].clone()
+red = BucketedGradReducer(params, bucket_bytes=20000)   # several buckets, one tensor larger than a bucket
+n = red.reduce(average=True)
+assert n >= 3, n
+for k, v in params.items():
+    exp = (grads[0][k] + (torch.zeros_like(grads[1][k]) if k == "w03" else grads[1][k])) / 2
+    assert torch.allclose(v.grad, exp, atol=1e-7), k
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_bucketed_grad_reducer_gloo_world2(tmp_path):
+    """The DDP gradient exchange of the training slice (insmos_amd/ddp.py): bucketed all-reduce == per-tensor mean."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, ROOT], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o
