@@ -204,6 +204,13 @@ int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, c
                             int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
                             void* stream);
 int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream);
+/* Fused BEV deblock + heads (base_bev_backbone.py:104-115, center_head.py:65-72): x (n_site, cin) NHWC BEV features;
+ * wd_packed / bd = the ConvTranspose2d(k=2,s=2)+BN as a 1x1 layer with 4*cup outputs laid out [ky][kx][co] (cup = 256);
+ * wh_packed / bh = the merged 1x1 heads (cup -> head_cout <= 16).  head ((4*n_site), ld_head): row site*4 + ky*2 + kx.
+ * The (4*n_site, cup) deconv output is never written: it is consumed from the accumulators.  Bit-identical to
+ * insmos_sparse_conv(deconv, relu) followed by insmos_sparse_conv(head). */
+int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd, int cup,
+                       const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head, void* stream);
 int insmos_debug_conv_force(int cot, int jt, int ring);
 
 /* ------------------------------------------------------------------------------------------------

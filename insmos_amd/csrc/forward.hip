@@ -406,8 +406,18 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         CK(conv(("bev" + std::to_string(k + 1)).c_str(), fa, nsite, nf, 0, &tb, nsite, fb, nf, 0, nullptr, 0, 0, 0, 0, 1));
         std::swap(fa, fb);
     }
-    CK(conv("deconv", fa, nsite, nf, 0, nullptr, nsite, upf, 4 * upc, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(conv("head", upf, ncell, upc, 0, nullptr, ncell, head, g.head_ld, 0, nullptr, 0, 0, 0, 0, 0));  // upf as (4*nsite, upc)
+    {
+        const InsmosConvW* wd = Lr("deconv");
+        const InsmosConvW* wh = Lr("head");
+        if (!wd || !wh) return INSMOS_EINVAL;
+        if (upc == 256 && nf % 16 == 0 && g.head_ld <= 16) {
+            // the 2x2 deconv output is read by the heads only: fused, it stays in the MFMA accumulators
+            CK(insmos_deconv_head(fa, nsite, nf, nf, wd->w, wd->b, upc, wh->w, wh->b, g.head_ld, head, g.head_ld, s));
+        } else {
+            CK(conv("deconv", fa, nsite, nf, 0, nullptr, nsite, upf, 4 * upc, 0, nullptr, 0, 0, 0, 0, 1));
+            CK(conv("head", upf, ncell, upc, 0, nullptr, ncell, head, g.head_ld, 0, nullptr, 0, 0, 0, 0, 0));  // upf as (4*nsite, upc)
+        }
+    }
     {
         const size_t wsb = insmos_center_decode_select_ws_bytes(ncell);
         const size_t mark = A.off;

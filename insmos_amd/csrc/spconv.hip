@@ -371,6 +371,72 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused ConvTranspose2d(k=2,s=2)+BN+ReLU and the 1x1 heads (base_bev_backbone.py:104-115 deblocks, center_head.py:65-72).
+// The deconv is a 1x1 conv to 4 sub-sites x CUP channels; its output is read ONLY by the heads, so it never has to exist
+// in memory: a wave owns 16 BEV sites x one sub-site, keeps the CUP = 16*NT deconv channels of those rows in its
+// accumulators, applies bias + ReLU, and -- because lane (g, j) of a D fragment holds channels 4g..4g+3 of row j, exactly
+// the B-fragment layout of a contraction over those channels -- feeds them straight into the head's MFMAs.
+// Same operation order as the two separate launches (chunks ascending, 4 steps each): identical bits.
+template <int NT>  // channel tiles of the deconv output per sub-site (CUP / 16)
+__global__ void __launch_bounds__(64) k_deconv_head(const float* __restrict__ x, uint32_t n_site, int ld_x, int n16_in,
+                                                     const float* __restrict__ wd, const float* __restrict__ bd,
+                                                     const float* __restrict__ wh, const float* __restrict__ bh,
+                                                     float* __restrict__ head, int ld_head, int head_cout) {
+    const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+    const uint32_t sub = blockIdx.x & 3u, rg = blockIdx.x >> 2;
+    const uint32_t row = rg * 16u + (uint32_t)j;
+    const uint32_t rowc = row < n_site ? row : n_site - 1;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_site * ld_x * 4), 0x00020000);
+    const uint32_t ntile_d = 4u * NT;  // channel tiles of the packed deconv layer
+    const __amdgpu_buffer_rsrc_t rs_wd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)wd, 0, (int)((size_t)n16_in * ntile_d * 1024u), 0x00020000);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t xoff = rowc * (uint32_t)ld_x * 4u + (uint32_t)g * 16u;
+    const uint32_t woff = (sub * NT * 256u + (uint32_t)lane * 4u) * 4u;
+    for (int c = 0; c < n16_in; ++c) {
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (uint32_t)c * 64u, 0));
+        const uint32_t sw = (uint32_t)c * ntile_d * 1024u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, woff + (uint32_t)t * 1024u, sw, 0));
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc[t] = MFMA(a[s2], b[s2], acc[t]);
+        }
+    }
+    // deconv epilogue (folded BN shift, ReLU) in registers
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *(const f32x4*)(bd + (sub * NT + t) * 16u + 4u * g);
+        acc[t] += bv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+    }
+    // heads: contraction over the NT*16 channels just computed; wh packed [chunk = NT][tile = 1][lane][4]
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 a2 = *(const f32x4*)(wh + ((size_t)t * 64 + lane) * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) o = MFMA(a2[s2], acc[t][s2], o);
+    }
+    if (row >= n_site) return;
+    const uint32_t co0 = 4u * g;
+    if ((int)co0 >= head_cout) return;
+    o += *(const f32x4*)(bh + co0);
+    float* op = head + ((size_t)row * 4 + sub) * ld_head + co0;
+    if ((int)co0 + 3 < head_cout && (ld_head & 3) == 0) {
+        *(f32x4*)op = o;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((int)co0 + r < head_cout) op[r] = o[r];
+    }
+}
+
 __global__ void k_dense_nbr2d(int H, int W, int32_t* __restrict__ nbr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t n = (int64_t)H * W;
@@ -622,6 +688,22 @@ extern "C" int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in,
                                        int res_mode, int relu_pre, int relu_post, void* stream) {
     return sparse_conv_impl(in, n_in, ld_in, cin, nbr, mask16, K, n_out, row0, wpacked, bias, out, ld_out, cout, res,
                             ld_res, res_mode, relu_pre, relu_post, stream);
+}
+
+extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd,
+                                  int cup, const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head,
+                                  void* stream) {
+    if (n_site <= 0) return INSMOS_OK;
+    if (!x || !wd_packed || !bd || !wh_packed || !bh || !head || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || cup != 256 ||
+        head_cout <= 0 || head_cout > 16 || ld_head < head_cout || ((uintptr_t)x & 15) || n_site * (int64_t)ld_x * 4 >= (1ll << 31))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = (long)((n_site + 15) / 16);
+    ProfScope ps(KK_SPARSE_CONV, s);
+    INSMOS_LAUNCH(k_deconv_head<16>, dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed, bd,
+                  wh_packed, bh, head, ld_head, head_cout);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
 }
 
 extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {

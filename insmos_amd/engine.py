@@ -97,6 +97,7 @@ class Engine:
         self.lib = _lib.load()
         self.native = native      # default path of forward_window (see there)
         self.prune_dead_rows = True  # MotionNet decoder layers skip rows nothing consumes
+        self.fuse_deconv_head = True  # BEV deblock + heads in one kernel (the step path can run them separately)
         self._ctx_box = [None]    # native context, shared with clones
         self._arena = None
         self.cfg = cfg
@@ -544,11 +545,21 @@ class Engine:
             self.conv(L[f"bev{k + 1}"], fa, nf, self.nbr_bev, nsite, fb, nf, relu_post=1)
             fa, fb = fb, fa
         upc = self.up_ch
-        upf = E((nsite, 4 * upc))  # rows [y][x], columns [ky][kx][co]  == (4*nsite, upc) sub-site rows
-        self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
         ncell = 4 * nsite
         head = E((ncell, self.head_ld))
-        self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld, n_in=ncell)  # upf viewed as (4*nsite, upc)
+        upf = None
+        if self.fuse_deconv_head and upc == 256 and nf % 16 == 0 and self.head_ld <= 16:
+            # the 2x2 deconv output (rows [y][x], columns [ky][kx][co] == (4*nsite, upc) sub-site rows) is read by the
+            # heads only: one kernel keeps it in the MFMA accumulators (bit-identical to the two launches below)
+            _lib.check(lib.insmos_deconv_head(fa.data_ptr(), nsite, nf, nf, L["deconv"].w.data_ptr(), L["deconv"].b.data_ptr(),
+                                              upc, L["head"].w.data_ptr(), L["head"].b.data_ptr(), self.head_ld,
+                                              head.data_ptr(), self.head_ld, st), "insmos_deconv_head")
+            self._conv_log.append((None, nsite, L["deconv"], 0))
+            self._conv_log.append((None, ncell, L["head"], 0))
+        else:
+            upf = E((nsite, 4 * upc))
+            self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
+            self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld, n_in=ncell)  # upf viewed as (4*nsite, upc)
         H2, W2 = 2 * self.bevH, 2 * self.bevW
         cb, cs = E((self.pre_max, 7)), E((self.pre_max,))
         cl, cc = E((self.pre_max,), torch.int32), E((self.pre_max,), torch.int32)

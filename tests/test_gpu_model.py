@@ -65,7 +65,14 @@ def test_forward_signature_and_parity(setup):
     eng.prune_dead_rows = True
     assert torch.equal(logits_full, logits_list[0])
     np.testing.assert_allclose(eng._me_debug["motion"].cpu().numpy()[:, :3], dbg["motion"]["voxel_motion"], atol=2e-4, rtol=1e-3)
-    eng.forward_window(batch[0]["past_point_clouds"], native=False)  # restore the pruned intermediates for the checks below
+    # ... and so does running the BEV deblock and the heads as two launches instead of the fused kernel
+    eng.fuse_deconv_head = False
+    logits_two, pred_two = eng.forward_window(batch[0]["past_point_clouds"], native=False)
+    head_two = eng._head_debug["head"].clone()
+    eng.fuse_deconv_head = True
+    eng.forward_window(batch[0]["past_point_clouds"], native=False)  # restore the default intermediates for the checks below
+    assert torch.equal(head_two, eng._head_debug["head"]) and torch.equal(logits_two, logits_list[0])
+    assert torch.equal(pred_two["pred_boxes"], pred["pred_boxes"])
     np.testing.assert_allclose(eng._un_debug["enc"].cpu().numpy(), dbg["unet"]["encoded"], atol=2e-4, rtol=1e-3)
     head = eng._head_debug["head"].cpu().numpy()
     H2, W2 = 2 * eng.bevH, 2 * eng.bevW
