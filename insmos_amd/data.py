@@ -83,6 +83,12 @@ class SequenceWindows:
         self.device = torch.device(device)
         self._cache = collections.OrderedDict()
         self._cache_cap = max(cache_scans, self.n + 1)
+        # read-ahead: files are read and uploaded by one background thread on its own copy stream, so the disk read and
+        # the H2D copy of the NEXT windows' scans overlap with the forward of the current ones (the forward takes ~2 ms per
+        # window; reading 1.9 MB and copying it does not fit in front of it)
+        self._pending = {}  # scan index -> Future of (device tensor, ready event)
+        self._pool = None
+        self._copy_stream = None
 
     def __len__(self):
         return max(0, len(self.files) - self.skip * (self.n - 1))
@@ -91,12 +97,53 @@ class SequenceWindows:
         scan_idx = self.skip * (self.n - 1) + j
         return list(range(scan_idx - self.skip * (self.n - 1), scan_idx + 1, self.skip))
 
+    def _load(self, i):
+        """Background thread: file -> pinned staging buffer (a small ring, allocated once: page-locking memory per scan
+        costs more than the copy) -> device on the copy stream."""
+        torch.cuda.set_device(self.device)
+        pts = np.fromfile(self.files[i], dtype=np.float32).reshape((-1, 4))  # predict_mos.py:199-203
+        n = pts.shape[0]
+        slot = self._stage_next % len(self._stage)
+        self._stage_next += 1
+        buf, ev_prev = self._stage[slot]
+        if ev_prev is not None:
+            ev_prev.synchronize()  # the previous copy out of this buffer has finished
+        if buf is None or buf.shape[0] < n:
+            buf = torch.empty((max(n, 150000) * 5 // 4, 4), dtype=torch.float32, pin_memory=True)
+        np.copyto(buf.numpy()[:n], pts)  # plain memcpy (a torch CPU op here would wake the whole intra-op thread pool)
+        with torch.cuda.stream(self._copy_stream):
+            t = buf[:n].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        self._stage[slot] = (buf, ev)
+        return t, ev
+
+    def prefetch(self, j_list):
+        """Start reading / uploading the scans of windows j_list that are not resident yet."""
+        if self.device.type != "cuda":
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="insmos-scan-reader")
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._stage, self._stage_next = [(None, None)] * 6, 0
+        for j in j_list:
+            if 0 <= j < len(self):
+                for i in self.indices(j):
+                    if i not in self._cache and i not in self._pending:
+                        self._pending[i] = self._pool.submit(self._load, i)
+
     def _scan(self, i):
         if i in self._cache:
             self._cache.move_to_end(i)
             return self._cache[i]
-        pts = np.fromfile(self.files[i], dtype=np.float32).reshape((-1, 4))  # predict_mos.py:199-203
-        t = torch.from_numpy(pts).to(self.device, non_blocking=True)
+        if i in self._pending:
+            t, ev = self._pending.pop(i).result()
+            torch.cuda.current_stream(self.device).wait_event(ev)  # the consumer stream waits, the host does not
+            t.record_stream(torch.cuda.current_stream(self.device))
+        else:
+            pts = np.fromfile(self.files[i], dtype=np.float32).reshape((-1, 4))  # predict_mos.py:199-203
+            t = torch.from_numpy(pts).to(self.device, non_blocking=True)
         self._cache[i] = t
         while len(self._cache) > self._cache_cap:
             self._cache.popitem(last=False)

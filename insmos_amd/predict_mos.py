@@ -20,6 +20,9 @@ import copy
 import ctypes
 import os
 
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
@@ -29,14 +32,20 @@ from .metrics import shard_indices
 from .models import InsMOSNet, load_semantic_config
 
 
+_LUT_CACHE = {}
+
+
 def output_stage(logits, ignore_index, learning_map_inv):
     """(labels int32 (n,), confidence fp32 (n, ncls-1)) on the device -- predict_mos.py:440-453."""
     lib = _lib.load()
     n, ncls = int(logits.shape[0]), int(logits.shape[1])
-    lut_np = np.zeros(ncls, dtype=np.int32)
-    for k, v in learning_map_inv.items():
-        lut_np[int(k)] = int(v)
-    lut = torch.from_numpy(lut_np).to(logits.device)
+    key = (str(logits.device), ncls, tuple(sorted((int(k), int(v)) for k, v in learning_map_inv.items())))
+    lut = _LUT_CACHE.get(key)
+    if lut is None:
+        lut_np = np.zeros(ncls, dtype=np.int32)
+        for k, v in learning_map_inv.items():
+            lut_np[int(k)] = int(v)
+        lut = _LUT_CACHE[key] = torch.from_numpy(lut_np).to(logits.device)
     labels = torch.empty((n,), dtype=torch.int32, device=logits.device)
     conf = torch.empty((n, ncls - 1), dtype=torch.float32, device=logits.device)
     mask = 0
@@ -47,6 +56,39 @@ def output_stage(logits, ignore_index, learning_map_inv):
     _lib.check(lib.insmos_output_stage(lg.data_ptr(), lg.stride(0), n, ncls, mask, lut.data_ptr(), labels.data_ptr(),
                                        conf.data_ptr(), st), "insmos_output_stage")
     return labels, conf
+
+
+class OutputWriter:
+    """Writes the three per-scan files off the critical path: a small thread pool waits for the event that marks a scan's
+    outputs complete, copies them to the host on its own stream and does the file I/O (numpy releases the GIL while
+    writing), so the main thread goes straight on to the next group of windows."""
+
+    def __init__(self, device, workers=2):
+        self.device = torch.device(device)
+        self.pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="insmos-writer")
+        self.local = threading.local()
+        self.futures = []
+
+    def submit(self, out_root, exp_id, seq, stem, labels, conf, pred):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))  # the outputs are complete once this event has fired
+        self.futures.append(self.pool.submit(self._write, out_root, exp_id, seq, stem, labels, conf, dict(pred), ev))
+        if len(self.futures) > 64:  # bound the device memory held by queued outputs
+            self.futures.pop(0).result()
+
+    def _write(self, out_root, exp_id, seq, stem, labels, conf, pred, ev):
+        torch.cuda.set_device(self.device)
+        if not hasattr(self.local, "stream"):
+            self.local.stream = torch.cuda.Stream(device=self.device)
+        ev.synchronize()
+        with torch.cuda.stream(self.local.stream):  # D2H copies on this worker's own stream: they block only this thread
+            write_outputs(out_root, exp_id, seq, stem, labels, conf, pred)
+
+    def close(self):
+        for f in self.futures:
+            f.result()
+        self.futures = []
+        self.pool.shutdown(wait=True)
 
 
 def write_outputs(out_root, exp_id, seq, stem, labels, conf, pred):
@@ -75,10 +117,14 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
         jobs = jobs[:limit]
     readers = {n_full: full}
     done = 0
+    writer = OutputWriter(device)
     mine = [jobs[idx] for idx in shard_indices(len(jobs), rank, world)]
     group = max(1, int(getattr(model.model, "windows_in_flight", 1)))  # batch items the model keeps in flight
     for g0 in range(0, len(mine), group):
         batch, metas = [], []
+        for n_past, j in mine[g0 + group:g0 + 2 * group]:  # read-ahead for the next group while this one computes
+            if n_past in readers:
+                readers[n_past].prefetch([j])
         for n_past, j in mine[g0:g0 + group]:
             if n_past not in readers:
                 c2 = copy.deepcopy(cfg)
@@ -96,8 +142,9 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
         for meta, preds, logits in zip(metas, pred_list, logits_list):
             labels, conf = output_stage(logits, ignore_index, sem["learning_map_inv"])
             stem = str(meta[2][-1])[-10:-4]
-            write_outputs(out_root, exp_id, seq, stem, labels, conf, preds[0])
+            writer.submit(out_root, exp_id, seq, stem, labels, conf, preds[0])
             done += 1
+    writer.close()
     return done
 
 
