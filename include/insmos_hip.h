@@ -348,7 +348,7 @@ int insmos_instance_relabel(const int32_t* index, int ncls, int col, const int32
 /* ------------------------------------------------------------------------------------------------
  * Training-step pieces (models/models.py:61-98 training_step, models/loss.py:20-34) -- the
  * gradients behind `loss.backward()` for the sparse convolutions and the MOS loss.  A FIRST SLICE: BatchNorm in
- * training mode, the CenterHead losses / target assignment and the optimiser are not here yet.
+ * training mode and the CenterHead targets / losses follow below; the optimiser stays with the caller (torch.optim).
  *   insmos_pack_weights_device: insmos_pack_weights_host on the device, from taps (K, cin_real, cout_real) that change
  *     every step; transpose = 1 packs W[k]^T (a layer mapping cout_real-wide rows to cin_real-wide ones: pass
  *     cin = padded cout_real, cout = cin_real) and mirror_taps = 1 reads tap K-1-k -- together the d/dx layer of a
@@ -381,6 +381,29 @@ int insmos_batchnorm_train_backward(const float* dy, int ld_dy, const float* y, 
 size_t insmos_mos_loss_ws_floats(int64_t n);
 int insmos_mos_loss(const float* logits, int ld, const int64_t* gt, int64_t n, int ncls, unsigned ignore_mask,
                     const float* class_weights, float* loss_sums, float* grad, int ld_grad, float* ws, void* stream);
+/* CenterHead training side (models/backbones_2d/center_head.py).
+ *   insmos_center_assign_targets: get_targets_single (:170-249) for ONE batch item.  gt_boxes8 (n_gt, 8) fp32 device =
+ *     [x, y, z, dx, dy, dz, yaw, label]; only the first max_objs rows are looked at (:201).  A row is used when
+ *     dx / voxel_x / factor > 0, dy / voxel_y / factor > 0, trunc(label - 1) > -1 and the truncated centre cell lies in
+ *     the (fm_h, fm_w) map (:211,:230-232).  radius = max(min_radius, int(gaussian_radius((length, width), overlap)))
+ *     (:212-215, :395-424, fp32); the gaussian (:346-393) is max-merged into heatmap (num_class, fm_h, fm_w), which this
+ *     call zeroes first.  anno_box (max_objs, 8) = [cx - x, cy - y, z, log dx, log dy, log dz, sin yaw, cos yaw],
+ *     ind (max_objs) int64 = y * fm_w + x, mask (max_objs) uint8; unused slots are zero.  range_is_f64: the reference
+ *     evaluates (x - range_x0) / voxel / factor in float32 when POINT_CLOUD_RANGE is an integer list (the shipped
+ *     config, config/config.yaml:6) and in float64 when it holds floats (torch 0-dim promotion) -- pass which.
+ *   insmos_center_head_loss: get_loss (:279-331) for one item.  cls_preds (hw, >= num_class) raw logits and box_preds
+ *     (hw, >= 8), row = y * fm_w + x (the NHWC maps of :71-72).  losses[3] (device) = [cls_weight * focal,
+ *     loc_weight * l1, their sum]; grad_cls / grad_box (or null) = d losses[2] / d cls_preds, d box_preds (all rows of
+ *     grad_box's 8 columns are written).  code_weights_host: 8 floats in HOST memory.  Fixed-order reductions. */
+int insmos_center_assign_targets(const float* gt_boxes8, int n_gt, int max_objs, int num_class, int fm_w, int fm_h,
+                                 double range_x0, double range_y0, int range_is_f64, float voxel_x, float voxel_y,
+                                 int out_size_factor, double gaussian_overlap, int min_radius, float* heatmap, float* anno_box,
+                                 int64_t* ind, uint8_t* mask, void* stream);
+size_t insmos_center_head_loss_ws_floats(int64_t hw, int num_class);
+int insmos_center_head_loss(const float* cls_preds, int ld_cls, const float* box_preds, int ld_box, int64_t hw, int num_class,
+                            const float* heatmap, const float* anno_box, const int64_t* ind, const uint8_t* mask, int max_objs,
+                            float cls_weight, float loc_weight, const float* code_weights_host, float* losses, float* grad_cls,
+                            int ld_gcls, float* grad_box, int ld_gbox, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native window runner -- InsMOS_Model.forward(list, 'test') for ONE batch item (models/models.py:313-364) as one

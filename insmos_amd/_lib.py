@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libinsmos_hip.so")
 
 c_vp, c_i64, c_int, c_f32, c_sz, c_u32 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_size_t, ctypes.c_uint)
+c_f64 = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/insmos_hip.h exactly
 SIGNATURES = {
@@ -80,6 +81,11 @@ SIGNATURES = {
                                                 c_vp, c_vp, c_vp, c_vp]),
     "insmos_mos_loss_ws_floats": (c_sz, [c_i64]),
     "insmos_mos_loss": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "insmos_center_assign_targets": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_f64, c_f64, c_int, c_f32, c_f32, c_int,
+                                             c_f64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_center_head_loss_ws_floats": (c_sz, [c_i64, c_int]),
+    "insmos_center_head_loss": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32,
+                                        c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_ctx_create": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "insmos_ctx_destroy": (c_int, [c_vp]),
     "insmos_forward_window": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp, c_vp]),

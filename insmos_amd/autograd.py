@@ -7,8 +7,10 @@
   * mos_loss(): MOSLoss.compute_loss (models/loss.py:20-34) with its gradient from one kernel.
 
 torch is used for what it is here for -- device memory, streams and the autograd tape that chains these nodes
-(models/models.py:61-98 calls loss.backward() on such a tape).  BatchNorm in training mode, the CenterHead losses /
-target assignment and the optimiser step are NOT part of this slice.
+(models/models.py:61-98 calls loss.backward() on such a tape).
+  * batch_norm_train(): nn.BatchNorm1d / MinkowskiBatchNorm in train() mode (+ fused ReLU), forward and backward.
+  * center_assign_targets() / center_head_loss(): CenterHead.assign_targets / get_loss (center_head.py:126-331).
+The optimiser step stays torch.optim's.
 """
 import ctypes
 
@@ -197,3 +199,84 @@ def mos_loss(logits, gt_labels, n_classes=3, ignore_index=(0,)):
     for c in ignore_index:
         mask |= 1 << int(c)
     return MosLossFunction.apply(logits, gt_labels, w, mask)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CenterHead training side (models/backbones_2d/center_head.py:126-331)
+# ---------------------------------------------------------------------------------------------------------------------
+def center_assign_targets(gt_boxes, head_cfg, grid_size, point_cloud_range, num_class=3):
+    """CenterHead.assign_targets(gt_boxes) (center_head.py:126-168): gt_boxes (B, M, 8) = box(7) + label on the device ->
+    {'heatmaps': [(B, C, H, W)], 'anno_boxes': [(B, max_objs, 8)], 'inds': [(B, max_objs) int64],
+     'masks': [(B, max_objs) uint8]} -- one task, like the reference.  One launch per batch item, no host round trips
+    (the reference loops over the boxes on the host, center_head.py:202-243)."""
+    import numpy as np
+    lib = _lib.load()
+    tc = head_cfg["TARGET_ASSIGNER_CONFIG"]
+    factor = int(tc["OUT_SIZE_FACTOR"])
+    fm_w, fm_h = int(grid_size[0]) // factor, int(grid_size[1]) // factor
+    max_objs = int(tc["MAX_OBJS"])
+    rng = np.asarray(point_cloud_range)
+    gt = gt_boxes.contiguous().float()
+    B, M = int(gt.shape[0]), int(gt.shape[1])
+    dev = gt.device
+    heat = torch.empty((B, num_class, fm_h, fm_w), dtype=torch.float32, device=dev)
+    anno = torch.empty((B, max_objs, 8), dtype=torch.float32, device=dev)
+    ind = torch.empty((B, max_objs), dtype=torch.int64, device=dev)
+    mask = torch.empty((B, max_objs), dtype=torch.uint8, device=dev)
+    st = _stream(dev)
+    for b in range(B):
+        _lib.check(lib.insmos_center_assign_targets(
+            gt[b].data_ptr(), M, max_objs, num_class, fm_w, fm_h, float(rng[0]), float(rng[1]),
+            1 if rng.dtype.kind == "f" else 0, float(np.float32(tc["VOXEL_SIZE"][0])), float(np.float32(tc["VOXEL_SIZE"][1])),
+            factor, float(tc["GAUSSIAN_OVERLAP"]), int(tc["MIN_RADIUS"]), heat[b].data_ptr(), anno[b].data_ptr(),
+            ind[b].data_ptr(), mask[b].data_ptr(), st), "insmos_center_assign_targets")
+    return {"heatmaps": [heat], "anno_boxes": [anno], "inds": [ind], "masks": [mask]}
+
+
+class CenterHeadLossFunction(torch.autograd.Function):
+    """(cls_preds (H*W, C) logits, box_preds (H*W, 8)) of ONE batch item -> losses (3,) = [cls, loc, total]."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, heatmap, anno_box, ind, mask, cls_weight, loc_weight, code_weights):
+        lib = _lib.load()
+        st = _stream(cls_preds.device)
+        cp, bp = cls_preds.contiguous().float(), box_preds.contiguous().float()
+        hw, nc = int(cp.shape[0]), int(cp.shape[1])
+        max_objs = int(ind.shape[0])
+        losses = torch.empty(3, dtype=torch.float32, device=cp.device)
+        g_cls = torch.empty_like(cp)
+        g_box = torch.empty_like(bp)
+        ws = torch.empty(int(lib.insmos_center_head_loss_ws_floats(hw, nc)), dtype=torch.float32, device=cp.device)
+        cw = (ctypes.c_float * 8)(*[float(v) for v in code_weights])
+        _lib.check(lib.insmos_center_head_loss(cp.data_ptr(), nc, bp.data_ptr(), 8, hw, nc, heatmap.contiguous().data_ptr(),
+                                               anno_box.contiguous().data_ptr(), ind.contiguous().data_ptr(),
+                                               mask.contiguous().data_ptr(), max_objs, float(cls_weight), float(loc_weight),
+                                               ctypes.cast(cw, ctypes.c_void_p), losses.data_ptr(), g_cls.data_ptr(), nc,
+                                               g_box.data_ptr(), 8, ws.data_ptr(), st), "insmos_center_head_loss")
+        ctx.save_for_backward(g_cls, g_box)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        g_cls, g_box = ctx.saved_tensors
+        # losses[2] = losses[0] + losses[1]; the stored gradients are those of the total, which is what get_loss() returns
+        # and the training step differentiates (center_head.py:283); the two parts share them through g[2] only
+        return g_cls * g[2], g_box * g[2], None, None, None, None, None, None, None
+
+
+def center_head_loss(cls_preds, box_preds, targets, head_cfg):
+    """CenterHead.get_loss() (center_head.py:279-288) for NHWC maps cls_preds (B, H, W, C) / box_preds (B, H, W, 8) and the
+    dict assign_targets returned -> (rpn_loss, tb_dict) with the reference's keys.  Differentiable in both maps
+    (through rpn_loss).  B = 1 is what the reference trains with per model call (models/models.py:313 walks the list);
+    for B > 1 the reference's batch-wide averages are reproduced only for B = 1, so larger batches are rejected."""
+    B = int(cls_preds.shape[0])
+    if B != 1:
+        raise ValueError("center_head_loss: one batch item per call (the reference's model loop feeds B = 1)")
+    lw = head_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]
+    nc = int(cls_preds.shape[-1])
+    losses = CenterHeadLossFunction.apply(cls_preds.reshape(-1, nc), box_preds.reshape(-1, 8), targets["heatmaps"][0][0],
+                                          targets["anno_boxes"][0][0], targets["inds"][0][0], targets["masks"][0][0],
+                                          lw["cls_weight"], lw["loc_weight"], lw["code_weights"])
+    host = losses.detach().cpu()
+    tb = {"rpn_loss_cls": float(host[0]), "rpn_loss_loc": float(host[1]), "rpn_loss": float(host[2])}
+    return losses[2], tb

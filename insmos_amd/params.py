@@ -44,7 +44,10 @@ def default_cfg():
                             "NUM_FILTERS": [128], "UPSAMPLE_STRIDES": [2], "NUM_UPSAMPLE_FILTERS": [256]},
             "DENSE_HEAD": {"NAME": "CenterHead", "CLASS_AGNOSTIC": False, "NUM_CLASS": 3,
                            "CLASE_NAME": ["Car", "Pedestrian", "Cyclist"],
-                           "TARGET_ASSIGNER_CONFIG": {"VOXEL_SIZE": [0.1, 0.1, 0.1], "OUT_SIZE_FACTOR": 4}},
+                           "TARGET_ASSIGNER_CONFIG": {"MAX_OBJS": 100, "VOXEL_SIZE": [0.1, 0.1, 0.1], "OUT_SIZE_FACTOR": 4,
+                                                      "GAUSSIAN_OVERLAP": 0.1, "MIN_RADIUS": 2},
+                           "LOSS_CONFIG": {"LOSS_WEIGHTS": {"cls_weight": 1.0, "loc_weight": 2.0,
+                                                            "code_weights": [1.0] * 8}}},
             "POST_PROCESSING": {"RECALL_THRESH_LIST": [0.3, 0.5, 0.7], "SCORE_THRESH": 0.1,
                                 "OUTPUT_RAW_SCORE": False,
                                 "NMS_CONFIG": {"MULTI_CLASSES_NMS": False, "NMS_TYPE": "nms_gpu", "NMS_THRESH": 0.01,

@@ -419,6 +419,117 @@ def mos_loss(logits, gt, n_classes=3, ignore_index=(0,)):
     return loss, grad
 
 
+def gaussian_radius_f32(height, width, min_overlap):
+    """center_head.py:395-424 on fp32 scalars, operation for operation (the reference evaluates it on 0-dim float32
+    tensors; Python scalars are cast to float32 before each multiplication)."""
+    f = np.float32
+    h, w, ov = f(height), f(width), float(min_overlap)
+    b1 = h + w
+    c1 = w * h * f(1 - ov) / f(1 + ov)
+    sq1 = np.sqrt(b1 * b1 - f(4) * c1)
+    r1 = (b1 + sq1) / f(2)
+    b2 = f(2) * (h + w)
+    c2 = f(1 - ov) * w * h
+    sq2 = np.sqrt(b2 * b2 - f(16) * c2)
+    r2 = (b2 + sq2) / f(2)
+    a3 = 4 * ov
+    b3 = f(-2 * ov) * (h + w)
+    c3 = f(ov - 1) * w * h
+    sq3 = np.sqrt(b3 * b3 - f(4 * a3) * c3)
+    r3 = (b3 + sq3) / f(2)
+    return min(r1, r2, r3)
+
+
+def center_assign_targets(gt_boxes8, grid_size, pc_range, voxel_size, out_size_factor, num_class, max_objs,
+                          gaussian_overlap, min_radius):
+    """CenterHead.get_targets_single (center_head.py:170-249) for one batch item, gt_boxes8 (M, 8) = box(7) + label:
+    -> heatmap (C, H, W) fp32, anno_box (max_objs, 8) fp32, ind (max_objs) int64, mask (max_objs) uint8.
+    Box sizes and the radius are float32 as in the reference (0-dim float32 tensors).  The cell coordinate
+    (x - pc_range[0]) / voxel / factor is float32 when pc_range is an INTEGER array (the shipped config,
+    config/config.yaml:6 -> np.array int64 -> torch int64) and float64 (then rounded to float32) when it holds floats:
+    torch promotes a 0-dim float32 minus a 0-dim float64 to float64.  The gaussian is float64, then cast (:346-362)."""
+    f = np.float32
+    range_f64 = np.asarray(pc_range).dtype.kind == "f"
+    gt = np.asarray(gt_boxes8, np.float32)
+    Wf, Hf = int(grid_size[0]) // int(out_size_factor), int(grid_size[1]) // int(out_size_factor)
+    vs = np.asarray(voxel_size, np.float32)
+    pr = np.asarray(pc_range, np.float32)
+    fac = f(out_size_factor)
+    heat = np.zeros((num_class, Hf, Wf), np.float32)
+    anno = np.zeros((max_objs, 8), np.float32)
+    ind = np.zeros((max_objs,), np.int64)
+    mask = np.zeros((max_objs,), np.uint8)
+    with np.errstate(all="ignore"):
+        for k in range(min(len(gt), max_objs)):
+            cls_id = int(np.trunc(gt[k, 7] - f(1)))
+            width = gt[k, 3] / vs[0] / fac
+            length = gt[k, 4] / vs[1] / fac
+            if not (width > 0 and length > 0 and cls_id > -1):
+                continue
+            radius = max(int(min_radius), int(gaussian_radius_f32(length, width, gaussian_overlap)))
+            if range_f64:
+                pr64 = np.asarray(pc_range, np.float64)
+                cx = f((np.float64(gt[k, 0]) - pr64[0]) / np.float64(vs[0]) / np.float64(out_size_factor))
+                cy = f((np.float64(gt[k, 1]) - pr64[1]) / np.float64(vs[1]) / np.float64(out_size_factor))
+            else:
+                cx = (gt[k, 0] - pr[0]) / vs[0] / fac
+                cy = (gt[k, 1] - pr[1]) / vs[1] / fac
+            x, y = int(np.trunc(cx)), int(np.trunc(cy))   # .to(torch.int32): truncation, so (-1, 0) lands in cell 0
+            if not (0 <= x < Wf and 0 <= y < Hf):
+                continue
+            d = 2 * radius + 1
+            sigma = d / 6
+            yy, xx = np.ogrid[-radius:radius + 1, -radius:radius + 1]
+            g = np.exp(-(xx * xx + yy * yy) / (2 * sigma * sigma))
+            g[g < np.finfo(g.dtype).eps * g.max()] = 0
+            left, right = min(x, radius), min(Wf - x, radius + 1)
+            top, bottom = min(y, radius), min(Hf - y, radius + 1)
+            hm = heat[cls_id, y - top:y + bottom, x - left:x + right]
+            np.maximum(hm, g[radius - top:radius + bottom, radius - left:radius + right].astype(np.float32), out=hm)
+            ind[k] = y * Wf + x
+            mask[k] = 1
+            anno[k] = [cx - f(x), cy - f(y), gt[k, 2], np.log(gt[k, 3]), np.log(gt[k, 4]), np.log(gt[k, 5]),
+                       np.sin(gt[k, 6]), np.cos(gt[k, 6])]
+    return heat, anno, ind, mask
+
+
+def center_head_loss(cls_preds, box_preds, heatmap, anno_box, ind, mask, cls_weight=1.0, loc_weight=2.0,
+                     code_weights=(1.0,) * 8):
+    """CenterHead.get_loss (center_head.py:279-331) for one batch item in float64: cls_preds (H, W, C) raw logits,
+    box_preds (H, W, 8) -> (loss_cls, loss_loc, d total / d cls_preds, d total / d box_preds).
+    clip_sigmoid :333-344 (clamp 1e-4 .. 1 - 1e-4, zero gradient where clamped), gaussian_focal_loss :597-616
+    (alpha 2, gamma 4, eps 1e-12, summed / max(#cells equal to 1, 1)), l1_loss :618-631 (sum / (#masked + 1e-4))."""
+    z = np.asarray(cls_preds, np.float64)
+    H, Wd, C = z.shape
+    t = np.asarray(heatmap, np.float64).transpose(1, 2, 0)  # (H, W, C)
+    sg = 1.0 / (1.0 + np.exp(-z))
+    sg32 = sg.astype(np.float32).astype(np.float64)         # the clamp DECISION is taken on the fp32 sigmoid ...
+    lo, hi = float(np.float32(1e-4)), float(np.float32(1 - 1e-4))
+    inside = (sg32 >= lo) & (sg32 <= hi)
+    p = np.where(inside, sg, np.clip(sg32, lo, hi))         # ... the value stays float64 where it is not clamped
+    eps = 1e-12
+    pos = (t == 1.0)
+    negw = (1.0 - t) ** 4
+    with np.errstate(all="ignore"):
+        pos_loss = -np.log(p + eps) * (1 - p) ** 2 * pos
+        neg_loss = -np.log(1 - p + eps) * p ** 2 * negw
+        avg = max(float(pos.sum()), 1.0)
+        loss_cls = float((pos_loss + neg_loss).sum() / avg) * cls_weight
+        dpos = (-(1 - p) ** 2 / (p + eps) + 2 * (1 - p) * np.log(p + eps)) * pos
+        dneg = (p ** 2 / (1 - p + eps) - 2 * p * np.log(1 - p + eps)) * negw
+    g_cls = (dpos + dneg) * (p * (1 - p)) * inside * (cls_weight / avg)
+    b = np.asarray(box_preds, np.float64).reshape(H * Wd, 8)
+    tb = np.asarray(anno_box, np.float64)
+    m = np.asarray(mask, np.float64)
+    num = m.sum()
+    wgt = m[:, None] * (~np.isnan(tb)) * np.asarray(code_weights, np.float64)[None, :]
+    diff = b[np.asarray(ind, np.int64)] - tb
+    loss_loc = float((np.abs(diff) * wgt).sum() / (num + 1e-4)) * loc_weight
+    g_box = np.zeros_like(b)
+    np.add.at(g_box, np.asarray(ind, np.int64), np.sign(diff) * wgt * (loc_weight / (num + 1e-4)))
+    return loss_cls, loss_loc, g_cls, g_box.reshape(H, Wd, 8)
+
+
 def overlap_bev_matrix(a, b):
     a = np.ascontiguousarray(a[:, :7], dtype=np.float32)
     b = np.ascontiguousarray(b[:, :7], dtype=np.float32)

@@ -360,6 +360,71 @@ def mos_loss_golden():
     print("mos_loss golden:", float(loss))
 
 
+def center_loss_golden():
+    """models/backbones_2d/center_head.py:126-331 as written (importable, pure torch/numpy on the CPU): assign_targets on
+    seeded GT boxes (incl. the skipped / clipped / truncated cases) and get_loss with autograd for the two head maps."""
+    from models.backbones_2d.center_head import CenterHead
+    rng = np.random.default_rng(77)
+    torch.manual_seed(77)
+    cfg_head = {"TARGET_ASSIGNER_CONFIG": {"MAX_OBJS": 14, "VOXEL_SIZE": [0.1, 0.1, 0.1], "OUT_SIZE_FACTOR": 4,
+                                           "GAUSSIAN_OVERLAP": 0.1, "MIN_RADIUS": 2},
+                "LOSS_CONFIG": {"LOSS_WEIGHTS": {"cls_weight": 1.0, "loc_weight": 2.0,
+                                                 "code_weights": [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}}}
+    grid = np.array([160, 120, 40])
+    # the shipped config lists POINT_CLOUD_RANGE as integers -> np.array int64 -> the cell coordinate is computed in
+    # float32; a float-valued list makes torch promote the same expression to float64 (both pinned: *_f64range below)
+    pcr = np.array([-8, -6, -3, 8, 6, 1])
+    head = CenterHead(cfg_head, 16, 3, ["Car", "Pedestrian", "Cyclist"], grid, pcr)
+    head64 = CenterHead(cfg_head, 16, 3, ["Car", "Pedestrian", "Cyclist"], grid, pcr.astype(np.float64))
+    W, H = 40, 30
+    M = 17  # more than MAX_OBJS: the tail is never looked at
+    gt = np.zeros((M, 8), np.float32)
+    gt[:, 0] = rng.uniform(-7.5, 7.5, M)
+    gt[:, 1] = rng.uniform(-5.5, 5.5, M)
+    gt[:, 2] = rng.uniform(-2.0, 0.0, M)
+    gt[:, 3] = rng.uniform(0.5, 5.0, M)
+    gt[:, 4] = rng.uniform(0.4, 2.5, M)
+    gt[:, 5] = rng.uniform(0.5, 2.0, M)
+    gt[:, 6] = rng.uniform(-3.2, 3.2, M)
+    gt[:, 7] = rng.integers(1, 4, M)
+    gt[1, 7] = 0                       # label 0 -> cls_id -1 -> skipped
+    gt[2, 3] = 0.0                     # zero width -> skipped
+    gt[3, 0] = -8.0 - 0.25             # coor_x in (-1, 0): int32 cast truncates to 0 -> kept (reference quirk)
+    gt[4, 0] = 8.0 + 0.7               # centre cell outside the map -> skipped
+    gt[5, :2] = (-7.9, -5.9)           # corner: gaussian window clipped on two sides
+    gt[6, :2] = gt[0, :2]              # same cell as box 0 ...
+    gt[6, 7] = gt[0, 7]                # ... and same class: one positive cell, two regression rows
+    gt[7, 3:5] = (9.0, 7.0)            # big box: radius above MIN_RADIUS
+    gt[8, :2] = (7.95, 5.95)           # last cell of the map
+    gt[9, 1] = -6.0 - 0.39             # coor_y in (-1, 0)
+    gt[10, 3:6] = (12.0, 11.0, 3.0)    # radius 4+
+    gtb = torch.from_numpy(gt.copy())[None]
+    # assign_targets (:126-168) only regroups what get_targets_single (:170-249) returns per batch item, through
+    # np.array(list of lists of tensors).transpose(1, 0) -- which numpy 2.x turns into a numeric 5-D array and rejects; the
+    # per-item function is called directly and regrouped here the way assign_targets does (task-major, stacked over batch)
+    hm, ab, idx, mk = head.get_targets_single(gtb[0, :, :-1], gtb[0, :, -1])
+    tg = {"heatmaps": [torch.stack([hm[0]])], "anno_boxes": [torch.stack([ab[0]])], "inds": [torch.stack([idx[0]])],
+          "masks": [torch.stack([mk[0]])]}
+    heat, anno, ind, mask = tg["heatmaps"][0][0], tg["anno_boxes"][0][0], tg["inds"][0][0], tg["masks"][0][0]
+    hm64, ab64, idx64, mk64 = head64.get_targets_single(gtb[0, :, :-1], gtb[0, :, -1])
+    cls_np = (rng.normal(size=(1, H, W, 3)) * 2.0 - 2.0).astype(np.float32)
+    cls_np[0, 3, 4, :] = (12.0, -12.0, 0.0)   # sigmoid beyond the [1e-4, 1 - 1e-4] clip on both sides
+    box_np = rng.normal(size=(1, H, W, 8)).astype(np.float32)
+    cls_leaf = torch.from_numpy(cls_np.copy()).requires_grad_(True)
+    box_leaf = torch.from_numpy(box_np.copy()).requires_grad_(True)
+    head.forward_ret_dict.update(tg)
+    head.forward_ret_dict["cls_preds"] = cls_leaf * 1.0   # (* 1.0: get_cls_layer_loss applies sigmoid_ in place)
+    head.forward_ret_dict["box_preds"] = box_leaf * 1.0
+    loss, tb = head.get_loss()
+    loss.backward()
+    np.savez(os.path.join(HERE, "center_loss.npz"), gt_boxes=gt, grid=grid, pc_range=pcr, max_objs=np.int64(14),
+             heatmap_f64range=hm64[0].numpy(), anno_box_f64range=ab64[0].numpy(), ind_f64range=idx64[0].numpy(),
+             mask_f64range=mk64[0].numpy(), heatmap=heat.numpy(), anno_box=anno.numpy(), ind=ind.numpy(), mask=mask.numpy(), cls_preds=cls_np,
+             box_preds=box_np, loss=np.float32(loss.item()), loss_cls=np.float32(tb["rpn_loss_cls"]),
+             loss_loc=np.float32(tb["rpn_loss_loc"]), grad_cls=cls_leaf.grad.numpy(), grad_box=box_leaf.grad.numpy())
+    print("center_loss golden:", tb, "positives", int((heat == 1).sum()), "mask", mask.numpy().tolist())
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -496,6 +561,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 
 
 if __name__ == "__main__":
+    if "--centerloss-only" in sys.argv:
+        center_loss_golden()
+        sys.exit(0)
     if "--mosloss-only" in sys.argv:
         mos_loss_golden()
         sys.exit(0)
@@ -514,3 +582,4 @@ if __name__ == "__main__":
         refine_golden()
         recall_golden()
         mos_loss_golden()
+        center_loss_golden()

@@ -310,3 +310,202 @@ def test_motionnet_training_step_vs_torch_reference():
         loss = tr.loss(pts, torch.from_numpy(gt).cuda())
         loss.backward()
     assert float(loss.detach()) < l0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CenterHead targets + losses (center_head.py:126-331)
+# ---------------------------------------------------------------------------------------------------------------------
+HEAD_CFG = {"TARGET_ASSIGNER_CONFIG": {"MAX_OBJS": 14, "VOXEL_SIZE": [0.1, 0.1, 0.1], "OUT_SIZE_FACTOR": 4,
+                                       "GAUSSIAN_OVERLAP": 0.1, "MIN_RADIUS": 2},
+            "LOSS_CONFIG": {"LOSS_WEIGHTS": {"cls_weight": 1.0, "loc_weight": 2.0, "code_weights": [1.0] * 8}}}
+
+
+def _oracle_targets(g, pc_range):
+    tc = HEAD_CFG["TARGET_ASSIGNER_CONFIG"]
+    return R.center_assign_targets(g["gt_boxes"], g["grid"], pc_range, tc["VOXEL_SIZE"], tc["OUT_SIZE_FACTOR"], 3,
+                                   tc["MAX_OBJS"], tc["GAUSSIAN_OVERLAP"], tc["MIN_RADIUS"])
+
+
+@pytest.mark.parametrize("tag", ["", "_f64range"])
+def test_oracle_center_targets_vs_reference(golden_dir, tag):
+    """Oracle against CenterHead.get_targets_single run as written (tests/golden/make_golden.py:center_loss_golden):
+    integer-valued range (fp32 cell arithmetic, the shipped config) and float-valued range (torch promotes to float64)."""
+    g = np.load(os.path.join(golden_dir, "center_loss.npz"))
+    pr = g["pc_range"] if tag == "" else g["pc_range"].astype(np.float64)
+    assert g["pc_range"].dtype.kind == "i"
+    heat, anno, ind, mask = _oracle_targets(g, pr)
+    np.testing.assert_array_equal(heat, g["heatmap" + tag])
+    np.testing.assert_array_equal(ind, g["ind" + tag])
+    np.testing.assert_array_equal(mask, g["mask" + tag])
+    np.testing.assert_array_equal(anno[:, :3], g["anno_box" + tag][:, :3])       # offsets and z: exact
+    np.testing.assert_allclose(anno[:, 3:], g["anno_box" + tag][:, 3:], atol=2e-7)  # log / sin / cos: libm vs torch, 1 ulp
+    # the cases the fixture was built around
+    assert mask.tolist() == [1, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    assert ind[3] % 40 == 0 and ind[9] // 40 == 0      # coordinates in (-1, 0) truncate into cell 0
+    assert ind[0] == ind[6] and int((heat == 1).sum()) == int(mask.sum()) - 1
+    assert ind[8] == 40 * 30 - 1
+
+
+def test_oracle_center_loss_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "center_loss.npz"))
+    lc, ll, gc, gb = R.center_head_loss(g["cls_preds"][0], g["box_preds"][0], g["heatmap"], g["anno_box"], g["ind"], g["mask"])
+    assert abs(lc - float(g["loss_cls"])) < 1e-5 * float(g["loss_cls"])
+    assert abs(ll - float(g["loss_loc"])) < 1e-5 * float(g["loss_loc"])
+    np.testing.assert_allclose(gc, g["grad_cls"][0], atol=2e-7, rtol=1e-5)
+    np.testing.assert_allclose(gb, g["grad_box"][0], atol=1e-8, rtol=1e-6)
+    assert (g["grad_cls"][0, 3, 4, :2] == 0).all()      # sigmoid clipped on both sides -> no gradient
+
+
+def test_oracle_center_loss_matches_finite_differences():
+    rng = np.random.default_rng(5)
+    H, W = 6, 7
+    gt = np.array([[0.5, 0.3, -1.0, 1.6, 0.8, 1.5, 0.4, 1], [-0.9, 0.6, -1.2, 0.9, 0.7, 1.7, -1.0, 3]], np.float32)
+    heat, anno, ind, mask = R.center_assign_targets(gt, [28, 24, 40], np.array([-1.4, -1.2, -3, 1.4, 1.2, 1]), [0.1] * 3, 4, 3,
+                                                    5, 0.1, 2)
+    cls = rng.normal(size=(H, W, 3))
+    box = rng.normal(size=(H, W, 8))
+    lc, ll, gc, gb = R.center_head_loss(cls, box, heat, anno, ind, mask)
+    h = 1e-5
+    for _ in range(12):
+        i, j, c = rng.integers(0, H), rng.integers(0, W), rng.integers(0, 3)
+        cp, cm = cls.copy(), cls.copy()
+        cp[i, j, c] += h
+        cm[i, j, c] -= h
+        fd = (sum(R.center_head_loss(cp, box, heat, anno, ind, mask)[:2]) - sum(R.center_head_loss(cm, box, heat, anno, ind, mask)[:2])) / (2 * h)
+        assert abs(fd - gc[i, j, c]) < 1e-5 + 1e-4 * abs(fd)
+    for k in range(2):
+        y, x = divmod(int(ind[k]), W)
+        bp, bm = box.copy(), box.copy()
+        bp[y, x, 2] += h
+        bm[y, x, 2] -= h
+        fd = (sum(R.center_head_loss(cls, bp, heat, anno, ind, mask)[:2]) - sum(R.center_head_loss(cls, bm, heat, anno, ind, mask)[:2])) / (2 * h)
+        assert abs(fd - gb[y, x, 2]) < 1e-6
+
+
+def _gpu_targets(g, pc_range):
+    import torch
+    from insmos_amd.autograd import center_assign_targets
+    return center_assign_targets(torch.from_numpy(g["gt_boxes"])[None].cuda(), HEAD_CFG, g["grid"], pc_range, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["", "_f64range"])
+def test_center_targets_kernel_vs_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "center_loss.npz"))
+    pr = g["pc_range"] if tag == "" else g["pc_range"].astype(np.float64)
+    tg = _gpu_targets(g, pr)
+    heat, anno = tg["heatmaps"][0][0].cpu().numpy(), tg["anno_boxes"][0][0].cpu().numpy()
+    ind, mask = tg["inds"][0][0].cpu().numpy(), tg["masks"][0][0].cpu().numpy()
+    np.testing.assert_array_equal(ind, g["ind" + tag])          # integer work: exact
+    np.testing.assert_array_equal(mask, g["mask" + tag])
+    assert ((heat == 1) == (g["heatmap" + tag] == 1)).all() and ((heat == 0) == (g["heatmap" + tag] == 0)).all()
+    np.testing.assert_allclose(heat, g["heatmap" + tag], atol=0, rtol=2e-7)  # float64 exp on the device, rounded to fp32
+    np.testing.assert_array_equal(anno[:, :3], g["anno_box" + tag][:, :3])
+    np.testing.assert_allclose(anno[:, 3:], g["anno_box" + tag][:, 3:], atol=5e-7)
+    oh, oa, oi, om = _oracle_targets(g, pr)
+    np.testing.assert_array_equal(ind, oi)
+    np.testing.assert_allclose(heat, oh, atol=0, rtol=2e-7)
+
+
+@pytest.mark.gpu
+def test_center_targets_kernel_many_boxes_vs_oracle():
+    """Full-size map (300 x 250), 100 slots, 180 random boxes incl. out-of-range / degenerate ones; twice -> same bits."""
+    import torch
+    from insmos_amd.autograd import center_assign_targets
+    from insmos_amd import params as P
+    rng = np.random.default_rng(9)
+    cfg = P.default_cfg()
+    hc = cfg["MODEL"]["DENSE_HEAD"]
+    M = 180
+    gt = np.zeros((M, 8), np.float32)
+    gt[:, 0] = rng.uniform(-66, 66, M)
+    gt[:, 1] = rng.uniform(-55, 55, M)
+    gt[:, 2] = rng.uniform(-2, 0, M)
+    gt[:, 3:6] = rng.uniform(0.3, 12.0, (M, 3))
+    gt[:, 6] = rng.uniform(-3.2, 3.2, M)
+    gt[:, 7] = rng.integers(0, 4, M)
+    gt[::17, 3] = 0
+    grid = np.array([1200, 1000, 40])
+    pr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
+    tc = hc["TARGET_ASSIGNER_CONFIG"]
+    oh, oa, oi, om = R.center_assign_targets(gt, grid, pr, tc["VOXEL_SIZE"], tc["OUT_SIZE_FACTOR"], 3, tc["MAX_OBJS"],
+                                             tc["GAUSSIAN_OVERLAP"], tc["MIN_RADIUS"])
+    outs = []
+    for _ in range(2):
+        tg = center_assign_targets(torch.from_numpy(gt)[None].cuda(), hc, grid, pr, 3)
+        outs.append([tg[k][0][0].cpu().numpy() for k in ("heatmaps", "anno_boxes", "inds", "masks")])
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    heat, anno, ind, mask = outs[0]
+    assert 20 < om.sum() < 100
+    np.testing.assert_array_equal(ind, oi)
+    np.testing.assert_array_equal(mask, om)
+    np.testing.assert_allclose(heat, oh, atol=0, rtol=2e-7)
+    np.testing.assert_array_equal(anno[:, :3], oa[:, :3])
+    np.testing.assert_allclose(anno[:, 3:], oa[:, 3:], atol=5e-7)
+
+
+@pytest.mark.gpu
+def test_center_head_loss_kernel_vs_reference(golden_dir):
+    import torch
+    from insmos_amd.autograd import center_head_loss
+    g = np.load(os.path.join(golden_dir, "center_loss.npz"))
+    tg = {"heatmaps": [torch.from_numpy(g["heatmap"])[None].cuda()], "anno_boxes": [torch.from_numpy(g["anno_box"])[None].cuda()],
+          "inds": [torch.from_numpy(g["ind"])[None].cuda()], "masks": [torch.from_numpy(g["mask"])[None].cuda()]}
+    cls = torch.from_numpy(g["cls_preds"]).cuda().requires_grad_(True)
+    box = torch.from_numpy(g["box_preds"]).cuda().requires_grad_(True)
+    loss, tb = center_head_loss(cls, box, tg, HEAD_CFG)
+    loss.backward()
+    assert abs(tb["rpn_loss_cls"] - float(g["loss_cls"])) < 2e-5 * float(g["loss_cls"])
+    assert abs(tb["rpn_loss_loc"] - float(g["loss_loc"])) < 2e-5 * float(g["loss_loc"])
+    assert abs(tb["rpn_loss"] - float(g["loss"])) < 2e-5 * float(g["loss"])
+    np.testing.assert_allclose(cls.grad.cpu().numpy(), g["grad_cls"], atol=3e-7, rtol=2e-4)
+    np.testing.assert_allclose(box.grad.cpu().numpy(), g["grad_box"], atol=1e-8, rtol=1e-5)
+    assert bool((cls.grad[0, 3, 4, :2] == 0).all())
+    # the oracle agrees to the same tolerance, and a second call gives the same bits (fixed-order reductions)
+    lc, ll, gc, gb = R.center_head_loss(g["cls_preds"][0], g["box_preds"][0], g["heatmap"], g["anno_box"], g["ind"], g["mask"])
+    assert abs(tb["rpn_loss"] - (lc + ll)) < 2e-5 * (lc + ll)
+    cls2 = torch.from_numpy(g["cls_preds"]).cuda().requires_grad_(True)
+    box2 = torch.from_numpy(g["box_preds"]).cuda().requires_grad_(True)
+    loss2, _ = center_head_loss(cls2, box2, tg, HEAD_CFG)
+    loss2.backward()
+    assert float(loss2.detach()) == float(loss.detach())
+    assert bool((cls2.grad == cls.grad).all()) and bool((box2.grad == box.grad).all())
+
+
+@pytest.mark.gpu
+def test_center_head_loss_full_map_vs_oracle():
+    """BASELINE cfg-2 head map (250 x 300 cells, 3 classes): targets from the kernel, loss + gradients against the oracle."""
+    import torch
+    from insmos_amd.autograd import center_assign_targets, center_head_loss
+    from insmos_amd import params as P
+    rng = np.random.default_rng(21)
+    cfg = P.default_cfg()
+    hc = cfg["MODEL"]["DENSE_HEAD"]
+    M = 60
+    gt = np.zeros((M, 8), np.float32)
+    gt[:, 0] = rng.uniform(-58, 58, M)
+    gt[:, 1] = rng.uniform(-48, 48, M)
+    gt[:, 2] = rng.uniform(-2, 0, M)
+    gt[:, 3:6] = rng.uniform(0.5, 5.0, (M, 3))
+    gt[:, 6] = rng.uniform(-3.2, 3.2, M)
+    gt[:, 7] = rng.integers(1, 4, M)
+    grid = np.array([1200, 1000, 40])
+    pr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
+    tg = center_assign_targets(torch.from_numpy(gt)[None].cuda(), hc, grid, pr, 3)
+    H, W = 250, 300
+    cls_np = (rng.normal(size=(1, H, W, 3)) * 1.5 - 3.0).astype(np.float32)
+    box_np = rng.normal(size=(1, H, W, 8)).astype(np.float32)
+    cls = torch.from_numpy(cls_np).cuda().requires_grad_(True)
+    box = torch.from_numpy(box_np).cuda().requires_grad_(True)
+    loss, tb = center_head_loss(cls, box, tg, hc)
+    loss.backward()
+    heat, anno = tg["heatmaps"][0][0].cpu().numpy(), tg["anno_boxes"][0][0].cpu().numpy()
+    ind, mask = tg["inds"][0][0].cpu().numpy(), tg["masks"][0][0].cpu().numpy()
+    lw = hc["LOSS_CONFIG"]["LOSS_WEIGHTS"]
+    lc, ll, gc, gb = R.center_head_loss(cls_np[0], box_np[0], heat, anno, ind, mask, lw["cls_weight"], lw["loc_weight"],
+                                        lw["code_weights"])
+    assert abs(tb["rpn_loss_cls"] - lc) < 1e-4 * lc and abs(tb["rpn_loss_loc"] - ll) < 1e-4 * ll
+    np.testing.assert_allclose(cls.grad.cpu().numpy()[0], gc, atol=3e-7, rtol=3e-4)
+    np.testing.assert_allclose(box.grad.cpu().numpy()[0], gb, atol=1e-8, rtol=1e-5)
+    assert int((box.grad != 0).any(dim=-1).sum()) <= int(mask.sum())
