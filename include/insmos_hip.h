@@ -437,6 +437,8 @@ typedef struct InsmosNetCfg {
 typedef struct InsmosForwardOut {
     int64_t me_voxels[4], n_cur, unet_voxels[5], n_candidates, n_boxes, n_out_of_window;
     int64_t logits_off, boxes_off, scores_off, labels_off, arena_needed;
+    int64_t cur_points_off; /* current_point (n_cur, 8) fp32 = [x, y, z, r, m0, m1, m2, 0] (motionnet.py:42-48): the motion
+                               features the 'eval' mode's motion loss is taken on (models/models.py:321-323) */
 } InsmosForwardOut;
 int insmos_ctx_create(const InsmosNetCfg* cfg, const char* const* names, const InsmosConvW* layers, int n_layers,
                       void** ctx_out);

@@ -111,7 +111,7 @@ class NetCfg(ctypes.Structure):  # InsmosNetCfg
 class ForwardOut(ctypes.Structure):  # InsmosForwardOut
     _fields_ = [("me_voxels", c_i64 * 4), ("n_cur", c_i64), ("unet_voxels", c_i64 * 5), ("n_candidates", c_i64),
                 ("n_boxes", c_i64), ("n_out_of_window", c_i64), ("logits_off", c_i64), ("boxes_off", c_i64),
-                ("scores_off", c_i64), ("labels_off", c_i64), ("arena_needed", c_i64)]
+                ("scores_off", c_i64), ("labels_off", c_i64), ("arena_needed", c_i64), ("cur_points_off", c_i64)]
 
 _lib = None
 

@@ -506,5 +506,6 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     out->scores_off = (int64_t)((char*)psc - (char*)arena);
     out->labels_off = (int64_t)((char*)pl - (char*)arena);
     out->arena_needed = (int64_t)A.off;
+    out->cur_points_off = (int64_t)((char*)cur - (char*)arena);
     return INSMOS_OK;
 }

@@ -98,6 +98,8 @@ class Engine:
         self.native = native      # default path of forward_window (see there)
         self.prune_dead_rows = True  # MotionNet decoder layers skip rows nothing consumes
         self.fuse_deconv_head = True  # BEV deblock + heads in one kernel (the step path can run them separately)
+        self.keep_current_points = False  # 'eval' mode: keep current_point (Ncur, 8) of the last window (motion loss)
+        self.last_current_points = None
         self._ctx_box = [None]    # native context, shared with clones
         self._arena = None
         self.cfg = cfg
@@ -443,6 +445,8 @@ class Engine:
                                                    cur_index.data_ptr(), ncur, cur.data_ptr(), 8, st),
                    "insmos_build_current_points")
         self._me_debug = dict(b3=b3, b8=b8, motion=motion, cat8=cat8)
+        if self.keep_current_points:
+            self.last_current_points = cur
         return cur
 
     # ------------------------------------------------------------------------------------------------
@@ -730,6 +734,8 @@ class Engine:
         pred = {"pred_boxes": view(out.boxes_off, K * 7, torch.float32, (K, 7)),
                 "pred_scores": view(out.scores_off, K, torch.float32, (K,)),
                 "pred_labels": view(out.labels_off, K, torch.int64, (K,))}
+        if self.keep_current_points:
+            self.last_current_points = view(out.cur_points_off, ncur * 8, torch.float32, (ncur, 8))
         return logits, pred
 
     def clone_shared(self):

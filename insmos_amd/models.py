@@ -8,8 +8,9 @@ models/models.py:269-376: three lists are returned (batch items may be in flight
   pred_dicts_list[i][0] = {"pred_boxes" (K,7) fp32, "pred_scores" (K,) fp32, "pred_labels" (K,) int64}
   recall_dicts_list[i]  = {}           (no gt_boxes on the test path, post_process.py:68-69)
   point_logits_list[i]  = (Ncur, 3) fp32 raw MOS logits, rows in the order of the t == 0 input rows.
-Only Model_mode == 'test' is implemented (the north-star path); 'train'/'eval' need ground truth and
-the training harness, which are out of scope.  No pytorch_lightning is needed: a Lightning .ckpt is a
+Model_mode 'test' (the north-star path) and 'eval' (the validation step's forward: the same path plus the two MOS losses,
+models/models.py:347-353) are implemented; 'train' is served by the separate training pieces (insmos_amd/autograd.py,
+train_motionnet.py).  No pytorch_lightning is needed: a Lightning .ckpt is a
 torch-pickled dict with "hyper_parameters" and "state_dict" (models/models.py:30,52).
 """
 import os
@@ -84,12 +85,25 @@ class InsMOS_Model:
         return self._workers[:3]
 
     def forward(self, list_batch_dict, Model_mode):
-        if Model_mode != "test":
-            raise NotImplementedError("insmos_amd implements the inference path: Model_mode == 'test'")
+        """'test' (models/models.py:355-359,375-376) and 'eval' (:347-353,369-373, the validation step: the same forward
+        plus MOSLoss on the point logits and on the motion features, needs batch_dict["past_labels"])."""
+        if Model_mode == "train":
+            raise NotImplementedError("Model_mode == 'train': the training pieces are insmos_amd.autograd / "
+                                      "insmos_amd.train_motionnet (DESIGN.md 1f); forward() serves 'test' and 'eval'")
+        if Model_mode not in ("test", "eval"):
+            raise ValueError(f"unknown Model_mode {Model_mode!r}")
+        keep = Model_mode == "eval"
         n = len(list_batch_dict)
         w = min(n, self.windows_in_flight)
+
+        def one(engine, b):
+            engine.keep_current_points = keep
+            logits, pred = engine.forward_window(b["past_point_clouds"])
+            cur_pts, engine.last_current_points = engine.last_current_points, None
+            return logits, pred, cur_pts
+
         if w <= 1:
-            results = [self.engine.forward_window(b["past_point_clouds"]) for b in list_batch_dict]
+            results = [one(self.engine, b) for b in list_batch_dict]
         else:
             engines, streams, pool = self._get_workers(w)
             dev = torch.device(self.device)
@@ -101,23 +115,45 @@ class InsMOS_Model:
                 streams[wi].wait_stream(cur)  # the inputs were produced on the caller's stream
                 with torch.cuda.stream(streams[wi]):
                     for i in range(wi, n, w):
-                        results[i] = engines[wi].forward_window(list_batch_dict[i]["past_point_clouds"])
+                        results[i] = one(engines[wi], list_batch_dict[i])
 
             for f in [pool.submit(run, wi) for wi in range(w)]:
                 f.result()  # re-raises worker exceptions
             for st in streams[:w]:
                 cur.wait_stream(st)
-            for logits, pred in results:
-                for t in (logits, *pred.values()):
+            for logits, pred, cur_pts in results:
+                for t in (logits, *pred.values(), *([cur_pts] if cur_pts is not None else [])):
                     t.record_stream(cur)  # allocated on a worker stream, consumed on the caller's
         preb_dict_list, recall_dict_list, preb_mos_lable_list = [], [], []
         thresh = self.cfg["MODEL"]["POST_PROCESSING"].get("RECALL_THRESH_LIST", [0.3, 0.5, 0.7])
-        for b, (logits, pred) in zip(list_batch_dict, results):
+        for b, (logits, pred, _) in zip(list_batch_dict, results):
             preb_dict_list.append([pred])
             # post_process.py:216-220: recall bookkeeping only when the batch carries ground-truth boxes (validation)
             recall_dict_list.append(generate_recall_record(pred["pred_boxes"], {}, 0, b, thresh) if "gt_boxes" in b else {})
             preb_mos_lable_list.append(logits)
-        return preb_dict_list, recall_dict_list, preb_mos_lable_list
+        if Model_mode == "test":
+            return preb_dict_list, recall_dict_list, preb_mos_lable_list
+        # ---- 'eval': models/models.py:321-323 (motion loss on current_motion_feature[:, :3]), :350 (loss on the logits),
+        # :369-373 (means over the batch items; val_loss as a Python float, val_motion_loss as a (1,) tensor)
+        from .autograd import mos_loss
+        gt_mos_label_list = []
+        val_loss = torch.zeros(1, device=self.device)
+        val_motion_loss = torch.zeros(1, device=self.device)
+        with torch.no_grad():
+            for b, (logits, _, cur_pts) in zip(list_batch_dict, results):
+                gt = b["past_labels"][-1]
+                if int(gt.shape[0]) != int(logits.shape[0]):
+                    raise ValueError(f"past_labels[-1] has {int(gt.shape[0])} labels for {int(logits.shape[0])} current points")
+                motion = cur_pts[:, 4:4 + self.mos_class]  # use_motion_loss False keeps the first 3 columns (:318-319)
+                val_motion_loss = val_motion_loss + mos_loss(motion, gt, self.mos_class, self.ignore_index)
+                val_loss = val_loss + mos_loss(logits, gt, self.mos_class, self.ignore_index)
+                # MOSLoss.compute_loss overwrites the ignored columns of ITS INPUT with -inf (loss.py:25), and that input
+                # is the tensor the reference hands back as the prediction (:353) -- so do the returned logits
+                logits[:, list(self.ignore_index)] = float("-inf")
+                gt_mos_label_list.append(gt)
+        val_loss = val_loss / n
+        val_motion_loss = val_motion_loss / n
+        return (preb_dict_list, recall_dict_list, gt_mos_label_list, preb_mos_lable_list, val_loss.item(), val_motion_loss)
 
     __call__ = forward
 

@@ -132,6 +132,53 @@ def test_windows_in_flight_match_sequential(setup):
             assert torch.equal(p1[0][0][k], pr[k]), k
 
 
+def test_eval_mode_is_test_mode_plus_the_two_losses(setup):
+    """Model_mode 'eval' (models/models.py:347-353, 369-373): same predictions as 'test', MOSLoss of the point logits and of
+    the motion features against past_labels[-1] (oracle: ref_ops.mos_loss on the oracle's own logits / current_point),
+    six return values, ignored logit column overwritten with -inf as MOSLoss.compute_loss does to its input."""
+    model, window, dbg = setup["model"], setup["window"], setup["dbg"]
+    rng = np.random.default_rng(3)
+    ncur = int((window[:, 4] == 0).sum())
+    gts = [torch.from_numpy(rng.integers(0, 3, ncur)).cuda() for _ in range(3)]
+    pts = torch.from_numpy(window).cuda()
+    batch = [{"past_point_clouds": pts, "past_labels": [None, gts[i]]} for i in range(3)]
+    with torch.no_grad():
+        p_test, _, l_test = model.forward([{"past_point_clouds": pts}], "test")
+        out = model.forward(batch, "eval")
+    assert len(out) == 6
+    preds, recalls, gt_list, logits_list, val_loss, val_motion_loss = out
+    assert isinstance(val_loss, float) and tuple(val_motion_loss.shape) == (1,)
+    assert len(preds) == len(recalls) == len(gt_list) == len(logits_list) == 3
+    exp_loss, exp_motion, own_loss = 0.0, 0.0, 0.0
+    own_logits = l_test[0].cpu().numpy()
+    for i in range(3):
+        assert gt_list[i] is gts[i]
+        assert bool(torch.isinf(logits_list[i][:, 0]).all()) and bool((logits_list[i][:, 0] < 0).all())
+        assert torch.equal(logits_list[i][:, 1:], l_test[0][:, 1:])
+        for k in p_test[0][0]:
+            assert torch.equal(preds[i][0][k], p_test[0][0][k])
+        g = gts[i].cpu().numpy()
+        exp_loss += R.mos_loss(setup["ref_logits"], g)[0] / 3
+        exp_motion += R.mos_loss(dbg["current_point"][:, 4:7], g)[0] / 3
+        own_loss += R.mos_loss(own_logits, g)[0] / 3
+    assert abs(val_loss - own_loss) < 2e-5 * max(1.0, abs(own_loss))   # the loss kernel on the path's own logits
+    assert abs(val_loss - exp_loss) < 1e-3 * max(1.0, abs(exp_loss))   # ... and end to end against the oracle's logits
+    assert abs(float(val_motion_loss[0]) - exp_motion) < 1e-3 * max(1.0, abs(exp_motion))
+    # the motion features the loss was taken on are the native runner's current_point columns == the step path's
+    eng = model.model.engine
+    eng.keep_current_points = True
+    eng.forward_window(pts)
+    native_cur = eng.last_current_points.clone()
+    eng.forward_window(pts, native=False)
+    assert torch.equal(native_cur, eng.last_current_points)
+    eng.keep_current_points = False
+    np.testing.assert_allclose(native_cur[:, :7].cpu().numpy(), dbg["current_point"][:, :7], atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        model.forward(batch, "train")
+    with pytest.raises(ValueError):
+        model.forward([{"past_point_clouds": pts, "past_labels": [gts[0][:-1]]}], "eval")
+
+
 def test_native_runner_arena_growth_and_errors(setup):
     """The native runner grows its arena on INSMOS_EWORKSPACE and reports the reference-visible input errors."""
     from insmos_amd.engine import Engine
