@@ -450,6 +450,46 @@ class Engine:
         return cur
 
     # ------------------------------------------------------------------------------------------------
+    def detect(self, head, up):
+        """CenterHead decode + post_processing (center_head.py:251-276, post_process.py:112-224) on a head map
+        (n_cells, head_ld) = [cls | box] rows: up=2 -> the deconv's sub-site row order, up=1 -> plain [row][col] order.
+        -> (pred_boxes (post_max, 7), scores, labels int64, count (device), candidate count (device), candidates...)."""
+        lib, st, E = self.lib, self._stream(), self._empty
+        H2, W2 = 2 * self.bevH, 2 * self.bevW
+        ncell = H2 * W2
+        cb, cs = E((self.pre_max, 7)), E((self.pre_max,))
+        cl, cc = E((self.pre_max,), torch.int32), E((self.pre_max,), torch.int32)
+        cnt_c = E((4,), torch.int32)
+        w = self._workspace(lib.insmos_center_decode_select_ws_bytes(ncell))
+        _lib.check(lib.insmos_center_decode_select(head.data_ptr(), self.head_ld, self.ncls, H2, W2, up, self.out_factor,
+                                                   self.tvs[0], self.tvs[1], self.range[0], self.range[1],
+                                                   self.score_thresh, self.pre_max, cb.data_ptr(), cs.data_ptr(),
+                                                   cl.data_ptr(), cc.data_ptr(), cnt_c.data_ptr(), w.data_ptr(), w.numel(),
+                                                   st), "insmos_center_decode_select")
+        keep = E((self.post_max,), torch.int32)
+        cnt_k = E((4,), torch.int32)
+        w = self._workspace(lib.insmos_nms_ws_bytes(self.pre_max))
+        _lib.check(lib.insmos_nms_rotated_bev(cb.data_ptr(), cnt_c.data_ptr(), self.pre_max, self.nms_thresh,
+                                              self.post_max, keep.data_ptr(), cnt_k.data_ptr(), w.data_ptr(), w.numel(),
+                                              st), "insmos_nms_rotated_bev")
+        pb, psc = E((self.post_max, 7)), E((self.post_max,))
+        pl = E((self.post_max,), torch.int64)
+        _lib.check(lib.insmos_gather_preds(cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), keep.data_ptr(),
+                                           cnt_k.data_ptr(), self.post_max, pb.data_ptr(), psc.data_ptr(), pl.data_ptr(),
+                                           st), "insmos_gather_preds")
+        return pb, psc, pl, cnt_k, cnt_c, cb, cs, cl, cc, keep
+
+    def instance_onehot(self, pb, pl, cnt_k, level_coords, n, mult, out, ld, col, scratch):
+        """Array_Index.find_features_by_bbox_with_yaw at one decoder level (spconv_unet.py:322-345): boxes scaled to that
+        level's voxel units (stride 8 / mult), one-hot class columns written at out[:, col:col+ncls]."""
+        lo = np.array(self.range[0:3], dtype=np.float32)
+        vsz = np.array(self.vs, dtype=np.float32)
+        _lib.check(self.lib.insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), cnt_k.data_ptr(), self.post_max, _hp(lo),
+                                                   _hp(vsz), 8.0, float(mult), level_coords.data_ptr(), n, self.ncls,
+                                                   16, 1 if self.quirk_exact else 0, out.data_ptr() + 4 * col, ld,
+                                                   scratch.data_ptr(), self._stream()), "insmos_boxes_to_onehot")
+
+    # ------------------------------------------------------------------------------------------------
     def unet(self, cur):
         """cur (Ncur, 8) -> (point logits (Ncur,3), pred dict of device tensors)."""
         lib, st, E, L = self.lib, self._stream(), self._empty, self.L
@@ -564,39 +604,15 @@ class Engine:
             upf = E((nsite, 4 * upc))
             self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
             self.conv(L["head"], upf, upc, None, ncell, head, self.head_ld, n_in=ncell)  # upf viewed as (4*nsite, upc)
-        H2, W2 = 2 * self.bevH, 2 * self.bevW
-        cb, cs = E((self.pre_max, 7)), E((self.pre_max,))
-        cl, cc = E((self.pre_max,), torch.int32), E((self.pre_max,), torch.int32)
-        cnt_c = E((4,), torch.int32)
-        w = self._workspace(lib.insmos_center_decode_select_ws_bytes(ncell))
-        _lib.check(lib.insmos_center_decode_select(head.data_ptr(), self.head_ld, ncls, H2, W2, 2, self.out_factor,
-                                                   self.tvs[0], self.tvs[1], self.range[0], self.range[1],
-                                                   self.score_thresh, self.pre_max, cb.data_ptr(), cs.data_ptr(),
-                                                   cl.data_ptr(), cc.data_ptr(), cnt_c.data_ptr(), w.data_ptr(), w.numel(),
-                                                   st), "insmos_center_decode_select")
-        keep = E((self.post_max,), torch.int32)
-        cnt_k = E((4,), torch.int32)
-        w = self._workspace(lib.insmos_nms_ws_bytes(self.pre_max))
-        _lib.check(lib.insmos_nms_rotated_bev(cb.data_ptr(), cnt_c.data_ptr(), self.pre_max, self.nms_thresh,
-                                              self.post_max, keep.data_ptr(), cnt_k.data_ptr(), w.data_ptr(), w.numel(),
-                                              st), "insmos_nms_rotated_bev")
-        pb, psc = E((self.post_max, 7)), E((self.post_max,))
-        pl = E((self.post_max,), torch.int64)
-        _lib.check(lib.insmos_gather_preds(cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), keep.data_ptr(),
-                                           cnt_k.data_ptr(), self.post_max, pb.data_ptr(), psc.data_ptr(), pl.data_ptr(),
-                                           st), "insmos_gather_preds")
+        pb, psc, pl, cnt_k, cnt_c, cb, cs, cl, cc, keep = self.detect(head, up=2)
         self._head_debug = dict(head=head, cand_boxes=cb, cand_scores=cs, cand_labels=cl, cand_cell=cc, n_cand=cnt_c,
                                 keep=keep, spatial_features_2d=upf, bev=bev)
 
         # ---- upsample fusion (spconv_unet.py:319-402)
         scratch = E((int(lib.insmos_boxes_to_onehot_scratch_ints(self.post_max, max(nv.values()))),), torch.int32)
-        lo = np.array(self.range[0:3], dtype=np.float32)
 
         def onehot(level, mult, out, ld, col):
-            _lib.check(lib.insmos_boxes_to_onehot(pb.data_ptr(), pl.data_ptr(), cnt_k.data_ptr(), self.post_max, _hp(lo),
-                                                  _hp(vsz), 8.0, float(mult), coords[level].data_ptr(), nv[level], ncls,
-                                                  16, 1 if self.quirk_exact else 0, out.data_ptr() + 4 * col, ld,
-                                                  scratch.data_ptr(), st), "insmos_boxes_to_onehot")
+            self.instance_onehot(pb, pl, cnt_k, coords[level], nv[level], mult, out, ld, col, scratch)
 
         def ur_block(lvl, C, x_lat, ld_lat, catm):
             """UR_block_forward up to (not including) conv_inv; catm[:, 0:C] already holds x_bottom."""

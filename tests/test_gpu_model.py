@@ -179,6 +179,42 @@ def test_eval_mode_is_test_mode_plus_the_two_losses(setup):
         model.forward([{"past_point_clouds": pts, "past_labels": [gts[0][:-1]]}], "eval")
 
 
+def test_training_graph_on_running_stats_reproduces_inference(setup):
+    """insmos_amd/train_unet.py with BatchNorm on running statistics == the (oracle-checked) inference path: pins the
+    training graph's wiring (layer order, concatenations, pair-sum reduction, BEV scatter, deconv table, point gather)."""
+    from insmos_amd.engine import Engine
+    from insmos_amd.train_unet import UNetV2Trainer
+    cfg, window, sd = setup["cfg"], setup["window"], setup["sd"]
+    eng = Engine(cfg, sd, "cuda:0")
+    eng.keep_current_points = True
+    pts = torch.from_numpy(window).cuda()
+    logits_inf, pred_inf = eng.forward_window(pts, native=False)
+    cur = eng.last_current_points.clone()
+    head_inf = eng._head_debug["head"].clone()
+    H, W = eng.bevH, eng.bevW
+    tr = UNetV2Trainer(cfg, sd, engine=eng)
+    tr.bn_training = False
+    with torch.no_grad():
+        out = tr.forward(cur)
+    # head maps: the inference head rows are in the deconv's [y][x][ky][kx] sub-site order
+    hi = head_inf.view(H, W, 2, 2, -1).permute(0, 2, 1, 3, 4).reshape(4 * H * W, -1)
+    d_cls = float((out["cls_preds"].reshape(-1, 3) - hi[:, :3]).abs().max())
+    d_box = float((out["box_preds"].reshape(-1, 8) - hi[:, 3:11]).abs().max())
+    d_log = float((out["point_logits"] - logits_inf).abs().max())
+    print("max abs diff: cls %.2e box %.2e point logits %.2e; boxes %d vs %d" %
+          (d_cls, d_box, d_log, len(out["pred_dicts"][0]["pred_boxes"]), len(pred_inf["pred_boxes"])))
+    assert d_cls < 1e-3 and d_box < 1e-3
+    assert len(pred_inf["pred_boxes"]) > 0
+    assert len(out["pred_dicts"][0]["pred_boxes"]) == len(pred_inf["pred_boxes"])
+    assert float((out["pred_dicts"][0]["pred_boxes"] - pred_inf["pred_boxes"]).abs().max()) < 1e-3
+    assert torch.equal(out["pred_dicts"][0]["pred_labels"], pred_inf["pred_labels"])
+    assert d_log < 1e-3
+    # the tap-layout round trip: exported parameters are the checkpoint's
+    exp = tr.export_state_dict()
+    for k, v in exp.items():
+        np.testing.assert_array_equal(v, np.asarray(sd[k], np.float32).reshape(v.shape), err_msg=k)
+
+
 def test_native_runner_arena_growth_and_errors(setup):
     """The native runner grows its arena on INSMOS_EWORKSPACE and reports the reference-visible input errors."""
     from insmos_amd.engine import Engine

@@ -194,3 +194,40 @@ def test_bucketed_grad_reducer_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_unet_trainer_layouts_round_trip_and_deconv_table():
+    """Host side of insmos_amd/train_unet.py (no GPU): checkpoint layout -> tap layout -> export is the identity, and the
+    4-tap table that stands for ConvTranspose2d(2, 2) reproduces torch's conv_transpose2d."""
+    import types
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd import params as P
+    from insmos_amd.train_unet import UNetV2Trainer
+    cfg = P.default_cfg()
+    sd = P.random_state_dict(cfg, 3)
+    H, W = 3, 5
+    tr = UNetV2Trainer(cfg, sd, device="cpu", engine=types.SimpleNamespace(bevH=H, bevW=W))
+    exp = tr.export_state_dict()
+    unet_keys = [k for k in P.param_spec(cfg) if k.startswith(P.UNET_PREFIX)]
+    assert sorted(exp) == sorted(unet_keys)
+    for k in unet_keys:
+        np.testing.assert_array_equal(exp[k], np.asarray(sd[k], np.float32), err_msg=k)
+    assert all(not v.requires_grad for v in tr.buffers.values()) and all(v.requires_grad for v in tr.params.values())
+    nbr, nbr_t = tr._deconv_nbr()
+    assert nbr.shape == (4, 4 * H * W) and nbr_t.shape == (4, H * W)
+    assert int((nbr >= 0).sum()) == 4 * H * W and int((nbr_t >= 0).sum()) == 4 * H * W
+    for k in range(4):
+        o = torch.nonzero(nbr[k] >= 0).flatten()
+        assert torch.equal(nbr_t[k][nbr[k][o].long()].long(), o)   # transposed table: nbr_t[k][i] = o <=> nbr[k][o] = i
+    rng = np.random.default_rng(0)
+    ci, co = 6, 4
+    wt = torch.from_numpy(rng.normal(size=(ci, co, 2, 2)).astype(np.float32))
+    x = torch.from_numpy(rng.normal(size=(H * W, ci)).astype(np.float32))
+    taps = torch.from_numpy(P.convT2d_weight_to_taps(wt.numpy()))
+    y = torch.zeros((4 * H * W, co))
+    for k in range(4):
+        o = torch.nonzero(nbr[k] >= 0).flatten()
+        y[o] += x[nbr[k][o].long()] @ taps[k]
+    ref = F.conv_transpose2d(x.T.reshape(1, ci, H, W), wt, stride=2)[0].permute(1, 2, 0).reshape(4 * H * W, co)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-5)
