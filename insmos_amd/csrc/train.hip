@@ -11,6 +11,7 @@
 //   d/db      db    = sum_o dy[o]                     -- k_col_sum (two stages, fixed order)
 //   loss      MOSLoss.compute_loss (models/loss.py:20-34): ignored classes -> -inf, softmax, log(clamp(., 1e-8)),
 //             class-weighted NLL; k_mos_loss writes the per-point terms and d loss / d logits, reduced in fixed order.
+#include <cstdlib>
 #include "common.h"
 
 namespace insmos {
@@ -84,6 +85,69 @@ __global__ void __launch_bounds__(256) k_conv_dw(const float* __restrict__ x, in
     }
     const int gci = ci_t * 16 + ci, gco = co_t * 16 + co;
     if (gci < cin && gco < cout) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + gco] = acc;
+}
+
+// ---- dW on the matrix cores (EXPERIMENTAL: selected with INSMOS_DW_MFMA=1; written at the end of round 1 and not yet run
+// on hardware -- the default stays k_conv_dw until tests/test_train_slice.py has passed with the flag set) ----
+// D[i = ci][j = co] += sum_r A[i][r] * B[r][j] with the contraction over ROWS, 4 rows per v_mfma_f32_16x16x4_f32:
+//   A[i = lane & 15][r = lane >> 4] = x[nbr[k][o_r]][ci0 + i]   (0 where the row has no neighbour under tap k)
+//   B[r = lane >> 4][j = lane & 15] = dy[o_r][co0 + j]
+// One wave = one (row chunk, tap, 16-channel ci tile) and NT co tiles (NT * 4 accumulator registers); 64 neighbour
+// indices are fetched per 64 rows and broadcast per 4-row step; a step whose four rows all lack the tap is skipped
+// (wave-uniform).  Rows are visited in ascending order and the per-chunk partial sums are reduced in fixed order by
+// k_conv_dw_reduce, so the result is deterministic (it differs from k_conv_dw's only in summation order).
+#define DW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ void __launch_bounds__(64) k_conv_dw_mfma(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
+                                                     int ld_dy, const int32_t* __restrict__ nbr, int64_t n_out, int cin,
+                                                     int cout, int rows_per_chunk, int n_co_groups,
+                                                     float* __restrict__ partial, int K) {
+    const int chunk = blockIdx.x, k = blockIdx.y;
+    const int ci_t = blockIdx.z / n_co_groups, co_g = blockIdx.z % n_co_groups;
+    const int lane = threadIdx.x, li = lane & 15, lr = lane >> 4;
+    const int ci = ci_t * 16 + li;
+    const bool ci_ok = ci < cin;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    const int64_t r_end = min(r_begin + rows_per_chunk, n_out);
+    dw_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    int co[NT];
+    bool co_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        co[t] = (co_g * NT + t) * 16 + li;
+        co_ok[t] = co[t] < cout;
+    }
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+        const int64_t o_mine = r0 + lane;
+        const int idx64 = (o_mine < r_end) ? (nbr ? nbr[(int64_t)k * n_out + o_mine] : (int)o_mine) : -1;
+        if (__ballot(idx64 >= 0) == 0ull) continue;
+#pragma unroll 4
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int idx = __shfl(idx64, 4 * sidx + lr, 64);  // neighbour of row r0 + 4*sidx + lr
+            if (__ballot(idx >= 0) == 0ull) continue;            // wave-uniform: none of the four rows has tap k
+            const int64_t o = r0 + 4 * sidx + lr;
+            const float a = (idx >= 0 && ci_ok) ? x[(int64_t)idx * ld_x + ci] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = (idx >= 0 && co_ok[t]) ? dy[o * ld_dy + co[t]] : 0.f;
+                acc[t] = DW_MFMA(a, b, acc[t]);
+            }
+        }
+    }
+    // D[i = 4 * (lane >> 4) + reg][j = lane & 15]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!co_ok[t]) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int gci = ci_t * 16 + 4 * lr + reg;
+            if (gci < cin) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + co[t]] = acc[t][reg];
+        }
+    }
 }
 
 __global__ void k_conv_dw_reduce(const float* __restrict__ partial, int n_chunks, int64_t per_chunk, float* __restrict__ dw,
@@ -276,6 +340,17 @@ extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, 
     const int nch = dw_chunks(n_out, &rpc);
     const int n_ci = (cin + 15) / 16, n_co = (cout + 15) / 16;
     ProfScope ps(KK_SPARSE_CONV, s);
+    static const bool use_mfma = [] { const char* e = getenv("INSMOS_DW_MFMA"); return e && e[0] == '1'; }();
+    if (use_mfma) {
+        // co tiles per wave: as many as the layer has, up to 8 (32 accumulator registers)
+        const int nt = n_co >= 8 ? 8 : n_co >= 4 ? 4 : n_co >= 2 ? 2 : 1;
+        const int n_cg = (n_co + nt - 1) / nt;
+        const dim3 grid(nch, K, n_ci * n_cg);
+        if (nt == 8) INSMOS_LAUNCH(k_conv_dw_mfma<8>, grid, dim3(64), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_cg, ws, K);
+        else if (nt == 4) INSMOS_LAUNCH(k_conv_dw_mfma<4>, grid, dim3(64), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_cg, ws, K);
+        else if (nt == 2) INSMOS_LAUNCH(k_conv_dw_mfma<2>, grid, dim3(64), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_cg, ws, K);
+        else INSMOS_LAUNCH(k_conv_dw_mfma<1>, grid, dim3(64), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_cg, ws, K);
+    } else
     INSMOS_LAUNCH(k_conv_dw, dim3(nch, K, n_ci * n_co), dim3(256), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_co, ws,
                   K);
     const int64_t per = (int64_t)K * cin * cout;

@@ -75,6 +75,21 @@ def _padc(c):
     return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
 
 
+class _NativeCtx:
+    """Owner of one insmos_ctx_create handle (destroyed with the last reference)."""
+
+    def __init__(self, lib, handle, keepalive):
+        self.lib, self.handle, self.keepalive = lib, handle, keepalive
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.lib is not None:
+                self.lib.insmos_ctx_destroy(self.handle)
+        except Exception:  # interpreter shutdown: the library may already be gone
+            pass
+        self.handle = None
+
+
 class NbrTable:
     """Output-stationary neighbour table + its per-16-row-group active-tap bitmasks."""
 
@@ -155,7 +170,7 @@ class Engine:
 
     def _load_weights(self, sd):
         self.sd = sd
-        self._ctx_box = [None]  # (old contexts are leaked on purpose: clones may still run on them)
+        self._ctx_box = [None]  # a fresh box: clones made earlier keep (and may still run on) the old context
         L, dev, lib = {}, self.device, self.lib
         M = P.ME_PREFIX
 
@@ -713,8 +728,10 @@ class Engine:
             ctx = ctypes.c_void_p()
             _lib.check(self.lib.insmos_ctx_create(ctypes.byref(cfgs), arr_n, arr_l, len(names), ctypes.byref(ctx)),
                        "insmos_ctx_create")
-            self._ctx_box[0] = ctx
-        return self._ctx_box[0]
+            # the holder frees the C++ object when the last engine (or clone) that can still run on it lets go of the box;
+            # it also keeps the device tensors the context points at alive for as long as the context exists
+            self._ctx_box[0] = _NativeCtx(self.lib, ctx, (self.L, self.w0_const, self.b0_const, self.nbr_bev))
+        return self._ctx_box[0].handle
 
     def _forward_native(self, pts):
         if not self.const_input:
