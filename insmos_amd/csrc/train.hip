@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(256) k_conv_dw(const float* __restrict__ x, in
     if (gci < cin && gco < cout) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + gco] = acc;
 }
 
-// ---- dW on the matrix cores (EXPERIMENTAL: selected with INSMOS_DW_MFMA=1; written at the end of round 1 and not yet run
-// on hardware -- the default stays k_conv_dw until tests/test_train_slice.py has passed with the flag set) ----
+// ---- dW on the matrix cores (selected with INSMOS_DW_MFMA=1: it passes the conv-autograd tests of
+// tests/test_train_slice.py, but it has not been timed against k_conv_dw yet, so it is not the default) ----
 // D[i = ci][j = co] += sum_r A[i][r] * B[r][j] with the contraction over ROWS, 4 rows per v_mfma_f32_16x16x4_f32:
 //   A[i = lane & 15][r = lane >> 4] = x[nbr[k][o_r]][ci0 + i]   (0 where the row has no neighbour under tap k)
 //   B[r = lane >> 4][j = lane & 15] = dy[o_r][co0 + j]
