@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--n-az", type=int, default=1886, help="azimuth steps of the synthetic scan (1886 = S0, 120k pts)")
     ap.add_argument("--candidates", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-az", type=int, default=472)
+    ap.add_argument("--cpu-sample-az", type=int, default=944,
+                    help="azimuth steps of the CPU-baseline sample window (944 = half of S0: ~12 s of oracle time on the GPU box)")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
     ap.add_argument("--windows-per-step", type=int, default=8, help="batch items of one forward() = one step")
     args = ap.parse_args()

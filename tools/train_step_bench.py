@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""tools/train_step_bench.py -- time of one FULL training step (InsMOSTrainer: MotionNet + 3D branch in train mode, the
+four losses, backward, Adam) on the S0 window, with the per-kernel-class breakdown from the library's own profiler.
+
+    python tools/train_step_bench.py [n_az]                 # default 1886 (S0, 1.2 M points)
+    INSMOS_DW_MFMA=1 python tools/train_step_bench.py       # the MFMA dW kernel instead of the LDS one
+"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from insmos_amd import params as P  # noqa: E402
+from insmos_amd.synth import make_labels  # noqa: E402
+from insmos_amd.train_unet import InsMOSTrainer  # noqa: E402
+
+n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 1886
+cfg = P.default_cfg()
+w = bench.load_window(0, n_az)
+rng = np.random.default_rng(0)
+M = 40
+gt_boxes = np.zeros((1, M, 8), np.float32)
+gt_boxes[0, :, 0] = rng.uniform(-55, 55, M)
+gt_boxes[0, :, 1] = rng.uniform(-45, 45, M)
+gt_boxes[0, :, 2] = rng.uniform(-1.5, -0.5, M)
+gt_boxes[0, :, 3:6] = rng.uniform([1.5, 0.6, 1.2], [4.5, 2.0, 1.8], (M, 3))
+gt_boxes[0, :, 6] = rng.uniform(-3.1, 3.1, M)
+gt_boxes[0, :, 7] = rng.integers(1, 4, M)
+batch = [{"past_point_clouds": torch.from_numpy(w).cuda(),
+          "past_labels": [None, torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=0)).cuda()],
+          "gt_boxes": torch.from_numpy(gt_boxes).cuda()}]
+tr = InsMOSTrainer(cfg, P.random_state_dict(cfg, 0, cls_bias=-2.0, box_w_std=0.05))
+opt = torch.optim.Adam(list(tr.params.values()), lr=float(cfg["TRAIN"]["LR"]),
+                       weight_decay=float(cfg["TRAIN"].get("WEIGHT_DECAY", 0.0)))  # models/models.py:188-193
+lib = tr.motion.engine.lib
+steps, warm = 4, 2
+for i in range(warm + steps):
+    if i == warm:
+        torch.cuda.synchronize()
+        lib.insmos_prof_reset()
+        lib.insmos_prof_enable(1)
+        t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    loss, tb, _, _ = tr.forward(batch, "train")
+    loss.backward()
+    opt.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+prof = bench.read_profile(lib)
+lib.insmos_prof_enable(0)
+print(f"full training step, {len(w)} points: {dt * 1e3:.1f} ms (loss {float(loss.detach()):.4f}, {tb[0]}); "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; INSMOS_DW_MFMA={os.environ.get('INSMOS_DW_MFMA', '0')}",
+      flush=True)
+for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f"    {k:24s} {ms / steps:9.3f} ms/step  {cnt // steps:6d} launches/step")
