@@ -150,6 +150,10 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
 
 def main():
     ap = argparse.ArgumentParser(description="InsMOS inference on MI355X (counterpart of scripts/predict_mos.py)")
+    ap.add_argument("--cfg_file", type=str, default="config/config.yaml",
+                    help="accepted for command-line compatibility; like the reference (predict_mos.py:288) the configuration "
+                         "is taken from the checkpoint's hyper_parameters, not from this file")
+    ap.add_argument("--ext", type=str, default=".bin", help="accepted for compatibility (unused by the reference too)")
     ap.add_argument("--ckpt", type=str, default=None, help="Lightning checkpoint; omitted -> seeded random weights")
     ap.add_argument("--data_path", type=str, required=True, help="root holding <seq>/velodyne, poses.txt, calib.txt")
     ap.add_argument("--split", type=str, default="valid", help="valid (seq 08) or test (11..21), as the reference")
