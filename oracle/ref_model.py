@@ -14,7 +14,11 @@ Follows, layer by layer:
   post_processing              models/post_process.py:112-224
 BatchNorm is applied as a separate eval-mode op after each conv, as the reference does (the HIP
 path folds it into the taps; the difference is fp32 round-off and is covered by the tolerance).
-PARITY UNPINNED for the ME/spconv layers (see ref_ops.py); pinned pieces are marked there.
+PARITY UNPINNED for the ME/spconv PRIMITIVES (see ref_ops.py); pinned pieces are marked there.
+The WIRING of this file (layer list, indice keys, concatenations, box scaling, instance features, gathers) and every
+checkpoint parameter name / shape ARE pinned: tests/golden/wiring.npz holds the output of the reference's own model
+classes, imported from the reference as written and run over stand-ins of the two missing libraries that are backed by
+ref_ops.py (oracle/shims/README.md); test_restated_wiring_vs_reference_model_code compares this file against it.
 """
 import numpy as np
 

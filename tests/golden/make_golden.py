@@ -425,6 +425,82 @@ def center_loss_golden():
     print("center_loss golden:", tb, "positives", int((heat == 1).sum()), "mask", mask.numpy().tolist())
 
 
+def wiring_golden():
+    """The reference's OWN model code (models/backbones_3d/{motionnet,voxel_generate,spconv_unet}.py, models/MinkowskiEngine/
+    {minkunet,resnet,customminkunet}.py, mean_vfe / height_compression / base_bev_backbone / center_head / post_process /
+    compiled Array_Index) executed as written over the stand-ins of oracle/shims (primitives = the oracle's), with a seeded
+    checkpoint loaded by name.  Pins (1) every parameter name and shape of insmos_amd/params.py to the reference's module
+    definitions, (2) the restated WIRING of oracle/ref_model.py.  It does NOT pin MinkowskiEngine / spconv primitive
+    semantics (oracle/shims/README.md)."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from insmos_amd import params as P
+    from insmos_amd.synth import make_window
+    from model_util import detecting_state_dict
+    import Array_Index
+    import models.utils as mutils  # namespace package of the reference; the extension is built in place there upstream
+    mutils.Array_Index = Array_Index
+    sys.modules["models.utils.Array_Index"] = Array_Index
+    stub = types.ModuleType("models.bbox_post_process.iou3d_nms_cuda")
+
+    def nms_gpu(boxes, keep_t, thresh):
+        bnp = boxes.detach().cpu().numpy()
+        k = greedy_keep(ref_iou(bnp, bnp), thresh)
+        keep_t[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    stub.nms_gpu = nms_gpu
+    sys.modules["models.bbox_post_process.iou3d_nms_cuda"] = stub
+    torch.Tensor.cuda = lambda self, *a, **k: self  # container-only: the reference calls .cuda() on the keep buffer
+    from models.backbones_3d.motionnet import MotionNet
+    from models.backbones_3d.voxel_generate import VoxelGenerate
+    from models.backbones_3d.spconv_unet import UNetV2
+    from models.backbones_2d.mean_vfe import MeanVFE
+
+    cfg = P.default_cfg()
+    window = make_window(seed=21, n_scans=3, n_az=160)
+    sd = detecting_state_dict(cfg, window, seed=4, target=(60, 200))
+    # ---- the reference's constructors, as models/models.py:273-294 calls them
+    pcr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
+    vs = cfg["DATA"]["VOXEL_SIZE"]
+    grid = np.round((pcr[3:6] - pcr[0:3]) / np.array(vs)).astype(np.int64)
+    in_ch = len(cfg["MODEL"]["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
+    motion = MotionNet(cfg["MODEL"]["DELTA_T_PREDICTION"], vs, 3)
+    voxgen = VoxelGenerate(vs, pcr, 100000, 5, in_ch)
+    vfe = MeanVFE(cfg["MODEL"]["VFE"], in_ch)
+    unet = UNetV2(cfg, in_ch, grid, vs, pcr, 3)
+    report = {}
+    for mod, prefix in ((motion, P.ME_PREFIX.rsplit("MinkUNet.", 1)[0]), (unet, P.UNET_PREFIX)):
+        sub = {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in sd.items() if k.startswith(prefix)}
+        res = mod.load_state_dict(sub, strict=False)
+        missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+        assert not missing and not res.unexpected_keys, (prefix, missing[:5], res.unexpected_keys[:5])
+        report[prefix] = len(sub)
+        mod.eval()
+    n_spec = len(P.param_spec(cfg))
+    assert sum(report.values()) == n_spec == len(sd), (report, n_spec, len(sd))
+    # ---- models/models.py:313-359 ('test' branch) with the reference's modules
+    with torch.no_grad():
+        bd = {"past_point_clouds": torch.from_numpy(window.copy())}
+        bd = motion(bd)
+        bd["current_motion_feature"] = bd["current_motion_feature"][:, :3]
+        current_point = bd["current_point"].clone()
+        bd = voxgen(bd)
+        bd = vfe(bd)
+        logits, pred_dicts, recall = unet(bd, "test")
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sd[k]).tobytes() for k in sorted(sd))).hexdigest()
+    pd = pred_dicts[0]
+    np.savez_compressed(os.path.join(HERE, "wiring.npz"), window=window, sd_digest=np.array(digest),
+                        current_point=current_point.numpy(), logits=logits.numpy(), pred_boxes=pd["pred_boxes"].numpy(),
+                        pred_scores=pd["pred_scores"].numpy(), pred_labels=pd["pred_labels"].numpy(),
+                        n_voxels=np.int64(bd["voxel_features"].shape[0]), n_params=np.int64(n_spec))
+    print("wiring golden: %d tensors loaded by name into the reference's modules (%s); %d points, %d voxels, %d boxes, "
+          "logit range [%.3f, %.3f]" % (n_spec, report, len(window), bd["voxel_features"].shape[0], len(pd["pred_boxes"]),
+                                        float(logits.min()), float(logits.max())))
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -561,6 +637,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 
 
 if __name__ == "__main__":
+    if "--wiring-only" in sys.argv:
+        wiring_golden()
+        sys.exit(0)
     if "--centerloss-only" in sys.argv:
         center_loss_golden()
         sys.exit(0)
@@ -583,3 +662,4 @@ if __name__ == "__main__":
         recall_golden()
         mos_loss_golden()
         center_loss_golden()
+        wiring_golden()

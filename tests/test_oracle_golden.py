@@ -111,3 +111,31 @@ def test_iou3d_and_recall_record(golden_dir):
     assert [rd2[k] for k in sorted(rd2)] == g["rd2_vals"].tolist()
     rd0 = R.generate_recall_record(np.zeros((0, 7), np.float32), {}, g["gt_pad"], thr)
     assert [rd0[k] for k in sorted(rd0)] == g["rd0_vals"].tolist()
+
+
+def test_restated_wiring_vs_reference_model_code(golden_dir):
+    """tests/golden/wiring.npz = the reference's OWN MotionNet / VoxelGenerate / MeanVFE / UNetV2 modules (imported from
+    the reference as written, checkpoint loaded by parameter name) run over the stand-ins of oracle/shims, i.e. the
+    reference's layer definitions and forward() code on the oracle's primitives.  The oracle's restated forward must
+    reproduce it: this pins the restatement's WIRING (and, at generation time, all 329 parameter names / shapes) to the
+    reference's code.  Primitive MinkowskiEngine / spconv semantics stay dep-knowledge (oracle/shims/README.md)."""
+    import hashlib
+    from insmos_amd import params as P
+    from model_util import detecting_state_dict
+    from oracle import ref_model as M
+    g = np.load(os.path.join(golden_dir, "wiring.npz"))
+    cfg = P.default_cfg()
+    window = g["window"]
+    sd = detecting_state_dict(cfg, window, seed=4, target=(60, 200))
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sd[k]).tobytes() for k in sorted(sd))).hexdigest()
+    assert digest == str(g["sd_digest"]), "the seeded checkpoint recipe changed: regenerate with make_golden.py --wiring-only"
+    assert int(g["n_params"]) == len(P.param_spec(cfg)) == len(sd)
+    logits, pred, dbg = M.forward_window(sd, cfg, window, want_debug=True)
+    np.testing.assert_allclose(dbg["current_point"], g["current_point"], atol=5e-6)     # MotionNet branch
+    assert len(dbg["unet"]["voxel_features"]) == int(g["n_voxels"])
+    assert len(g["pred_boxes"]) >= 5 and len(pred["pred_boxes"]) == len(g["pred_boxes"])  # the instance branch is live
+    np.testing.assert_allclose(pred["pred_boxes"], g["pred_boxes"], atol=1e-5)
+    np.testing.assert_array_equal(pred["pred_labels"], g["pred_labels"])
+    np.testing.assert_allclose(pred["pred_scores"], g["pred_scores"], atol=1e-6)
+    np.testing.assert_allclose(logits, g["logits"], atol=5e-5)                            # whole forward
+    assert float(np.abs(g["logits"]).max()) > 1.0
