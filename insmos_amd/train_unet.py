@@ -62,21 +62,25 @@ class UNetV2Trainer:
         self._deconv_tables = None
 
     # ---------------------------------------------------------------------------------------------
+    def to_reference_layout(self, stem, v):
+        """A tensor in this class's tap layout (a parameter, its gradient, a buffer) -> the reference checkpoint's layout."""
+        kind, shape = self._layout[stem]
+        v = _np(v)
+        if kind == "spconv":      # (K, ci, co) -> (co, kz, ky, kx, ci)
+            v = v.transpose(2, 0, 1)
+        elif kind in ("conv2d", "box_w"):  # (kh*kw, ci, co) -> (co, ci, kh, kw)
+            v = v.transpose(2, 1, 0)
+        elif kind == "convT2d":   # (kh*kw, ci, co) -> (ci, co, kh, kw)
+            v = v.transpose(1, 2, 0)
+        elif kind == "linear":    # (1, in, out) -> (out, in)
+            v = v[0].T
+        return np.ascontiguousarray(v).reshape(shape)
+
     def export_state_dict(self):
         """Parameters and running statistics back in the reference's checkpoint layout (numpy, UNET_PREFIX names)."""
-        out = {}
-        for stem, (kind, shape) in self._layout.items():
-            v = _np(self.buffers[stem] if stem in self.buffers else self.params[stem])
-            if kind == "spconv":      # (K, ci, co) -> (co, kz, ky, kx, ci)
-                v = v.transpose(2, 0, 1).reshape(shape)
-            elif kind in ("conv2d", "box_w"):  # (kh*kw, ci, co) -> (co, ci, kh, kw)
-                v = v.transpose(2, 1, 0).reshape(shape)
-            elif kind == "convT2d":   # (kh*kw, ci, co) -> (ci, co, kh, kw)
-                v = v.transpose(1, 2, 0).reshape(shape)
-            elif kind == "linear":    # (1, in, out) -> (out, in)
-                v = v[0].T
-            out[P.UNET_PREFIX + stem] = np.ascontiguousarray(v.reshape(shape), dtype=np.float32)
-        return out
+        return {P.UNET_PREFIX + stem: self.to_reference_layout(stem, self.buffers[stem] if stem in self.buffers
+                                                              else self.params[stem]).astype(np.float32)
+                for stem in self._layout}
 
     # ---------------------------------------------------------------------------------------------
     def _bn(self, x, stem, relu):

@@ -15,6 +15,18 @@ def _as_list(v, d):
     return [int(v)] * d if np.isscalar(v) else [int(x) for x in v]
 
 
+def conv_torch(x, nbr, taps):
+    """y[o] = sum_k x[nbr[k][o]] @ taps[k] with torch index ops (autograd-capable); nbr None = 1x1."""
+    if nbr is None:
+        return x @ taps[0]
+    y = torch.zeros((nbr.shape[1], taps.shape[2]), dtype=x.dtype)
+    for k in range(nbr.shape[0]):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        if len(o):
+            y = y.index_add(0, torch.from_numpy(o), x[torch.from_numpy(nbr[k][o].astype(np.int64))] @ taps[k])
+    return y
+
+
 class CoordinateManager:
     """Coordinate maps per tensor stride; coarser maps derive from the finest one (floor(c / s) * s, unique)."""
 
@@ -109,10 +121,16 @@ class _ConvBase(nn.Module):
             out_coords, _ = x.manager.get(ts_out)  # the cached finer map (needed for ME.cat, minkunet.py:164,171,178)
             offs = R.me_kernel_offsets(self.kernel_size, ts_out)
             nbr = R.me_nbr(out_coords, in_keys, offs, -1)
-        y = R.sparse_conv(x.F.detach().cpu().numpy().astype(np.float32), nbr, taps)
-        y = torch.from_numpy(np.asarray(y, np.float32))
-        if self.bias is not None:
-            y = y + self.bias.detach()
+        if torch.is_grad_enabled():  # training-wiring golden: the same contraction as differentiable torch index ops
+            kt = self.kernel[None] if self.kernel.dim() == 2 else self.kernel
+            y = conv_torch(x.F, nbr, kt)
+            if self.bias is not None:
+                y = y + self.bias
+        else:
+            y = R.sparse_conv(x.F.detach().cpu().numpy().astype(np.float32), nbr, taps)
+            y = torch.from_numpy(np.asarray(y, np.float32))
+            if self.bias is not None:
+                y = y + self.bias.detach()
         return x._like(y, ts_out)
 
 

@@ -96,9 +96,16 @@ class SparseConvolution(SparseModule):
             ks, perm = x.keys()
             nbr = R.spconv_nbr_inverse(fine, ks, perm, x.spatial_shape, c["ksize"], c["stride"], c["padding"])
             out = SparseConvTensor(None, c["in_indices"], c["in_shape"], x.batch_size, x.indice_dict, c["in_keys"])
-        y = torch.from_numpy(np.asarray(R.sparse_conv(feat, nbr, self._taps()), np.float32))
-        if self.bias is not None:
-            y = y + self.bias.detach()
+        if torch.is_grad_enabled():  # training-wiring golden: differentiable torch index ops, weight in its own layout
+            from MinkowskiEngine import conv_torch
+            co, kz, ky, kx, ci = self.weight.shape
+            y = conv_torch(x.features, nbr, self.weight.reshape(co, kz * ky * kx, ci).permute(1, 2, 0))
+            if self.bias is not None:
+                y = y + self.bias
+        else:
+            y = torch.from_numpy(np.asarray(R.sparse_conv(feat, nbr, self._taps()), np.float32))
+            if self.bias is not None:
+                y = y + self.bias.detach()
         out.features = y
         return out
 

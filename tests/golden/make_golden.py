@@ -501,6 +501,136 @@ def wiring_golden():
                                         float(logits.min()), float(logits.max())))
 
 
+def _grad_samples(name, numel, n=12):
+    """Fixed pseudo-random flat indices per tensor (seeded by the name) -- the fixture keeps a norm and a few entries of
+    every gradient instead of 6.5 M floats."""
+    import zlib
+    return np.random.default_rng(zlib.crc32(name.encode())).integers(0, numel, n)
+
+
+def train_wiring_golden():
+    """The reference's OWN training forward (models/models.py:313-345: MotionNet -> MOSLoss, VoxelGenerate, MeanVFE,
+    UNetV2(..., 'train') -> CenterHead.get_loss + MOSLoss) and torch autograd through it, run over the oracle-backed
+    stand-ins of oracle/shims in their differentiable form, modules in train() mode (batch-statistics BatchNorm).
+    Output: the four losses, the boxes the pass predicted, and for EVERY parameter the gradient's norm and 12 entries.
+    One deviation from the code as written: CenterHead.assign_targets (center_head.py:126-168) regroups the per-item
+    targets through np.array(list of lists of tensors).transpose(1, 0), which numpy 2.x rejects; the regrouping (and only
+    that) is replaced by an equivalent torch.stack -- get_targets_single and everything else run unmodified."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    sys.path.insert(0, ROOT)
+    from insmos_amd import params as P
+    from insmos_amd.synth import make_labels, make_window
+    import Array_Index
+    import models.utils as mutils
+    mutils.Array_Index = Array_Index
+    sys.modules["models.utils.Array_Index"] = Array_Index
+    ov = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_overlap.so"))
+    ov.ref_boxes_overlap_bev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    stub = types.ModuleType("models.bbox_post_process.iou3d_nms_cuda")
+
+    def nms_gpu(boxes, keep_t, thresh):
+        bnp = boxes.detach().cpu().numpy()
+        k = greedy_keep(ref_iou(bnp, bnp), thresh)
+        keep_t[:len(k)] = torch.from_numpy(k)
+        return len(k)
+
+    def overlap_stub(a, b, out):
+        a = np.ascontiguousarray(a.detach().numpy(), np.float32)
+        b = np.ascontiguousarray(b.detach().numpy(), np.float32)
+        o = np.zeros((len(a), len(b)), np.float32)
+        ov.ref_boxes_overlap_bev(a.ctypes.data, len(a), b.ctypes.data, len(b), o.ctypes.data)
+        out.copy_(torch.from_numpy(o))
+        return 1
+
+    stub.nms_gpu, stub.boxes_overlap_bev_gpu = nms_gpu, overlap_stub
+    sys.modules["models.bbox_post_process.iou3d_nms_cuda"] = stub
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    saved_ft = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    from models.backbones_3d.motionnet import MotionNet
+    from models.backbones_3d.voxel_generate import VoxelGenerate
+    from models.backbones_3d.spconv_unet import UNetV2
+    from models.backbones_2d.mean_vfe import MeanVFE
+    from models.backbones_2d.center_head import CenterHead
+    from models.loss import MOSLoss
+
+    def assign_targets_regrouped(self, gt_boxes):
+        per_item = [self.get_targets_single(b[:, :-1], b[:, -1]) for b in gt_boxes]
+        return {name: [torch.stack([it[i][0] for it in per_item])]
+                for i, name in enumerate(("heatmaps", "anno_boxes", "inds", "masks"))}
+
+    CenterHead.assign_targets = assign_targets_regrouped
+    try:
+        cfg = P.default_cfg()
+        window = make_window(seed=21, n_scans=3, n_az=96)
+        gt_labels = make_labels(window[window[:, 4] == 0], seed=21)
+        rng = np.random.default_rng(5)
+        cur_xyz = window[window[:, 4] == 0][:, :3]
+        M = 7
+        gt_boxes = np.zeros((1, M + 2, 8), np.float32)          # two all-zero padding rows, as the collate function leaves
+        pick = cur_xyz[rng.integers(0, len(cur_xyz), M)]
+        gt_boxes[0, :M, 0:2] = pick[:, :2] + rng.normal(0, 0.3, (M, 2))
+        gt_boxes[0, :M, 2] = rng.uniform(-1.5, -0.5, M)
+        gt_boxes[0, :M, 3:6] = rng.uniform([1.5, 0.6, 1.2], [4.5, 2.0, 1.8], (M, 3))
+        gt_boxes[0, :M, 6] = rng.uniform(-3.1, 3.1, M)
+        gt_boxes[0, :M, 7] = rng.integers(1, 4, M)
+        sd = P.random_state_dict(cfg, 9, cls_bias=-1.0, box_w_std=0.05)
+        pcr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
+        vs = cfg["DATA"]["VOXEL_SIZE"]
+        grid = np.round((pcr[3:6] - pcr[0:3]) / np.array(vs)).astype(np.int64)
+        in_ch = len(cfg["MODEL"]["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
+        motion = MotionNet(cfg["MODEL"]["DELTA_T_PREDICTION"], vs, 3)
+        voxgen = VoxelGenerate(vs, pcr, 100000, 5, in_ch)
+        vfe = MeanVFE(cfg["MODEL"]["VFE"], in_ch)
+        unet = UNetV2(cfg, in_ch, grid, vs, pcr, 3)
+        crit = MOSLoss(3, [0])
+        prefixes = ((motion, P.ME_PREFIX.rsplit("MinkUNet.", 1)[0]), (unet, P.UNET_PREFIX))
+        for mod, prefix in prefixes:
+            sub = {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in sd.items() if k.startswith(prefix)}
+            res = mod.load_state_dict(sub, strict=False)
+            assert not [k for k in res.missing_keys if not k.endswith("num_batches_tracked")] and not res.unexpected_keys
+            mod.train()
+        gt_t = torch.from_numpy(gt_labels)
+        bd = {"past_point_clouds": torch.from_numpy(window.copy()), "gt_boxes": torch.from_numpy(gt_boxes)}
+        bd = motion(bd)                                                             # models.py:316
+        bd["current_motion_feature"] = bd["current_motion_feature"][:, :3]          # :318-319 (a no-op for 3 classes)
+        current_point = bd["current_point"].detach().clone()
+        loss_motion = crit.compute_loss(bd["current_motion_feature"], gt_t)         # :321-323
+        bd = voxgen(bd)                                                             # :326
+        bd = vfe(bd)                                                                # :327
+        (loss_rpn, tb), point_seg = unet(bd, "train")                               # :331
+        loss_mos = crit.compute_loss(point_seg, gt_t)                               # :332
+        loss = loss_rpn + loss_mos + loss_motion                                    # :335 (USE_MOTION_LOSS)
+        loss.backward()
+        names, norms, samples = [], [], []
+        for mod, prefix in prefixes:
+            for n, prm in mod.named_parameters():
+                assert prm.grad is not None, prefix + n
+                g = prm.grad.detach().numpy().astype(np.float64).reshape(-1)
+                names.append(prefix + n)
+                norms.append(float(np.sqrt((g * g).sum())))
+                samples.append(g[_grad_samples(prefix + n, g.size)])
+        assert sorted(names) == sorted(k for k, (shape, kind) in P.param_spec(cfg).items() if kind not in ("bn_m", "bn_v"))
+        # the boxes this pass predicted (post_processing of the train-mode head, spconv_unet.py:316-318): recomputed from
+        # the stored head maps exactly as UNetV2.forward does
+        from models.post_process import post_processing
+        with torch.no_grad():
+            pdicts, _ = post_processing({"batch_cls_preds": bd["batch_cls_preds"], "batch_box_preds": bd["batch_box_preds"],
+                                         "cls_preds_normalized": False}, cfg["MODEL"]["POST_PROCESSING"], 3)
+        np.savez_compressed(os.path.join(HERE, "train_wiring.npz"), gt_labels=gt_labels, gt_boxes=gt_boxes,
+                            current_point=current_point.numpy(), pred_boxes=pdicts[0]["pred_boxes"].numpy(),
+                            pred_labels=pdicts[0]["pred_labels"].numpy(),
+                            losses=np.array([tb["rpn_loss_cls"], tb["rpn_loss_loc"], float(loss_mos), float(loss_motion),
+                                             float(loss)], np.float64),
+                            grad_names=np.array(names), grad_norms=np.array(norms), grad_samples=np.array(samples),
+                            n_voxels=np.int64(bd["voxel_features"].shape[0]))
+        print("train wiring golden: losses cls %.5f loc %.5f mos %.5f motion %.5f; %d parameters with gradients; %d boxes "
+              "predicted by the pass; %d voxels" % (tb["rpn_loss_cls"], tb["rpn_loss_loc"], float(loss_mos), float(loss_motion),
+                                                    len(names), len(pdicts[0]["pred_boxes"]), bd["voxel_features"].shape[0]))
+    finally:
+        torch.cuda.FloatTensor = saved_ft
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -639,6 +769,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 if __name__ == "__main__":
     if "--wiring-only" in sys.argv:
         wiring_golden()
+        sys.exit(0)
+    if "--train-wiring-only" in sys.argv:
+        train_wiring_golden()
         sys.exit(0)
     if "--centerloss-only" in sys.argv:
         center_loss_golden()
