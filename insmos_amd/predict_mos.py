@@ -102,17 +102,38 @@ def write_outputs(out_root, exp_id, seq, stem, labels, conf, pred):
     np.save(os.path.join(d_box, stem + ".npy"), {k: v.cpu().numpy() for k, v in pred.items()})
 
 
+def enumerate_jobs(n_full, dt_pred, dt_data, n_files):
+    """The (n_past, window index, scan index) list of scripts/predict_mos.py:304-383 for one sequence.
+
+    Warm-up (:306-309): `for i in range(int(N_PAST_STEPS * DELTA_T_PREDICTION * 10))` with N_PAST_STEPS = i + 1 and
+    DELTA_T_PREDICTION forced to 0.1, and only the FIRST sample of each such dataset is predicted (:373 `break`): scan i from
+    scans 0..i.  Then every window of the full configuration.  A warm-up scan that a full window also produces is written
+    twice by the reference, the full window last; such warm-up jobs are dropped here (same final files, no double work) --
+    with the shipped configuration (0.1 s, N = 10) that is exactly the reference's tenth warm-up iteration."""
+    skip = int(round(dt_pred / dt_data))
+    n_windows = max(0, n_files - skip * (n_full - 1))
+    first_full = skip * (n_full - 1)
+    jobs = []
+    for i in range(int(n_full * dt_pred * 10)):
+        n_past = i + 1
+        if i >= first_full and n_windows > 0:
+            continue                      # overwritten by a full window
+        if n_files - (n_past - 1) <= 0:
+            continue                      # DemoDataset of that length is empty (:99-101)
+        jobs.append((n_past, 0, i))
+    for j in range(n_windows):
+        jobs.append((n_full, j, first_full + j))
+    return jobs
+
+
 def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device="cuda:0", limit=None):
     sem = model.semantic_config
     ignore_index = model.ignore_index
     exp_id = cfg["EXPERIMENT"]["ID"]
     n_full = int(cfg["MODEL"]["N_PAST_STEPS"])
-    jobs = []  # (n_past, window index)
-    for i in range(n_full - 1):  # warm-up: scan i predicted from scans 0..i
-        jobs.append((i + 1, 0))
     full = SequenceWindows(cfg, seq_dir, n_full, device)
-    for j in range(len(full)):
-        jobs.append((n_full, j))
+    jobs = [(n_past, j) for n_past, j, _ in enumerate_jobs(n_full, float(cfg["MODEL"]["DELTA_T_PREDICTION"]), full.dt_data,
+                                                           len(full.files))]
     if limit is not None:
         jobs = jobs[:limit]
     readers = {n_full: full}

@@ -75,6 +75,60 @@ def mini_dataset(tmp_path_factory, golden_dir):
     return root, d, scans
 
 
+def test_restated_driver_vs_reference_main(golden_dir, mini_dataset):
+    """tests/golden/driver.npz = every file the reference's scripts/predict_mos.py main() wrote for this six-scan sequence,
+    run as written (make_golden.py:driver_golden: DemoDataset, the warm-up loop, load_from_checkpoint, forward(list, 'test'),
+    output stage; over the oracle-backed stand-ins of oracle/shims).  The restated pieces the GPU tests lean on -- the job
+    list of insmos_amd.predict_mos.enumerate_jobs, the window builder `_ref_window`, the oracle forward and output stage --
+    must reproduce those files: labels exactly, confidences to 1e-6, the same set of boxes (their order among tied scores
+    is unspecified in torch.topk / sort)."""
+    from insmos_amd import data as D, params as P
+    from insmos_amd.predict_mos import enumerate_jobs
+    from oracle import ref_model as M
+    g = np.load(os.path.join(golden_dir, "driver.npz"))
+    root, d, scans = mini_dataset
+    assert [len(s) for s in scans] == list(g["scan_sizes"])
+    poses = D.read_lidar_poses(d)
+    cfg = P.default_cfg()
+    cfg["MODEL"]["N_PAST_STEPS"] = 3
+    sd = P.random_state_dict(cfg, 2, cls_bias=-1.5, box_w_std=0.05)
+    jobs = enumerate_jobs(3, 0.1, 0.1, len(scans))
+    assert ["%06d" % sc for _, _, sc in jobs] == list(g["stems"])        # one prediction per scan, the reference's stems
+    assert [n for n, _, _ in jobs] == [1, 2, 3, 3, 3, 3]                 # shortened histories for the first N - 1 scans
+    for n_past, j, scan_idx in jobs:
+        idx = list(range(scan_idx - (n_past - 1), scan_idx + 1))
+        win = _ref_window(scans, poses, idx, n_past, 0.1)
+        logits, pred = M.forward_window(sd, cfg, win)
+        lab, conf = R.output_stage(logits)
+        st = "%06d" % scan_idx
+        np.testing.assert_array_equal(lab, g["label_" + st])
+        assert lab.dtype == np.int32 and set(np.unique(lab)) <= {9, 251}
+        np.testing.assert_allclose(conf, g["conf_" + st], atol=1e-6)
+        a, b = pred["pred_boxes"], g["pred_boxes_" + st]
+        assert len(a) == len(b) == 500
+        dist = np.abs(a[:, None, :] - b[None, :, :]).max(2)
+        match = dist.argmin(1)
+        assert (dist.min(1) < 1e-4).all() and len(set(match.tolist())) == len(a)      # a permutation of the same boxes
+        np.testing.assert_array_equal(pred["pred_labels"], g["pred_labels_" + st][match])
+        np.testing.assert_allclose(pred["pred_scores"], g["pred_scores_" + st][match], atol=1e-6)
+        assert (match == np.arange(len(a))).mean() > 0.98                              # and almost always the same order
+
+
+def test_enumerate_jobs_follows_the_reference_loop():
+    """scripts/predict_mos.py:306-309: range(int(N * dt * 10)) warm-up datasets with N' = i + 1 at 0.1 s, first sample only."""
+    from insmos_amd.predict_mos import enumerate_jobs
+    j = enumerate_jobs(10, 0.1, 0.1, 100)
+    assert j[:9] == [(i + 1, 0, i) for i in range(9)] and j[9] == (10, 0, 9) and len(j) == 100
+    assert sorted(s for _, _, s in j) == list(range(100))
+    # DELTA_T_PREDICTION 0.2 on 0.1 s data: 20 warm-up datasets, the full windows start at scan 18 and overwrite 18, 19
+    j = enumerate_jobs(10, 0.2, 0.1, 25)
+    assert [x for x in j if x[0] != 10 or x[2] < 18] == [(i + 1, 0, i) for i in range(18)]
+    assert [x for x in j if x[2] >= 18] == [(10, k, 18 + k) for k in range(7)]
+    # fewer scans than the history: only the warm-up datasets that are not empty
+    assert enumerate_jobs(10, 0.1, 0.1, 4) == [(1, 0, 0), (2, 0, 1), (3, 0, 2), (4, 0, 3)]
+    assert enumerate_jobs(10, 0.1, 0.1, 0) == []
+
+
 @pytest.mark.gpu
 def test_stack_scans_matches_reference_restated(mini_dataset):
     import torch
