@@ -735,6 +735,19 @@ def driver_golden():
         sys.argv = argv
     base = os.path.join(tmp, "preb_out", cfg["EXPERIMENT"]["ID"])
     out = {"n_scans": np.int64(len(scans)), "scan_sizes": np.array([len(sc) for sc in scans])}
+    # ---- the validation forward, InsMOS_Model.forward(list, 'eval') (models/models.py:347-353, 369-373), as written:
+    # the window of scan 5 exactly as DemoDataset builds it, seeded labels for its current scan
+    ds = mod.DemoDataset(cfg, os.path.join(tmp, "data"), split="test")
+    item = ds[len(ds) - 1]
+    ev_labels = np.random.default_rng(8).integers(0, 3, len(scans[5]))
+    model = mod.models.InsMOSNet.load_from_checkpoint(ckpt, hparams=cfg).eval()
+    with torch.no_grad():
+        ev = model.forward([{"past_point_clouds": item["past_point_clouds"], "meta": item["meta"],
+                             "past_labels": [torch.from_numpy(ev_labels)], "batch_size_npast": 3}], "eval")
+    assert len(ev) == 6 and isinstance(ev[4], float) and tuple(ev[5].shape) == (1,)
+    out.update(eval_window=item["past_point_clouds"].numpy(), eval_labels=ev_labels, eval_val_loss=np.float64(ev[4]),
+               eval_val_motion_loss=np.float64(ev[5][0]), eval_logits=ev[3][0].numpy())
+    print("eval golden: val_loss %.6f val_motion_loss %.6f" % (ev[4], float(ev[5][0])))
     stems = sorted(f[:-6] for f in os.listdir(os.path.join(base, "mos_preb", "sequences", "08", "predictions")))
     out["stems"] = np.array(stems)
     nbox = []

@@ -114,6 +114,28 @@ def test_restated_driver_vs_reference_main(golden_dir, mini_dataset):
         assert (match == np.arange(len(a))).mean() > 0.98                              # and almost always the same order
 
 
+def test_restated_eval_mode_vs_reference_forward(golden_dir, mini_dataset):
+    """The reference's InsMOS_Model.forward(list, 'eval') run as written (driver.npz: eval_*): six return values, val_loss as
+    a float, val_motion_loss as a (1,) tensor, and the returned logits carry -inf in the ignored column because MOSLoss
+    overwrites its input.  The restated pieces the GPU 'eval' test leans on (oracle forward + ref_ops.mos_loss on the point
+    logits and on the motion features, window builder) must reproduce its numbers."""
+    from insmos_amd import data as D, params as P
+    from oracle import ref_model as M
+    g = np.load(os.path.join(golden_dir, "driver.npz"))
+    root, d, scans = mini_dataset
+    poses = D.read_lidar_poses(d)
+    win = _ref_window(scans, poses, [3, 4, 5], 3, 0.1)
+    np.testing.assert_array_equal(win, g["eval_window"])                 # DemoDataset.__getitem__ itself, bit for bit
+    cfg = P.default_cfg()
+    sd = P.random_state_dict(cfg, 2, cls_bias=-1.5, box_w_std=0.05)
+    logits, pred, dbg = M.forward_window(sd, cfg, win, want_debug=True)
+    gt = g["eval_labels"]
+    assert abs(R.mos_loss(logits, gt)[0] - float(g["eval_val_loss"])) < 2e-6
+    assert abs(R.mos_loss(dbg["current_point"][:, 4:7], gt)[0] - float(g["eval_val_motion_loss"])) < 2e-6
+    assert np.isneginf(g["eval_logits"][:, 0]).all()
+    np.testing.assert_allclose(logits[:, 1:], g["eval_logits"][:, 1:], atol=2e-5)
+
+
 def test_enumerate_jobs_follows_the_reference_loop():
     """scripts/predict_mos.py:306-309: range(int(N * dt * 10)) warm-up datasets with N' = i + 1 at 0.1 s, first sample only."""
     from insmos_amd.predict_mos import enumerate_jobs
