@@ -459,46 +459,61 @@ def wiring_golden():
     from models.backbones_3d.spconv_unet import UNetV2
     from models.backbones_2d.mean_vfe import MeanVFE
 
+    import copy
+
+    def run_case(cfg, window, sd):
+        # ---- the reference's constructors, as models/models.py:273-294 calls them
+        pcr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
+        vs = cfg["DATA"]["VOXEL_SIZE"]
+        grid = np.round((pcr[3:6] - pcr[0:3]) / np.array(vs)).astype(np.int64)
+        in_ch = len(cfg["MODEL"]["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
+        motion = MotionNet(cfg["MODEL"]["DELTA_T_PREDICTION"], vs, 3)
+        voxgen = VoxelGenerate(vs, pcr, 100000, 5, in_ch)
+        vfe = MeanVFE(cfg["MODEL"]["VFE"], in_ch)
+        unet = UNetV2(cfg, in_ch, grid, vs, pcr, 3)
+        report = {}
+        for mod, prefix in ((motion, P.ME_PREFIX.rsplit("MinkUNet.", 1)[0]), (unet, P.UNET_PREFIX)):
+            sub = {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in sd.items() if k.startswith(prefix)}
+            res = mod.load_state_dict(sub, strict=False)
+            missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+            assert not missing and not res.unexpected_keys, (prefix, missing[:5], res.unexpected_keys[:5])
+            report[prefix] = len(sub)
+            mod.eval()
+        n_spec = len(P.param_spec(cfg))
+        assert sum(report.values()) == n_spec == len(sd), (report, n_spec, len(sd))
+        # ---- models/models.py:313-359 ('test' branch) with the reference's modules
+        with torch.no_grad():
+            bd = {"past_point_clouds": torch.from_numpy(window.copy())}
+            bd = motion(bd)
+            bd["current_motion_feature"] = bd["current_motion_feature"][:, :3]
+            current_point = bd["current_point"].clone()
+            bd = voxgen(bd)
+            bd = vfe(bd)
+            logits, pred_dicts, recall = unet(bd, "test")
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(sd[k]).tobytes() for k in sorted(sd))).hexdigest()
+        pd = pred_dicts[0]
+        print("wiring golden: %d tensors loaded by name into the reference's modules (%s); %d points, %d voxels, %d boxes, "
+              "logit range [%.3f, %.3f]" % (n_spec, report, len(window), bd["voxel_features"].shape[0], len(pd["pred_boxes"]),
+                                            float(logits.min()), float(logits.max())))
+        return dict(window_digest=np.array(hashlib.sha256(np.ascontiguousarray(window).tobytes()).hexdigest()),
+                    sd_digest=np.array(digest), current_point=current_point.numpy(), logits=logits.numpy(),
+                    pred_boxes=pd["pred_boxes"].numpy(), pred_scores=pd["pred_scores"].numpy(),
+                    pred_labels=pd["pred_labels"].numpy(), n_voxels=np.int64(bd["voxel_features"].shape[0]),
+                    n_params=np.int64(n_spec), bev_shape=np.array(bd["spatial_features"].shape))
+
     cfg = P.default_cfg()
     window = make_window(seed=21, n_scans=3, n_az=160)
-    sd = detecting_state_dict(cfg, window, seed=4, target=(60, 200))
-    # ---- the reference's constructors, as models/models.py:273-294 calls them
-    pcr = np.array(cfg["DATA"]["POINT_CLOUD_RANGE"])
-    vs = cfg["DATA"]["VOXEL_SIZE"]
-    grid = np.round((pcr[3:6] - pcr[0:3]) / np.array(vs)).astype(np.int64)
-    in_ch = len(cfg["MODEL"]["POINT_FEATURE_ENCODING"]["src_feature_list"]) + 3
-    motion = MotionNet(cfg["MODEL"]["DELTA_T_PREDICTION"], vs, 3)
-    voxgen = VoxelGenerate(vs, pcr, 100000, 5, in_ch)
-    vfe = MeanVFE(cfg["MODEL"]["VFE"], in_ch)
-    unet = UNetV2(cfg, in_ch, grid, vs, pcr, 3)
-    report = {}
-    for mod, prefix in ((motion, P.ME_PREFIX.rsplit("MinkUNet.", 1)[0]), (unet, P.UNET_PREFIX)):
-        sub = {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in sd.items() if k.startswith(prefix)}
-        res = mod.load_state_dict(sub, strict=False)
-        missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
-        assert not missing and not res.unexpected_keys, (prefix, missing[:5], res.unexpected_keys[:5])
-        report[prefix] = len(sub)
-        mod.eval()
-    n_spec = len(P.param_spec(cfg))
-    assert sum(report.values()) == n_spec == len(sd), (report, n_spec, len(sd))
-    # ---- models/models.py:313-359 ('test' branch) with the reference's modules
-    with torch.no_grad():
-        bd = {"past_point_clouds": torch.from_numpy(window.copy())}
-        bd = motion(bd)
-        bd["current_motion_feature"] = bd["current_motion_feature"][:, :3]
-        current_point = bd["current_point"].clone()
-        bd = voxgen(bd)
-        bd = vfe(bd)
-        logits, pred_dicts, recall = unet(bd, "test")
-    digest = hashlib.sha256(b"".join(np.ascontiguousarray(sd[k]).tobytes() for k in sorted(sd))).hexdigest()
-    pd = pred_dicts[0]
-    np.savez_compressed(os.path.join(HERE, "wiring.npz"), window=window, sd_digest=np.array(digest),
-                        current_point=current_point.numpy(), logits=logits.numpy(), pred_boxes=pd["pred_boxes"].numpy(),
-                        pred_scores=pd["pred_scores"].numpy(), pred_labels=pd["pred_labels"].numpy(),
-                        n_voxels=np.int64(bd["voxel_features"].shape[0]), n_params=np.int64(n_spec))
-    print("wiring golden: %d tensors loaded by name into the reference's modules (%s); %d points, %d voxels, %d boxes, "
-          "logit range [%.3f, %.3f]" % (n_spec, report, len(window), bd["voxel_features"].shape[0], len(pd["pred_boxes"]),
-                                        float(logits.min()), float(logits.max())))
+    out = run_case(cfg, window, detecting_state_dict(cfg, window, seed=4, target=(60, 200)))
+    # cfg-4 shape (BASELINE.json configs[3]): voxel 0.05 m -> sparse_shape [81, 2000, 2400], BEV depth 5 -> 640 features
+    c5 = copy.deepcopy(P.default_cfg())
+    c5["DATA"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    c5["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"] = 640
+    c5["MODEL"]["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    w5 = make_window(seed=9, n_scans=3, n_az=120)
+    o5 = run_case(c5, w5, detecting_state_dict(c5, w5, seed=6, target=(60, 200)))
+    assert list(o5["bev_shape"]) == [1, 640, 250, 300]
+    out.update({"v005_" + k: v for k, v in o5.items()})
+    np.savez_compressed(os.path.join(HERE, "wiring.npz"), **out)
 
 
 def _grad_samples(name, numel, n=12):
