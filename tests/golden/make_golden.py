@@ -21,6 +21,15 @@ Sources exercised (all importable / compilable here):
   refine.npz        scripts/refine.py:133-302 main() run as-is on a synthetic 12-frame sequence -> refined labels
   instance_index.npz  models/utils/src/Array_Index.cpp:85-154 find_point_in_instance_bbox_with_yaw (compiled), the
                     point -> instance-id map of scripts/refine.py:196 (yawed boxes, ground offset, label 0, orders)
+  center_loss.npz   models/backbones_2d/center_head.py:170-331 get_targets_single / get_loss + autograd (pure torch, CPU)
+The next three execute the reference's model / driver code AS WRITTEN over the oracle-backed stand-ins of oracle/shims for the
+two libraries the image lacks (they pin wiring and parameter names, not the libraries' primitives -- oracle/shims/README.md):
+  wiring.npz        models/backbones_3d/{motionnet,voxel_generate,spconv_unet}.py + models/MinkowskiEngine/*.py forward,
+                    checkpoint loaded by name (all 329 tensors), default and voxel-0.05 configurations
+  train_wiring.npz  the training forward of models/models.py:313-345 + torch autograd: losses, every parameter gradient
+  driver.npz        scripts/predict_mos.py main() on a six-scan sequence (every file it wrote) + forward(list, 'eval')
+Flags: --poses-only --instance-only --refine-only --recall-only --mosloss-only --centerloss-only --wiring-only
+       --train-wiring-only --driver-only
 """
 import ctypes
 import os
