@@ -134,6 +134,13 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
     full = SequenceWindows(cfg, seq_dir, n_full, device)
     jobs = [(n_past, j) for n_past, j, _ in enumerate_jobs(n_full, float(cfg["MODEL"]["DELTA_T_PREDICTION"]), full.dt_data,
                                                            len(full.files))]
+    if abs(float(cfg["MODEL"]["DELTA_T_PREDICTION"]) - 0.1) > 1e-9:
+        # the reference rebuilds the network with DELTA_T_PREDICTION = 0.1 for the warm-up windows (predict_mos.py:310-326);
+        # this driver holds ONE network (the configured time quantisation), so those windows are left out rather than
+        # predicted with the wrong quantisation
+        import warnings
+        warnings.warn("DELTA_T_PREDICTION != 0.1 s: the shortened-history warm-up scans are not predicted")
+        jobs = [jb for jb in jobs if jb[0] == n_full]
     if limit is not None:
         jobs = jobs[:limit]
     readers = {n_full: full}
