@@ -227,6 +227,14 @@ def main():
                 if conv_ms_per_window else 0,
             },
         }
+        # the north star's framing ("scans/sec ... as fraction of HBM roofline"): compulsory bytes of one cfg-2 window
+        # (every layer reads its input, its table and writes its output once = 1.33 GB) x windows/s over the
+        # HBM peak.  It comes out at a few per cent -- the path is not HBM-bound, which is why `bound` above is "mfma".
+        if args.n_az == 1886:
+            out["roofline"]["hbm_view"] = {"compulsory_gb_per_window": 1.33,
+                                           "achieved_gbs": round(1.33 * value / max(world, 1), 1),
+                                           "frac_of_hbm_peak": round(1.33 * value / max(world, 1) / PEAK_HBM_GBS, 4),
+                                           "note": "per GPU; compulsory bytes from SURVEY.md 8d, HBM peak 8 TB/s"}
         out["kernel_ms_per_window"] = {k: round(v[0] / nprof, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         out["device_ms_per_window_sum"] = round(total_ms, 3)
         # latency of ONE window, nothing else in flight
