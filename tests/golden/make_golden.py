@@ -50,6 +50,19 @@ _iou = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_iou3d.so"))
 _iou.ref_boxes_iou_bev.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 
 
+REAL_DEPS = "--real-deps" in sys.argv
+
+
+def _use_stand_ins():
+    """Put oracle/shims (MinkowskiEngine / spconv stand-ins over the oracle's primitives) on the path -- unless
+    --real-deps is given: on a machine where the reference's real dependencies are installed (MinkowskiEngine, spconv 2.3.6,
+    a CUDA GPU for their kernels) the same generators then record what the REAL libraries compute, and
+    tests/test_oracle_golden.py / test_train_wiring.py / test_data_stage.py check the oracle against THAT -- which pins the
+    primitive semantics this image cannot pin.  Not possible in this container."""
+    if not REAL_DEPS:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+
+
 def ref_iou(a, b):
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
@@ -442,7 +455,7 @@ def wiring_golden():
     definitions, (2) the restated WIRING of oracle/ref_model.py.  It does NOT pin MinkowskiEngine / spconv primitive
     semantics (oracle/shims/README.md)."""
     import hashlib
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    _use_stand_ins()
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from insmos_amd import params as P
@@ -462,7 +475,8 @@ def wiring_golden():
 
     stub.nms_gpu = nms_gpu
     sys.modules["models.bbox_post_process.iou3d_nms_cuda"] = stub
-    torch.Tensor.cuda = lambda self, *a, **k: self  # container-only: the reference calls .cuda() on the keep buffer
+    if not REAL_DEPS:
+        torch.Tensor.cuda = lambda self, *a, **k: self  # container-only: the reference calls .cuda() on the keep buffer
     from models.backbones_3d.motionnet import MotionNet
     from models.backbones_3d.voxel_generate import VoxelGenerate
     from models.backbones_3d.spconv_unet import UNetV2
@@ -540,7 +554,7 @@ def train_wiring_golden():
     One deviation from the code as written: CenterHead.assign_targets (center_head.py:126-168) regroups the per-item
     targets through np.array(list of lists of tensors).transpose(1, 0), which numpy 2.x rejects; the regrouping (and only
     that) is replaced by an equivalent torch.stack -- get_targets_single and everything else run unmodified."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    _use_stand_ins()
     sys.path.insert(0, ROOT)
     from insmos_amd import params as P
     from insmos_amd.synth import make_labels, make_window
@@ -663,7 +677,7 @@ def driver_golden():
     load_from_checkpoint(path, hparams=...) = construct + load_state_dict) and easydict.  .cuda() is a no-op here.
     Output: every file main() wrote (labels, confidences, box dicts) -> tests/golden/driver.npz."""
     import tempfile
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    _use_stand_ins()
     sys.path.insert(0, ROOT)
     from insmos_amd import params as P
     from insmos_amd.models import save_checkpoint
