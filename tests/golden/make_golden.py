@@ -783,7 +783,10 @@ def driver_golden():
         ev = model.forward([{"past_point_clouds": item["past_point_clouds"], "meta": item["meta"],
                              "past_labels": [torch.from_numpy(ev_labels)], "batch_size_npast": 3}], "eval")
     assert len(ev) == 6 and isinstance(ev[4], float) and tuple(ev[5].shape) == (1,)
-    out.update(eval_window=item["past_point_clouds"].numpy(), eval_labels=ev_labels, eval_val_loss=np.float64(ev[4]),
+    import hashlib
+    out.update(eval_window_digest=np.array(hashlib.sha256(np.ascontiguousarray(item["past_point_clouds"].numpy()).tobytes())
+                                           .hexdigest()), eval_window_shape=np.array(item["past_point_clouds"].shape),
+               eval_labels=ev_labels, eval_val_loss=np.float64(ev[4]),
                eval_val_motion_loss=np.float64(ev[5][0]), eval_logits=ev[3][0].numpy())
     print("eval golden: val_loss %.6f val_motion_loss %.6f" % (ev[4], float(ev[5][0])))
     stems = sorted(f[:-6] for f in os.listdir(os.path.join(base, "mos_preb", "sequences", "08", "predictions")))
