@@ -29,7 +29,7 @@ import torch
 from . import _lib, params as P
 from .data import SequenceWindows
 from .metrics import shard_indices
-from .models import InsMOSNet, load_semantic_config
+from .models import InsMOSNet
 
 
 _LUT_CACHE = {}
