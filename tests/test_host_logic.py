@@ -231,3 +231,68 @@ def test_unet_trainer_layouts_round_trip_and_deconv_table():
         y[o] += x[nbr[k][o].long()] @ taps[k]
     ref = F.conv_transpose2d(x.T.reshape(1, ci, H, W), wt, stride=2)[0].permute(1, 2, 0).reshape(4 * H * W, co)
     np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors in insmos_amd/_lib.py against include/insmos_hip.h as a C compiler lays it out: size of every
+    struct and offset of every field (a silent mismatch would corrupt the native runner's configuration / results)."""
+    import ctypes
+    import subprocess
+    from insmos_amd import _lib
+    pairs = {"InsmosConvW": _lib.ConvW, "InsmosNetCfg": _lib.NetCfg, "InsmosForwardOut": _lib.ForwardOut}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "insmos_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        s, f, v = ln.split()
+        got[(s, f)] = int(v)
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+        assert len([k for k in got if k[0] == cname]) == len(cls._fields_) + 1
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/insmos_hip.h against insmos_amd._lib.SIGNATURES: return type, argument count and the ctypes
+    class of every argument (a pointer passed as int, or an int64 as int, fails silently at run time)."""
+    import ctypes
+    import re
+    from insmos_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "insmos_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"typedef struct.*?\}\s*\w+;", "", hdr, flags=re.S)
+
+    def ctype(decl):
+        d = decl.strip()
+        if "*" in d:
+            return ctypes.c_void_p
+        base = " ".join(t for t in d.split()[:-1] if t != "const") if len(d.split()) > 1 else d
+        return {"int": ctypes.c_int, "int32_t": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+                "double": ctypes.c_double, "size_t": ctypes.c_size_t, "unsigned": ctypes.c_uint, "uint32_t": ctypes.c_uint,
+                "unsigned int": ctypes.c_uint}[base]
+
+    protos = re.findall(r"\b(int|size_t|const char\*|void)\s+(insmos_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 60
+    seen = set()
+    for ret, name, args in protos:
+        seen.add(name)
+        if name not in _lib.SIGNATURES:
+            continue   # (name coverage is test_header_symbols_all_exported's job)
+        restype, argtypes = _lib.SIGNATURES[name]
+        want_ret = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p, "void": None}[ret]
+        assert restype == want_ret, (name, restype, ret)
+        decls = [a for a in (x.strip() for x in args.replace("\n", " ").split(",")) if a and a != "void"]
+        assert len(decls) == len(argtypes), (name, len(decls), len(argtypes))
+        for i, (dcl, at) in enumerate(zip(decls, argtypes)):
+            assert ctype(dcl) == at, (name, i, dcl, at)
+    assert seen >= set(_lib.SIGNATURES), set(_lib.SIGNATURES) - seen
