@@ -204,6 +204,15 @@ int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, c
                             int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
                             void* stream);
 int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream);
+/* Several windows in ONE 4D coordinate set (EXPERIMENTAL, docs/round2_batching_plan.md; used by Engine.motionnet_windows only):
+ * bid[i] = window of point i (0 .. B-1); the window index is folded into the time coordinate, t' = floor(t / dt) * B + b
+ * (the t column of coords and the time field of keys), so every table / convolution entry point works unchanged when the
+ * SEARCHED table is built on time offsets scaled by B.  insmos_tslice_starts_batched: starts[d] = first row with
+ * floor(t' / B) >= tq_last - d. */
+int insmos_quantize4d_batched(const float* points, int64_t n, int ld_pts, const float* quant_host, const int32_t* bid, int B,
+                              uint64_t* keys, int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
+                              size_t ws_bytes, int compact_keys, void* stream);
+int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int B, int32_t* starts, void* stream);
 /* Fused BEV deblock + heads (base_bev_backbone.py:104-115, center_head.py:65-72): x (n_site, cin) NHWC BEV features;
  * wd_packed / bd = the ConvTranspose2d(k=2,s=2)+BN as a 1x1 layer with 4*cup outputs laid out [ky][kx][co] (cup = 256);
  * wh_packed / bh = the merged 1x1 heads (cup -> head_cout <= 16).  head ((4*n_site), ld_head): row site*4 + ky*2 + kx.

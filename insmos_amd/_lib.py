@@ -44,6 +44,9 @@ SIGNATURES = {
     "insmos_sparse_conv_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int,
                                         c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "insmos_quantize4d_batched": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int,
+                                          c_vp]),
+    "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),

@@ -102,6 +102,73 @@ __global__ void k_quant_keys(const float* __restrict__ pts, int64_t n, int ld, f
     tflag[i] = (ft == 0.0f) ? 1 : 0;
 }
 
+// ---- several windows in ONE coordinate set (docs/round2_batching_plan.md): the window index b is folded into the time
+// coordinate, t' = floor(t / dt) * B + b.  Time has no bounds and no striding and every table kernel treats time taps
+// symbolically, so with the searched (coarsest) table built on time offsets scaled by B nothing else has to know about
+// windows: rows stay time-major (the newest scans of ALL windows are one suffix), windows never share a neighbour.
+// Compact sort keys: the time field holds (tq + 15) * B + b in [0, 16 B) instead of tq + 15 in [0, 16).
+__host__ __device__ __forceinline__ uint64_t ckey_expand_b(uint64_t c, int B) {
+    const uint64_t bt = (c >> 36) - (uint64_t)(15 * B) + INSMOS_KEY_BIAS;
+    const uint64_t m = c & 0x1FFFFFFFFull;
+    const uint64_t ux = (((c >> 33) & 1) ? 0x8000u : 0x7800u) | compact3(m);
+    const uint64_t uy = (((c >> 34) & 1) ? 0x8000u : 0x7800u) | compact3(m >> 1);
+    const uint64_t uz = (((c >> 35) & 1) ? 0x8000u : 0x7800u) | compact3(m >> 2);
+    return (bt << 48) | spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+}
+
+template <bool COMPACT>
+__global__ void k_quant_keys_b(const float* __restrict__ pts, int64_t n, int ld, float q0, float q1, float q2, float q3,
+                               const int32_t* __restrict__ bid, int B, uint64_t* __restrict__ keys,
+                               uint32_t* __restrict__ idx, int32_t* __restrict__ tflag, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + i * ld;
+    float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;   // the same fp32 ops as k_quant_keys
+    const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz), tq = (int)floorf(ft);
+    const int b = bid[i];
+    const bool t_ok = tq > -4096 && tq < 4096 && b >= 0 && b < B;           // t' must fit the 16-bit biased time field
+    uint64_t k = t_ok ? key4_encode(x, y, z, tq * B + b) : INSMOS_INVALID_KEY;
+    if (k == INSMOS_INVALID_KEY) atomicAdd(&counts[2], 1);
+    if (COMPACT && k != INSMOS_INVALID_KEY) {
+        if (x < -2048 || x > 2047 || y < -2048 || y > 2047 || z < -2048 || z > 2047 || tq < -15 || tq > 0) {
+            atomicAdd(&counts[3], 1);
+            k = INSMOS_INVALID_KEY;
+        } else {
+            const uint64_t lx = (uint64_t)(x + INSMOS_KEY_BIAS) & 0x7FF, ly = (uint64_t)(y + INSMOS_KEY_BIAS) & 0x7FF,
+                           lz = (uint64_t)(z + INSMOS_KEY_BIAS) & 0x7FF;
+            k = ((uint64_t)((tq + 15) * B + b) << 36) | ((uint64_t)(z >= 0) << 35) | ((uint64_t)(y >= 0) << 34) |
+                ((uint64_t)(x >= 0) << 33) | spread3(lx) | (spread3(ly) << 1) | (spread3(lz) << 2);
+        }
+    }
+    keys[i] = k;
+    idx[i] = (uint32_t)i;
+    tflag[i] = (ft == 0.0f) ? 1 : 0;
+}
+
+template <bool COMPACT>
+__global__ void k_quant_scatter_b(const uint64_t* __restrict__ keys_s, const uint32_t* __restrict__ idx_s,
+                                  const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, int64_t n, int B,
+                                  uint64_t* __restrict__ vkeys, int32_t* __restrict__ vcoords,
+                                  int32_t* __restrict__ inverse, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys_s[i];
+    int vid = scan[i] - 1;
+    if (k != INSMOS_INVALID_KEY) {
+        if (flag[i]) {
+            if (COMPACT) k = ckey_expand_b(k, B);
+            vkeys[vid] = k;
+            int x, y, z, t;
+            key4_decode(k, x, y, z, t);
+            *(int4*)(vcoords + (int64_t)vid * 4) = make_int4(x, y, z, t);   // t column = t' (window index folded in)
+        }
+        inverse[idx_s[i]] = vid;
+    } else {
+        inverse[idx_s[i]] = -1;
+    }
+    if (i == n - 1) counts[0] = scan[i];
+}
+
 __global__ void k_head_flags(const uint64_t* __restrict__ keys, int64_t n, int shift_bits, int32_t* __restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -533,6 +600,23 @@ __global__ void k_tslice_starts(const uint64_t* __restrict__ keys, int64_t n, in
     starts[d] = (int32_t)lo;
 }
 
+// batched form: the time field is t' = tq * B + b; starts[d] = first row with tq >= tq_last - d
+__global__ void k_tslice_starts_b(const uint64_t* __restrict__ keys, int64_t n, int max_d, int B,
+                                  int32_t* __restrict__ starts) {
+    const int d = threadIdx.x;
+    if (d >= max_d) return;
+    const int tp_last = (int)(keys[n - 1] >> 48) - (int)INSMOS_KEY_BIAS;
+    const int tq_last = tp_last >= 0 ? tp_last / B : -((-tp_last + B - 1) / B);   // floor division
+    const long long want_tp = (long long)(tq_last - d) * B + (long long)INSMOS_KEY_BIAS;
+    const uint64_t want = want_tp > 0 ? (uint64_t)want_tp << 48 : 0ull;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    starts[d] = (int32_t)lo;
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -600,6 +684,76 @@ extern "C" int insmos_quantize4d_ex(const float* points, int64_t n, int ld_pts, 
         ProfScope ps(KK_QUANT_SCATTER, s);
         INSMOS_LAUNCH(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
     }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// Several windows in one coordinate set: bid[i] = window of point i (0 .. B-1), see k_quant_keys_b.  Same outputs as
+// insmos_quantize4d_ex; the t column of `coords` and the time field of `keys` hold t' = floor(t / dt) * B + b.
+extern "C" int insmos_quantize4d_batched(const float* points, int64_t n, int ld_pts, const float* quant_host,
+                                         const int32_t* bid, int B, uint64_t* keys, int32_t* coords, int32_t* inverse,
+                                         int32_t* cur_index, int32_t* counts, void* ws, size_t ws_bytes, int compact_keys,
+                                         void* stream) {
+    if (n <= 0 || ld_pts < 5 || !points || !quant_host || !bid || B < 1 || B > 64) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    size_t N = (size_t)n;
+    uint64_t* k_in = b.take<uint64_t>(N);
+    uint64_t* k_s = b.take<uint64_t>(N);
+    uint32_t* i_in = b.take<uint32_t>(N);
+    uint32_t* i_s = b.take<uint32_t>(N);
+    int32_t* flag = b.take<int32_t>(N);
+    int32_t* scan = b.take<int32_t>(N);
+    int32_t* tflag = b.take<int32_t>(N);
+    int32_t* tscan = b.take<int32_t>(N);
+    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N);
+    size_t tb = st > sc ? st : sc;
+    char* tmp = b.take<char>(tb);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+    unsigned g = cdiv(n, TPB);
+    {
+        ProfScope ps(KK_QUANT_KEYS, s);
+        if (compact_keys)
+            INSMOS_LAUNCH(k_quant_keys_b<true>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], bid, B, k_in, i_in, tflag, counts);
+        else
+            INSMOS_LAUNCH(k_quant_keys_b<false>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], bid, B, k_in, i_in, tflag, counts);
+    }
+    const int end_bit = compact_keys ? 36 + bits_for((uint64_t)(16 * B - 1)) : 64;
+    int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, end_bit, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
+    }
+    rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        if (compact_keys)
+            INSMOS_LAUNCH(k_quant_scatter_b<true>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
+                          counts);
+        else
+            INSMOS_LAUNCH(k_quant_scatter_b<false>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
+                          counts);
+    }
+    rc = inclusive_scan_i32(tmp, sc, tflag, tscan, N, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_QUANT_SCATTER, s);
+        INSMOS_LAUNCH(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int B, int32_t* starts,
+                                            void* stream) {
+    if (!keys || n <= 0 || max_d <= 0 || max_d > 64 || B < 1 || !starts) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    INSMOS_LAUNCH(k_tslice_starts_b, dim3(1), dim3(64), 0, s, keys, n, max_d, B, starts);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

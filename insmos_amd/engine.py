@@ -299,9 +299,14 @@ class Engine:
         return NbrTable(nbr, mask)
 
     # ------------------------------------------------------------------------------------------------
-    def motionnet(self, pts):
-        """pts (N, ld>=5) fp32 device [x,y,z,r,t] -> current_point (Ncur, 8) [x,y,z,r,m0,m1,m2,0]."""
+    def motionnet(self, pts, bid=None, B=1):
+        """pts (N, ld>=5) fp32 device [x,y,z,r,t] -> current_point (Ncur, 8) [x,y,z,r,m0,m1,m2,0].
+        bid / B (EXPERIMENTAL, docs/round2_batching_plan.md): pts holds B windows back to back, bid (N,) int32 names the
+        window of every point; the window index is folded into the time coordinate (t' = t * B + b), the searched table is
+        built on time offsets scaled by B, everything else runs unchanged on B x the rows -> current points of all windows
+        in input order (window-major)."""
         lib, st = self.lib, self._stream()
+        batched = bid is not None and B > 1
         N, ld = pts.shape[0], pts.stride(0)
         ws = self._workspace(lib.insmos_quantize4d_ws_bytes(N))
         keys0 = self._empty((N,), torch.int64)
@@ -311,9 +316,15 @@ class Engine:
         counts = self._empty((4,), torch.int32)
         quant = np.array([self.vs[0], self.vs[0], self.vs[0], self.dt], dtype=np.float32)
         for compact in (1, 0):  # 40-bit sort keys first; the full-width sort only for windows wider than +-2048 voxels
-            _lib.check(lib.insmos_quantize4d_ex(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
-                                                inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
-                                                ws.numel(), compact, st), "insmos_quantize4d_ex")
+            if batched:
+                _lib.check(lib.insmos_quantize4d_batched(pts.data_ptr(), N, ld, _hp(quant), bid.data_ptr(), B, keys0.data_ptr(),
+                                                         coords0.data_ptr(), inverse.data_ptr(), cur_index.data_ptr(),
+                                                         counts.data_ptr(), ws.data_ptr(), ws.numel(), compact, st),
+                           "insmos_quantize4d_batched")
+            else:
+                _lib.check(lib.insmos_quantize4d_ex(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
+                                                    inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), compact, st), "insmos_quantize4d_ex")
             c = counts.cpu().numpy()
             if int(c[3]) == 0:
                 break
@@ -351,8 +362,12 @@ class Engine:
         if self.prune_dead_rows:
             starts_d = self._empty((4, 16), torch.int32)
             for l in range(4):
-                _lib.check(lib.insmos_tslice_starts(keys[l].data_ptr(), n[l], 16, starts_d[l].data_ptr(), st),
-                           "insmos_tslice_starts")
+                if batched:
+                    _lib.check(lib.insmos_tslice_starts_batched(keys[l].data_ptr(), n[l], 16, B, starts_d[l].data_ptr(), st),
+                               "insmos_tslice_starts_batched")
+                else:
+                    _lib.check(lib.insmos_tslice_starts(keys[l].data_ptr(), n[l], 16, starts_d[l].data_ptr(), st),
+                               "insmos_tslice_starts")
             starts = starts_d.cpu().numpy()
         else:
             starts = np.zeros((4, 16), np.int32)
@@ -374,7 +389,11 @@ class Engine:
             return NbrTable(nb, mk)
 
         # only the coarsest level is searched; every finer table is derived through the Morton hierarchy
-        nbr81 = [None, None, None, self.build_nbr(coords[3], n[3], keys[3], None, n[3], 0, None, self.off81[3])]
+        off_c = self.off81[3]
+        if batched:  # the only arithmetic on t in the whole branch: time offsets of the searched table move by B
+            off_c = off_c.copy()
+            off_c[:, 3] *= B
+        nbr81 = [None, None, None, self.build_nbr(coords[3], n[3], keys[3], None, n[3], 0, None, off_c)]
         for l in (2, 1, 0):
             nb, mk = table(81, n[l])
             # the level-0 table is read by block8 only: rows of the last two scans (dead-row elimination, see above)
@@ -463,6 +482,21 @@ class Engine:
         if self.keep_current_points:
             self.last_current_points = cur
         return cur
+
+    # ------------------------------------------------------------------------------------------------
+    def motionnet_windows(self, pts_list):
+        """EXPERIMENTAL (docs/round2_batching_plan.md, step 1): MotionNet of several windows in ONE set of launches ->
+        list of current_point tensors, each bit-identical to motionnet() of that window alone."""
+        B = len(pts_list)
+        if B == 1:
+            return [self.motionnet(pts_list[0])]
+        pts = torch.cat([p[:, :5] for p in pts_list], 0).contiguous()
+        sizes = torch.tensor([int(p.shape[0]) for p in pts_list], device=pts.device)
+        bid = torch.repeat_interleave(torch.arange(B, device=pts.device, dtype=torch.int32), sizes)
+        cur = self.motionnet(pts, bid.contiguous(), B)
+        ncur = [int((p[:, 4] == 0).sum()) for p in pts_list]
+        assert sum(ncur) == int(cur.shape[0]), (ncur, cur.shape)
+        return list(torch.split(cur, ncur, 0))
 
     # ------------------------------------------------------------------------------------------------
     def detect(self, head, up):
