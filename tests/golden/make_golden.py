@@ -806,6 +806,51 @@ def driver_golden():
                                                                      return_counts=True))})
 
 
+def center_targets_fuzz_golden():
+    """CenterHead.get_targets_single (center_head.py:170-249) as written on 48 random box sets over three map geometries
+    (integer- and float-valued ranges): cells, masks, regression rows and a digest of every heat map -- a wide net for the
+    radius / cell rounding rules the oracle restates (center_loss.npz holds the hand-picked corner cases)."""
+    import hashlib
+    from models.backbones_2d.center_head import CenterHead
+    rng = np.random.default_rng(2024)
+    geoms = [(np.array([1200, 1000, 40]), np.array([-60, -50, -3, 60, 50, 1]), [0.1, 0.1, 0.1]),
+             (np.array([2400, 2000, 80]), np.array([-60.0, -50.0, -3.0, 60.0, 50.0, 1.0]), [0.05, 0.05, 0.05]),
+             (np.array([352, 400, 40]), np.array([0, -40, -3, 70.4, 40, 1]), [0.2, 0.2, 0.1])]
+    out = {"n_cases": np.int64(48)}
+    for case in range(48):
+        grid, pcr, vsz = geoms[case % 3]
+        cfgh = {"TARGET_ASSIGNER_CONFIG": {"MAX_OBJS": 30, "VOXEL_SIZE": vsz, "OUT_SIZE_FACTOR": 4,
+                                           "GAUSSIAN_OVERLAP": [0.1, 0.3, 0.5][case % 3], "MIN_RADIUS": [2, 1, 3][(case // 3) % 3]},
+                "LOSS_CONFIG": {"LOSS_WEIGHTS": {"cls_weight": 1.0, "loc_weight": 2.0, "code_weights": [1.0] * 8}}}
+        head = CenterHead(cfgh, 16, 3, ["Car", "Pedestrian", "Cyclist"], grid, pcr)
+        M = int(rng.integers(1, 40))
+        gt = np.zeros((M, 8), np.float32)
+        lo, hi = pcr[:3].astype(float), pcr[3:6].astype(float)
+        gt[:, 0] = rng.uniform(lo[0] - 3, hi[0] + 3, M)
+        gt[:, 1] = rng.uniform(lo[1] - 3, hi[1] + 3, M)
+        gt[:, 2] = rng.uniform(-2, 0, M)
+        gt[:, 3:6] = np.exp(rng.uniform(np.log(0.2), np.log(25.0), (M, 3)))
+        gt[:, 6] = rng.uniform(-7, 7, M)
+        gt[:, 7] = rng.integers(0, 4, M)
+        gt[rng.uniform(size=M) < 0.1, 3] = 0.0
+        gtb = torch.from_numpy(gt.copy())
+        hm, ab, idx, mk = head.get_targets_single(gtb[:, :-1], gtb[:, -1])
+        pre = "c%02d_" % case
+        out[pre + "gt"] = gt
+        out[pre + "geom"] = np.int64(case % 3)
+        out[pre + "overlap"] = np.float64(cfgh["TARGET_ASSIGNER_CONFIG"]["GAUSSIAN_OVERLAP"])
+        out[pre + "min_radius"] = np.int64(cfgh["TARGET_ASSIGNER_CONFIG"]["MIN_RADIUS"])
+        out[pre + "ind"] = idx[0].numpy()
+        out[pre + "mask"] = mk[0].numpy()
+        out[pre + "anno"] = ab[0].numpy()
+        h = hm[0].numpy()
+        out[pre + "heat_digest"] = np.array(hashlib.sha256(np.ascontiguousarray(h).tobytes()).hexdigest())
+        out[pre + "heat_sum"] = np.float64(h.astype(np.float64).sum())
+        out[pre + "heat_ones"] = np.int64((h == 1).sum())
+    np.savez_compressed(os.path.join(HERE, "center_targets_fuzz.npz"), **out)
+    print("center targets fuzz golden: 48 cases,", int(sum(out["c%02d_mask" % c].sum() for c in range(48))), "assigned boxes")
+
+
 def synth_refine_sequence(seed=3, n_frames=12, low_dynamic=False):
     """A tiny driving scene for the refine stage: cars (some moving, some parked), a pedestrian, background; per frame the
     scan, the 'predicted' boxes / labels, per-point MOS labels (9 / 251 with per-car moving ratios chosen to hit every
@@ -944,6 +989,9 @@ def _run_reference_refine(frames, poses_txt, calib_txt, tag, data):
 if __name__ == "__main__":
     if "--wiring-only" in sys.argv:
         wiring_golden()
+        sys.exit(0)
+    if "--centerfuzz-only" in sys.argv:
+        center_targets_fuzz_golden()
         sys.exit(0)
     if "--driver-only" in sys.argv:
         driver_golden()
