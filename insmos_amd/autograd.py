@@ -176,11 +176,18 @@ class MosLossFunction(torch.autograd.Function):
         st = _stream(logits.device)
         lg = logits.contiguous().float()
         n, ncls = lg.shape
+        # converted views are bound to locals: a temporary would be released before the launch that reads its memory
+        gt_l = gt.contiguous().long()
+        cw = class_weights.contiguous().float()
+        if gt_l.numel() != n:
+            raise ValueError(f"mos_loss: {gt_l.numel()} labels for {n} logit rows")
+        if gt_l.device != lg.device or cw.device != lg.device:
+            raise ValueError("mos_loss: logits, labels and class weights must live on the same device")
         sums = torch.empty(2, dtype=torch.float32, device=lg.device)
         grad = torch.empty((n, ncls), dtype=torch.float32, device=lg.device)
         ws = torch.empty(int(lib.insmos_mos_loss_ws_floats(n)), dtype=torch.float32, device=lg.device)
-        _lib.check(lib.insmos_mos_loss(lg.data_ptr(), lg.stride(0), gt.contiguous().long().data_ptr(), n, ncls, int(ignore_mask),
-                                       class_weights.contiguous().float().data_ptr(), sums.data_ptr(), grad.data_ptr(), ncls,
+        _lib.check(lib.insmos_mos_loss(lg.data_ptr(), lg.stride(0), gt_l.data_ptr(), n, ncls, int(ignore_mask),
+                                       cw.data_ptr(), sums.data_ptr(), grad.data_ptr(), ncls,
                                        ws.data_ptr(), st), "insmos_mos_loss")
         ctx.save_for_backward(grad)
         return sums[0] / sums[1]
@@ -248,20 +255,23 @@ class CenterHeadLossFunction(torch.autograd.Function):
         g_box = torch.empty_like(bp)
         ws = torch.empty(int(lib.insmos_center_head_loss_ws_floats(hw, nc)), dtype=torch.float32, device=cp.device)
         cw = (ctypes.c_float * 8)(*[float(v) for v in code_weights])
-        _lib.check(lib.insmos_center_head_loss(cp.data_ptr(), nc, bp.data_ptr(), 8, hw, nc, heatmap.contiguous().data_ptr(),
-                                               anno_box.contiguous().data_ptr(), ind.contiguous().data_ptr(),
-                                               mask.contiguous().data_ptr(), max_objs, float(cls_weight), float(loc_weight),
+        hm, ab, ix, mk = heatmap.contiguous(), anno_box.contiguous(), ind.contiguous(), mask.contiguous()  # alive across the launch
+        _lib.check(lib.insmos_center_head_loss(cp.data_ptr(), nc, bp.data_ptr(), 8, hw, nc, hm.data_ptr(),
+                                               ab.data_ptr(), ix.data_ptr(),
+                                               mk.data_ptr(), max_objs, float(cls_weight), float(loc_weight),
                                                ctypes.cast(cw, ctypes.c_void_p), losses.data_ptr(), g_cls.data_ptr(), nc,
                                                g_box.data_ptr(), 8, ws.data_ptr(), st), "insmos_center_head_loss")
         ctx.save_for_backward(g_cls, g_box)
-        return losses
+        # the stored gradients are those of the TOTAL (losses[2]); the two parts are reported, not differentiated
+        parts = losses[:2].detach()
+        ctx.mark_non_differentiable(parts)
+        return parts, losses[2]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_parts, g_total):
         g_cls, g_box = ctx.saved_tensors
-        # losses[2] = losses[0] + losses[1]; the stored gradients are those of the total, which is what get_loss() returns
-        # and the training step differentiates (center_head.py:283); the two parts share them through g[2] only
-        return g_cls * g[2], g_box * g[2], None, None, None, None, None, None, None
+        # total = cls + loc is what get_loss() returns and the training step differentiates (center_head.py:283)
+        return g_cls * g_total, g_box * g_total, None, None, None, None, None, None, None
 
 
 def center_head_loss(cls_preds, box_preds, targets, head_cfg):
@@ -274,9 +284,9 @@ def center_head_loss(cls_preds, box_preds, targets, head_cfg):
         raise ValueError("center_head_loss: one batch item per call (the reference's model loop feeds B = 1)")
     lw = head_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]
     nc = int(cls_preds.shape[-1])
-    losses = CenterHeadLossFunction.apply(cls_preds.reshape(-1, nc), box_preds.reshape(-1, 8), targets["heatmaps"][0][0],
-                                          targets["anno_boxes"][0][0], targets["inds"][0][0], targets["masks"][0][0],
-                                          lw["cls_weight"], lw["loc_weight"], lw["code_weights"])
-    host = losses.detach().cpu()
+    parts, total = CenterHeadLossFunction.apply(cls_preds.reshape(-1, nc), box_preds.reshape(-1, 8), targets["heatmaps"][0][0],
+                                                targets["anno_boxes"][0][0], targets["inds"][0][0], targets["masks"][0][0],
+                                                lw["cls_weight"], lw["loc_weight"], lw["code_weights"])
+    host = torch.cat([parts, total.detach().reshape(1)]).cpu()
     tb = {"rpn_loss_cls": float(host[0]), "rpn_loss_loc": float(host[1]), "rpn_loss": float(host[2])}
-    return losses[2], tb
+    return total, tb

@@ -23,6 +23,8 @@ class ClassificationMetrics:
         lib = _lib.load()
         logits = pred_logits if pred_logits.stride(1) == 1 else pred_logits.contiguous()
         gt = gt_labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        if gt.numel() != logits.shape[0]:
+            raise ValueError(f"compute_confusion_matrix: {gt.numel()} labels for {logits.shape[0]} logit rows")
         cm = out if out is not None else torch.zeros((self.n_classes, self.n_classes), dtype=torch.int64,
                                                      device=logits.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)

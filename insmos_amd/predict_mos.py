@@ -113,14 +113,16 @@ def enumerate_jobs(n_full, dt_pred, dt_data, n_files):
     skip = int(round(dt_pred / dt_data))
     n_windows = max(0, n_files - skip * (n_full - 1))
     first_full = skip * (n_full - 1)
+    skip_w = int(round(0.1 / dt_data))    # the warm-up datasets run at DELTA_T_PREDICTION = 0.1 whatever the config says (:308)
     jobs = []
     for i in range(int(n_full * dt_pred * 10)):
         n_past = i + 1
-        if i >= first_full and n_windows > 0:
-            continue                      # overwritten by a full window
-        if n_files - (n_past - 1) <= 0:
+        scan = skip_w * (n_past - 1)      # first sample of DemoDataset(N_PAST_STEPS = n_past): scan_idx = skip * (n_past - 1)
+        if n_files - scan <= 0:
             continue                      # DemoDataset of that length is empty (:99-101)
-        jobs.append((n_past, 0, i))
+        if first_full <= scan < first_full + n_windows:
+            continue                      # overwritten by a full window
+        jobs.append((n_past, 0, scan))
     for j in range(n_windows):
         jobs.append((n_full, j, first_full + j))
     return jobs

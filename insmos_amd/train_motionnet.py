@@ -96,7 +96,7 @@ class MotionNetTrainer:
         out = self._bn(sparse_conv(out, p["convtr7p2s2.kernel"], None, up[0], dn[0]), "bntr7", True)
         out = self._block("block8.0", torch.cat([out, out_p1], 1), n81[0])
         motion = sparse_conv(out, p["final.kernel"], p["final.bias"], None)  # (n0, 3)
-        cur = torch.nonzero(torch.floor(pts[:, 4] / self.dt) == 0).flatten()  # motionnet.py:42-46
+        cur = torch.nonzero((pts[:, 4] / self.dt) == 0).flatten()  # motionnet.py:42-46
         return motion[T["inverse"].long()[cur]]
 
     def loss(self, pts, gt_labels_cur):

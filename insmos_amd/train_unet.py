@@ -256,7 +256,7 @@ class InsMOSTrainer:
             gt = b["past_labels"][-1]
             motion = self.motion.forward(pts)                                   # (Ncur, 3), differentiable
             loss_motion = mos_loss(motion, gt, 3, (0,))
-            cur_rows = torch.nonzero(torch.floor(pts[:, 4] / self.dt) == 0).flatten()
+            cur_rows = torch.nonzero((pts[:, 4] / self.dt) == 0).flatten()
             cur = torch.zeros((cur_rows.shape[0], 8), dtype=torch.float32, device=self.device)
             cur[:, :4] = pts[cur_rows, :4]
             cur[:, 4:7] = motion.detach()                                       # voxelisation cuts the tape (see module doc)

@@ -540,8 +540,6 @@ def test_oracle_center_targets_vs_reference_fuzz(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("INSMOS_RUN_STAGED") != "1", reason="staged for round 2 (INSMOS_RUN_STAGED=1 runs it): the "
-                    "fuzz fixture was added after round 1's GPU budget was spent")
 def test_center_targets_kernel_vs_reference_fuzz(golden_dir):
     import torch
     from insmos_amd.autograd import center_assign_targets

@@ -1,14 +1,11 @@
-"""-m gpu, STAGED for round 2 (written after round 1's GPU budget was spent, never run): MotionNet of several windows in one
-set of launches (Engine.motionnet_windows; docs/round2_batching_plan.md step 1) must give every window the bits it gets alone."""
-import os
+"""-m gpu: MotionNet of several windows in one set of launches (Engine.motionnet_windows; docs/round2_batching_plan.md
+step 1) must give every window the bits it gets alone."""
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("INSMOS_RUN_STAGED") != "1",
-                                                  reason="staged for round 2 (INSMOS_RUN_STAGED=1 runs it): first run of "
-                                                         "the batched MotionNet prototype")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B", [2, 3, 8])

@@ -43,10 +43,6 @@ def test_hip_forward_vs_reference_model_code(golden_dir):
     np.testing.assert_array_equal(preds[0][0]["pred_labels"].cpu().numpy(), g["pred_labels"][dist.argmin(1)])
 
 
-@pytest.mark.skipif(os.environ.get("INSMOS_RUN_STAGED") != "1",
-                    reason="staged for round 2 (INSMOS_RUN_STAGED=1 runs it): first run of the HIP training step directly "
-                           "against the reference-code gradients (today it is checked through the float64 yardstick graphs, "
-                           "test_train_unet.py + test_train_wiring.py)")
 def test_hip_training_step_vs_reference_training_code(golden_dir):
     import zlib
     from insmos_amd import params as P

@@ -8,8 +8,8 @@
 R=$(pwd); mkdir -p $R/gpurun_out
 echo "== 1. training tests, INSMOS_DW_MFMA=1"
 INSMOS_DW_MFMA=1 timeout 400 python -m pytest tests/test_train_slice.py tests/test_train_unet.py -q -m gpu 2>&1 | tail -4
-echo "== 1b. staged tests (batched MotionNet prototype, HIP training step vs reference-code gradients)"
-INSMOS_RUN_STAGED=1 timeout 300 python -m pytest tests/test_zz_gpu_batched_motionnet.py tests/test_zz_gpu_reference_golden.py -q -m gpu -s 2>&1 | tail -12
+echo "== 1b. whole GPU suite, nothing staged"
+timeout 600 python -m pytest tests -q -m gpu -x 2>&1 | tail -30
 echo "== 1c. batched MotionNet against one window after the other"
 timeout 200 python tools/batched_motionnet_probe.py 4 2>&1 | tail -2
 echo "== 2. full training step (S0 window)"

@@ -41,6 +41,7 @@ def synth_item(seed, n_az, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps-per-epoch", type=int, default=5, help="the LR schedule steps once per this many iterations")
     ap.add_argument("--n-az", type=int, default=472)
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
@@ -64,9 +65,10 @@ def main():
         if reducer is not None:
             reducer.reduce()
         opt.step()
+        if (step + 1) % args.steps_per_epoch == 0:
+            sched.step()              # StepLR counts (pseudo-)epochs, as models/models.py:188-193 does
         if rank == 0:
             print(f"step {step}: loss {float(loss.detach()):.4f}  " + "  ".join(f"{k} {v:.4f}" for k, v in tb[0].items()), flush=True)
-    sched.step()
     if rank == 0 and args.out:
         out = dict(sd)
         out.update(tr.unet.export_state_dict())
