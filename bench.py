@@ -3,7 +3,8 @@
 
 A "step" is one forward() over a batch of `--windows-per-step` different windows (each N=10 pose-aligned
 scans, ~1.2 M points in, per-point MOS logits + boxes out) with the inputs already resident in HBM:
-BASELINE.json configs[1] (synthetic S0); the model keeps several of them in flight.
+BASELINE.json configs[1] (synthetic S0); the model runs them as launch sets of
+INSMOS_WINDOWS_PER_LAUNCH windows (one set of kernel launches per group), INSMOS_WINDOWS_IN_FLIGHT sets at a time.
 One process per GPU; ranks hold different windows (seeds rank*W ..) and there is no data-path collective -- the only exchange is the all_gather of the 3x3 confusion counters at the
 end of the timed region.  Rank 0 prints ONE JSON line.
 
@@ -45,30 +46,65 @@ def load_window(seed, n_az, n_scans=10):
     return w
 
 
-def calibrate_head(model, pts, target):
+def load_windows(seeds, n_az, n_scans=10):
+    """The step's windows; the ones not cached on this box yet are ray-cast in parallel worker processes (a window takes
+    ~10 s of numpy on one core)."""
+    missing = [sd for sd in seeds if not os.path.exists(f"/tmp/insmos_s0_seed{sd}_az{n_az}_n{n_scans}.npy")]
+    if len(missing) > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=min(len(missing), max(1, (os.cpu_count() or 2) // 2)),
+                                 mp_context=mp.get_context("spawn")) as ex:
+            list(ex.map(load_window, missing, [n_az] * len(missing), [n_scans] * len(missing)))
+    return [load_window(sd, n_az, n_scans) for sd in seeds]
+
+
+def calibrate_head(model, pts, target, cache=None, tag="", load_only=False):
     """Synthetic weights never fire the CenterHead (bias -log 99).  Shift the class bias so that about
     `target` cells pass SCORE_THRESH, giving the NMS / instance-feature stages a realistic load."""
     from insmos_amd import params as P
     eng = model.model.engine
-    eng.forward_window(pts, native=False)  # the step-by-step path keeps the head map
-    head = eng._head_debug["head"][:, :eng.ncls]
-    best = head.max(dim=1).values
-    kth = torch.topk(best, min(target, best.numel())).values[-1].item()
-    shift = math.log(0.1 / 0.9) - kth
+    shift = None
+    if cache and os.path.exists(cache):
+        with open(cache) as f:
+            shift = json.load(f).get(tag)
+    if shift is None:
+        if load_only:
+            raise SystemExit(f"--timed-only needs the calibration cache {cache} (run bench.py once without it)")
+        eng.forward_window(pts, native=False)  # the step-by-step path keeps the head map
+        head = eng._head_debug["head"][:, :eng.ncls]
+        best = head.max(dim=1).values
+        kth = torch.topk(best, min(target, best.numel())).values[-1].item()
+        shift = math.log(0.1 / 0.9) - kth
+        if cache:
+            try:
+                old = {}
+                if os.path.exists(cache):
+                    with open(cache) as f:
+                        old = json.load(f)
+                old[tag] = shift
+                with open(cache, "w") as f:
+                    json.dump(old, f)
+            except OSError:
+                pass
     key = P.UNET_PREFIX + "center_head.conv_cls.bias"
     sd = model.state_dict()
     sd[key] = (np.asarray(sd[key], np.float32) + np.float32(shift)).astype(np.float32)
     eng._load_weights(sd)
 
 
-def pmc_traffic(args):
-    """HBM bytes per conv launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE), committed under profiles/; null when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(args, wpl):
+    """HBM bytes of the conv launches from the rocprofv3 PMC passes of `bench.py --timed-only` at this configuration
+    (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, units and gfx950 corrections as the microarch guide
+    prescribes), committed under profiles/; null when the workload or the launch-set size differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if args.n_az != 1886 or not os.path.exists(path):
         return None
     with open(path) as f:
-        return round(json.load(f)["hbm_bytes_per_launch"])
+        j = json.load(f)
+    if int(j.get("windows_per_launch", -1)) != int(wpl):
+        return None
+    return j
 
 
 def read_profile(lib):
@@ -87,10 +123,16 @@ def main():
     ap.add_argument("--n-az", type=int, default=1886, help="azimuth steps of the synthetic scan (1886 = S0, 120k pts)")
     ap.add_argument("--candidates", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-az", type=int, default=944,
-                    help="azimuth steps of the CPU-baseline sample window (944 = half of S0: ~12 s of oracle time on the GPU box)")
+    ap.add_argument("--cpu-sample-az", type=int, default=1886,
+                    help="azimuth steps of the CPU-baseline window (1886 = the bench window itself: ~20-30 s of oracle time)")
+    ap.add_argument("--calibration", type=str, default="/tmp/insmos_bench_calibration.json",
+                    help="where the head-bias calibration of this workload is cached (so that a profiled run can skip it)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling mode (rocprofv3 --kernel-trace --stats / --pmc): load the cached calibration, run the "
+                         "warm-up and the timed steps and nothing else -- every kernel launch in the trace belongs to a step")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
-    ap.add_argument("--windows-per-step", type=int, default=8, help="batch items of one forward() = one step")
+    ap.add_argument("--windows-per-step", type=int, default=16, help="batch items of one forward() = one step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,13 +162,16 @@ def main():
     # one step = one forward() over a batch of `windows_per_step` DIFFERENT windows (seeds rank*W .. rank*W+W-1);
     # InsMOS_Model keeps up to INSMOS_WINDOWS_IN_FLIGHT of them in flight (threads + streams, same device weights)
     W = max(1, args.windows_per_step)
-    windows = [load_window(rank * W + i, args.n_az) for i in range(W)]
+    windows = load_windows([rank * W + i for i in range(W)], args.n_az)
     window = windows[0]
     pts_list = [torch.from_numpy(w).to(dev) for w in windows]
     pts = pts_list[0]
     model = InsMOSNet(cfg, state_dict=sd).cuda(local_rank).eval()
-    calibrate_head(model, pts, args.candidates)
+    calibrate_head(model, pts, args.candidates, cache=args.calibration, tag=f"rank{rank}_az{args.n_az}_c{args.candidates}",
+                   load_only=args.timed_only)
     eng = model.model.engine
+    wpl = min(W, model.model.windows_per_launch)
+    in_flight = min((W + wpl - 1) // wpl, model.model.windows_in_flight)
     batch = [{"past_point_clouds": p} for p in pts_list]
     ncur = int((window[:, 4] == 0).sum())
     gts = [torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=rank * W + i)).to(dev) for i, w in enumerate(windows)]
@@ -154,7 +199,31 @@ def main():
         dt = float(t.item())
     value = world * args.steps * W / dt
     iou = metrics.getIoU(cm_all).cpu().numpy()
-    in_flight = min(W, model.model.windows_in_flight)
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"timed_only": True, "value": round(value, 3), "steps": args.steps, "warmup": args.warmup,
+                              "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
+                              "windows_total": (args.steps + args.warmup) * W}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- the same loop sustained for several seconds (visible to an SMI sampler; not the headline)
+    sustained = None
+    if args.sustain_seconds > 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t1 < args.sustain_seconds:
+            model.forward(batch, "test")
+            k += 1
+        torch.cuda.synchronize()
+        sustained = k * W / (time.perf_counter() - t1)
+        if world > 1:
+            t = torch.tensor([sustained], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            sustained = float(t.item())
 
     out = {
         "metric": "scans_per_sec", "value": round(value, 3), "unit": "scans/s (windows of N=10 scans, ~120k pts/scan)",
@@ -162,80 +231,90 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg-2: synthetic S0 windows, N=10 scans, voxel 0.1 m, full InsMOS forward "
                                "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)",
-                   "windows_per_step": W, "windows_in_flight": in_flight,
+                   "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
                    "n_az": args.n_az, "points_per_window": int(len(window)), "current_points": ncur,
-                   "me_voxels": eng.last_counts.get("me_voxels"), "unet_voxels": eng.last_counts.get("unet_voxels"),
-                   "nms_candidates": eng.last_counts.get("n_candidates"), "boxes": eng.last_counts.get("n_boxes"),
                    "weights": "seeded random (He-normal, occupancy-corrected), head bias calibrated to "
                               f"~{args.candidates} candidates", "parallelism": f"dp{world} (windows sharded by rank)"},
         "ms_per_window": round(1000.0 * dt / (args.steps * W), 3),
+        "timed_region_s": round(dt, 3),
+        "sustained_scans_per_sec": round(sustained, 3) if sustained is not None else None,
         "mos_iou_moving_vs_pseudo_gt": float(iou[2]),
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_sparse_conv), HIP events on the launch streams, same workload:
-        #  (a) as timed: `in_flight` windows at once -> launches of different windows overlap, so the busy time of the
-        #      kernel is the UNION of its launches' event intervals; (b) one window at a time: plain per-launch durations
+        # ---- roofline of the dominant kernel (k_sparse_conv), HIP events on the launch stream, same workload, ONE launch
+        # set at a time (nothing else on the GPU): plain per-launch durations -- what `rocprofv3 --kernel-trace --stats` of
+        # `INSMOS_WINDOWS_IN_FLIGHT=1 bench.py --timed-only` shows (profiles/, tools/roofline_from_rocprof.py)
         lib = _lib.load()
-        KK_CONV = next(k for k in range(64) if lib.insmos_prof_name(k) == b"sparse_conv_mfma")
-        eng.prune_dead_rows = False
-        eng.forward_window(pts, native=False)  # every row of every layer, as the reference computes them
-        work_ref = eng.algorithmic_work()
-        eng.prune_dead_rows = True
-        eng.forward_window(pts, native=False)  # step path: fills the launch log the EXECUTED work is counted from
-        work = eng.algorithmic_work()
-        nprof = 3
+        flops = flops_ref = gather = launches = comp = 0
+        counts0 = None
+        for p in pts_list:                      # algorithmic work of every window of the step (step path, per window)
+            eng.prune_dead_rows = False
+            eng.forward_window(p, native=False)  # every row of every layer, as the reference computes them
+            flops_ref += eng.algorithmic_work()["flops"]
+            eng.prune_dead_rows = True
+            eng.forward_window(p, native=False)  # fills the launch log the EXECUTED work is counted from
+            wk = eng.algorithmic_work()
+            flops += wk["flops"]
+            gather += wk["gather_bytes"]
+            comp += wk["compulsory_bytes"]
+            launches = wk["launches"]
+            if counts0 is None:
+                counts0 = dict(eng.last_counts)
+                eng.forward_window(p)
+                counts0.update({k: eng.last_counts.get(k) for k in ("n_candidates", "n_boxes")})
+        out["config"].update({"me_voxels": counts0.get("me_voxels"), "unet_voxels": counts0.get("unet_voxels"),
+                              "nms_candidates": counts0.get("n_candidates"), "boxes": counts0.get("n_boxes")})
+        groups = [pts_list[i:i + wpl] for i in range(0, W, wpl)]
+        nprof = 2
+        for g_ in groups:
+            eng.forward_windows(g_)
         lib.insmos_prof_reset()
         lib.insmos_prof_enable(1)
         for _ in range(nprof):
-            model.forward(batch, "test")
-        uni, tot, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        _lib.check(lib.insmos_prof_read_union(KK_CONV, ctypes.byref(uni), ctypes.byref(tot), ctypes.byref(cnt)), "prof")
-        lib.insmos_prof_reset()
-        for _ in range(nprof):
-            for p in pts_list[:1]:
-                eng.forward_window(p)
+            for g_ in groups:
+                eng.forward_windows(g_)
         prof = read_profile(lib)
         lib.insmos_prof_enable(0)
         lib.insmos_prof_reset()
-        conv_ms, conv_launches = prof.get("sparse_conv_mfma", (0.0, 0))
-        conv_ms_per_window = conv_ms / nprof
-        total_ms = sum(v[0] for v in prof.values()) / nprof
-        ach1 = work["flops"] / (conv_ms_per_window * 1e-3) / 1e12 if conv_ms_per_window > 0 else 0.0
         n_win = nprof * W
-        busy_per_window = uni.value / n_win
-        ach = work["flops"] / (busy_per_window * 1e-3) / 1e12 if busy_per_window > 0 else 0.0
+        conv_ms, conv_launches = prof.get("sparse_conv_mfma", (0.0, 0))
+        conv_ms_per_window = conv_ms / n_win
+        total_ms = sum(v[0] for v in prof.values()) / n_win
+        flops_w, flops_ref_w, gather_w = flops / W, flops_ref / W, gather / W
+        ach = flops_w / (conv_ms_per_window * 1e-3) / 1e12 if conv_ms_per_window > 0 else 0.0
+        traffic = pmc_traffic(args, wpl)
         out["roofline"] = {
-            "kernel": "k_sparse_conv (all %d launches of one window)" % work["launches"], "bound": "mfma",
-            "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args),
-            "algorithmic_gflop_per_window": round(work["flops"] / 1e9, 3),
-            "reference_gflop_per_window": round(work_ref["flops"] / 1e9, 3),
+            "kernel": "k_sparse_conv + k_deconv_head + k_resolve_taps<conv0> (the %d convolution launches of a launch set)"
+                      % launches,
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic else None,
+            "traffic_bytes_per_window": round(traffic["hbm_bytes_per_window"]) if traffic else None,
+            "algorithmic_gflop_per_window": round(flops_w / 1e9, 3),
+            "reference_gflop_per_window": round(flops_ref_w / 1e9, 3),
             "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed); MotionNet rows "
                          "nothing consumes are skipped (DESIGN.md 3.3), the reference computes reference_gflop_per_window",
-            "method": f"{in_flight} windows in flight: achieved = algorithmic FLOP of the conv launches / UNION of their "
-                      "HIP-event intervals (other kernels share the GPU during that time); single_stream = one window at a "
-                      "time, plain per-launch durations (what a rocprof kernel trace of a sequential run shows)",
-            "busy_ms_per_window": round(busy_per_window, 3),
-            "overlapped_avg_launch_us": round(1000.0 * tot.value / max(cnt.value, 1), 2),
-            "single_stream": {
-                "achieved": round(ach1, 3), "frac": round(ach1 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "kernel_ms_per_window": round(conv_ms_per_window, 3),
-                "avg_launch_us": round(1000.0 * conv_ms / max(conv_launches, 1), 2),
-                "gather_gbs": round(work["gather_bytes"] / (conv_ms_per_window * 1e-3) / 1e9, 1) if conv_ms_per_window else 0,
-                "gather_frac_of_hbm_peak": round(work["gather_bytes"] / (conv_ms_per_window * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-                if conv_ms_per_window else 0,
-            },
+            "method": f"one launch set of {wpl} windows at a time on one stream: achieved = algorithmic FLOP of the conv "
+                      "launches / sum of their HIP-event durations (= rocprofv3 kernel stats of INSMOS_WINDOWS_IN_FLIGHT=1 "
+                      "bench.py --timed-only, tools/roofline_from_rocprof.py)",
+            "kernel_ms_per_window": round(conv_ms_per_window, 4),
+            "avg_launch_us": round(1000.0 * conv_ms / max(conv_launches, 1), 2),
+            "launches_per_window": round(conv_launches / n_win, 2),
+            "gather_gbs": round(gather_w / (conv_ms_per_window * 1e-3) / 1e9, 1) if conv_ms_per_window else 0,
         }
-        # the north star's framing ("scans/sec ... as fraction of HBM roofline"): compulsory bytes of one cfg-2 window
-        # (every layer reads its input, its table and writes its output once = 1.33 GB) x windows/s over the
-        # HBM peak.  It comes out at a few per cent -- the path is not HBM-bound, which is why `bound` above is "mfma".
-        if args.n_az == 1886:
-            out["roofline"]["hbm_view"] = {"compulsory_gb_per_window": 1.33,
-                                           "achieved_gbs": round(1.33 * value / max(world, 1), 1),
-                                           "frac_of_hbm_peak": round(1.33 * value / max(world, 1) / PEAK_HBM_GBS, 4),
-                                           "note": "per GPU; compulsory bytes from SURVEY.md 8d, HBM peak 8 TB/s"}
-        out["kernel_ms_per_window"] = {k: round(v[0] / nprof, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        # the north star's framing ("scans/sec ... as fraction of HBM roofline"): compulsory bytes of one window (every
+        # layer reads its input and its table rows and writes its output once; profiles/r01_layer_work_s0.csv) x windows/s
+        # over the HBM peak.  A few per cent: the path is not HBM-bound, which is why `bound` above is "mfma".
+        comp = comp / W
+        out["roofline"]["hbm_view"] = {"compulsory_gb_per_window": round(comp / 1e9, 3),
+                                       "achieved_gbs": round(comp / 1e9 * value / max(world, 1), 1),
+                                       "frac_of_hbm_peak": round(comp / 1e9 * value / max(world, 1) / PEAK_HBM_GBS, 4),
+                                       "measured_hbm_gb_per_window": round(traffic["hbm_bytes_per_window"] / 1e9, 3) if traffic else None,
+                                       "note": "per GPU; compulsory = sum over the conv launches of 4*(rows_in*Cin + rows_out*Cout) "
+                                               "+ 4*K*rows_out table bytes (mean over the step's windows); HBM peak 8 TB/s"}
+        out["kernel_ms_per_window"] = {k: round(v[0] / n_win, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        out["launches_per_window"] = round(sum(v[1] for v in prof.values()) / n_win, 1)
         out["device_ms_per_window_sum"] = round(total_ms, 3)
         # latency of ONE window, nothing else in flight
         torch.cuda.synchronize()
@@ -255,32 +334,34 @@ def main():
                 for r in rows:
                     f.write("%s,%d,%d,%d,%d,%.1f\n" % r)
 
-        # ---- CPU baseline: the oracle (a port, not MinkowskiEngine) on a bounded sample of the same workload
+        # ---- CPU baseline: the oracle (a port, not MinkowskiEngine) on the bench window itself (one window of the step)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_model as M
             from oracle import ref_ops as R
-            sw = load_window(0, args.cpu_sample_az)
+            sw = windows[0] if args.cpu_sample_az == args.n_az else load_window(0, args.cpu_sample_az)
             t1 = time.perf_counter()
             ref_logits, ref_pred = M.forward_window(model.state_dict(), cfg, sw)
             cpu_s = time.perf_counter() - t1
-            _, _, lg = model.forward([{"past_point_clouds": torch.from_numpy(sw).to(dev)}], "test")
+            pr, _, lg = model.forward([{"past_point_clouds": torch.from_numpy(sw).to(dev)}], "test")
             got = lg[0].cpu().numpy()
             lab, _ = R.output_stage(got)
             lab_ref, _ = R.output_stage(ref_logits)
             out["cpu_baseline"] = {
-                "value": round(1.0 / cpu_s, 4), "unit": "scans/s on the sample", "cores": R.num_threads(), "kind": "port",
-                "sample": f"one S0-style window at n_az={args.cpu_sample_az} ({len(sw)} points = "
-                          f"{len(sw) / len(window):.3f} of the bench window), oracle/ref_model.forward_window "
+                "value": round(1.0 / cpu_s, 4), "unit": "scans/s", "cores": R.num_threads(), "kind": "port",
+                "sample": f"ONE window of the bench step (seed 0, n_az={args.cpu_sample_az}, {len(sw)} points = "
+                          f"{len(sw) / len(window):.3f} of a bench window), oracle/ref_model.forward_window "
                           "(numpy + OpenMP C, torch-CPU for the dense BEV convs); CPU restatement, NOT MinkowskiEngine",
                 "seconds": round(cpu_s, 2),
             }
             out["parity_on_sample"] = {"max_abs_logit_diff": float(np.abs(got - ref_logits).max()),
                                        "labels_equal": bool((lab == lab_ref).all()),
-                                       "label_mismatches": int((lab != lab_ref).sum()), "points": int(len(lab))}
+                                       "label_mismatches": int((lab != lab_ref).sum()), "points": int(len(lab)),
+                                       "boxes_oracle_gpu": [int(len(ref_pred["pred_boxes"])), int(len(pr[0][0]["pred_boxes"]))]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":

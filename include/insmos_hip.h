@@ -204,14 +204,55 @@ int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, c
                             int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
                             void* stream);
 int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream);
-/* Several windows in ONE 4D coordinate set (EXPERIMENTAL, docs/round2_batching_plan.md; used by Engine.motionnet_windows only):
- * bid[i] = window of point i (0 .. B-1); the window index is folded into the time coordinate, t' = floor(t / dt) * B + b
- * (the t column of coords and the time field of keys), so every table / convolution entry point works unchanged when the
- * SEARCHED table is built on time offsets scaled by B.  insmos_tslice_starts_batched: starts[d] = first row with
- * floor(t' / B) >= tq_last - d. */
-int insmos_quantize4d_batched(const float* points, int64_t n, int ld_pts, const float* quant_host, const int32_t* bid, int B,
-                              uint64_t* keys, int32_t* coords, int32_t* inverse, int32_t* cur_index, int32_t* counts, void* ws,
-                              size_t ws_bytes, int compact_keys, void* stream);
+/* ---- B windows in ONE set of launches (replaces the per-item loop of InsMOS_Model.forward, models/models.py:313) -------
+ * The batch entry points below (suffix _windows / _b) are the single-window ones with a leading window dimension; B = 1
+ * gives exactly the single-window results, and every window of a batch gets the bits it gets alone.  B <= 16.
+ *   4D branch: the window index is folded into the time coordinate, t' = floor(t / dt) * B + b (the t column of coords and
+ *   the time field of keys), so every table / convolution entry point works unchanged when the SEARCHED table is built on
+ *   time offsets scaled by B.  3D branch: column 0 of the (n, 4) indices is the window (spconv's batch column), keys are
+ *   b * cells + (z*H + y)*W + x, rows are window-major.
+ * insmos_quantize4d_windows: points_host[b] / n_points_host[b] = device pointer / point count of window b (host arrays);
+ *   outputs as insmos_quantize4d_ex over the concatenation of the windows (window-major point index);
+ *   counts (5 + B int32): [0] voxels, [1] current points, [2] outside the key window, [3] outside the compact-key box,
+ *   [4 + b] first current point of window b in cur_index ([4 + B] = all).
+ * insmos_tslice_starts_batched: starts[d] = first row with floor(t' / B) >= tq_last - d. */
+int insmos_quantize4d_windows(const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
+                              const float* quant_host, uint64_t* keys, int32_t* coords, int32_t* inverse, int32_t* cur_index,
+                              int32_t* counts, void* ws, size_t ws_bytes, int compact_keys, void* stream);
+int insmos_build_current_points_windows(const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
+                                        const float* motion, int ld_motion, const int32_t* inverse, const int32_t* cur_index,
+                                        int64_t n_cur, float* cur, int ld_cur, void* stream);
+/* win_start (device, B + 1 int32): first point of each window in the window-major point array (null: one window).  Every
+ * window is voxelised in its own first-seen order and capped at max_voxels on its own (the reference calls VoxelGenerate
+ * per batch item, models/models.py:326); voxel rows are window-major, pc_voxel_id holds batch-wide rows.
+ * counts: [0] voxel rows, [1] occupied cells, [2] in-range points, with win_start also [4 + b] = first row of window b. */
+int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start, int B,
+                                 const float* range_host, const float* vsize_host, int max_voxels, int max_pts, float* feat,
+                                 int ld_feat, int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
+                                 int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+size_t insmos_down_coords3d_ws_bytes_b(const int32_t* out_shape_host, int B);
+int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host, const int32_t* stride_host,
+                           const int32_t* pad_host, const int32_t* out_shape_host, int B, uint64_t* out_keys,
+                           int32_t* out_coords, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+int insmos_dense_nbr2d_b(int H, int W, int B, int32_t* nbr, void* stream);            /* B images stacked along the rows */
+int insmos_sparse_to_bev_b(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D, int H, int W, int B,
+                           float* bev, void* stream);                                    /* bev (B, H, W, C*D) */
+/* head rows (B * H * W, ld_head); candidate arrays (B, pre_max, .); counts (B, 4): [b][0] kept, [b][1] above threshold */
+int insmos_center_decode_select_b(const float* head, int ld_head, int ncls, int H, int W, int up, int B, float out_factor,
+                                  float vx, float vy, float x0, float y0, float score_thresh, int pre_max, float* cand_boxes,
+                                  float* cand_scores, int32_t* cand_labels, int32_t* cand_cell, int32_t* counts, void* ws,
+                                  size_t ws_bytes, void* stream);
+size_t insmos_nms_ws_bytes_b(int max_n, int B);
+int insmos_nms_rotated_bev_b(const float* boxes, const int32_t* n_dev, int max_n, float thresh, int post_max, int B,
+                             int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+int insmos_gather_preds_b(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels, const int32_t* keep,
+                          const int32_t* n_keep_dev, int pre_max, int post_max, int B, float* pred_boxes, float* pred_scores,
+                          int64_t* pred_labels, void* stream);
+size_t insmos_boxes_to_onehot_scratch_ints_b(int max_boxes, int B, int64_t n);
+int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev, int max_boxes,
+                             int B, const float* range_lo_host, const float* vsize_host, float stride, float mult,
+                             const int32_t* coords, int64_t n, int ncls, int pad_to, int quirk_exact, float* out, int ld_out,
+                             int32_t* scratch, void* stream);
 int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int B, int32_t* starts, void* stream);
 /* Fused BEV deblock + heads (base_bev_backbone.py:104-115, center_head.py:65-72): x (n_site, cin) NHWC BEV features;
  * wd_packed / bd = the ConvTranspose2d(k=2,s=2)+BN as a 1x1 layer with 4*cup outputs laid out [ky][kx][co] (cup = 256);
@@ -448,12 +489,17 @@ typedef struct InsmosForwardOut {
     int64_t logits_off, boxes_off, scores_off, labels_off, arena_needed;
     int64_t cur_points_off; /* current_point (n_cur, 8) fp32 = [x, y, z, r, m0, m1, m2, 0] (motionnet.py:42-48): the motion
                                features the 'eval' mode's motion loss is taken on (models/models.py:321-323) */
+    int64_t batch;          /* windows that shared this launch set: me_voxels and unet_voxels[1..4] are totals of the batch */
 } InsmosForwardOut;
 int insmos_ctx_create(const InsmosNetCfg* cfg, const char* const* names, const InsmosConvW* layers, int n_layers,
                       void** ctx_out);
 int insmos_ctx_destroy(void* ctx);
 int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts, void* arena, size_t arena_bytes,
                           void* stream, InsmosForwardOut* out);
+/* The whole batch list of InsMOS_Model.forward in one launch set: points_host[b] (n_points_host[b], ld_pts) device arrays,
+ * outs[b] as above for window b (offsets into the shared arena).  B = 1 is insmos_forward_window. */
+int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
+                           void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs);
 
 #ifdef __cplusplus
 }

@@ -44,8 +44,23 @@ SIGNATURES = {
     "insmos_sparse_conv_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int,
                                         c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
-    "insmos_quantize4d_batched": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int,
-                                          c_vp]),
+    "insmos_quantize4d_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "insmos_build_current_points_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "insmos_voxelize_mean_windows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
+                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_down_coords3d_ws_bytes_b": (c_sz, [c_vp, c_int]),
+    "insmos_down_coords3d_b": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_dense_nbr2d_b": (c_int, [c_int, c_int, c_int, c_vp, c_vp]),
+    "insmos_sparse_to_bev_b": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "insmos_center_decode_select_b": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_f32, c_f32, c_f32, c_f32,
+                                              c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_nms_ws_bytes_b": (c_sz, [c_int, c_int]),
+    "insmos_nms_rotated_bev_b": (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_gather_preds_b": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_boxes_to_onehot_scratch_ints_b": (c_sz, [c_int, c_int, c_i64]),
+    "insmos_boxes_to_onehot_b": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
+                                         c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
@@ -114,7 +129,8 @@ class NetCfg(ctypes.Structure):  # InsmosNetCfg
 class ForwardOut(ctypes.Structure):  # InsmosForwardOut
     _fields_ = [("me_voxels", c_i64 * 4), ("n_cur", c_i64), ("unet_voxels", c_i64 * 5), ("n_candidates", c_i64),
                 ("n_boxes", c_i64), ("n_out_of_window", c_i64), ("logits_off", c_i64), ("boxes_off", c_i64),
-                ("scores_off", c_i64), ("labels_off", c_i64), ("arena_needed", c_i64), ("cur_points_off", c_i64)]
+                ("scores_off", c_i64), ("labels_off", c_i64), ("arena_needed", c_i64), ("cur_points_off", c_i64),
+                ("batch", c_i64)]
 
 _lib = None
 

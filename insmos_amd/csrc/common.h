@@ -108,6 +108,40 @@ __host__ __device__ __forceinline__ uint64_t key3_encode(int z, int y, int x, in
     return ((uint64_t)z * (uint64_t)H + (uint64_t)y) * (uint64_t)W + (uint64_t)x;
 }
 
+// 3D key with the spconv batch column: windows of one batch are stacked along a leading axis, key = b * cells + lin
+__host__ __device__ __forceinline__ uint64_t key3b_encode(int b, int z, int y, int x, int D, int H, int W) {
+    const uint64_t k = key3_encode(z, y, x, D, H, W);
+    return k == INSMOS_INVALID_KEY ? k : k + (uint64_t)b * ((uint64_t)D * (uint64_t)H * (uint64_t)W);
+}
+
+// ---- several windows in one launch set (docs/round2_batching_plan.md) ----------------------------------------------
+// The point clouds of the B windows of a batch stay where the caller has them: kernels that read points take this table
+// by value (kernel-argument memory: every access below is a wave-uniform scalar load) and locate a global point index
+// i in [0, start[B]) with a short select chain.
+#define INSMOS_MAX_BATCH 16
+struct WinPts {
+    const float* p[INSMOS_MAX_BATCH];
+    int64_t start[INSMOS_MAX_BATCH + 1];
+    int B;
+};
+__device__ __forceinline__ const float* win_point(const WinPts& W, int64_t i, int ld, int& b) {
+    const float* base = W.p[0];
+    int64_t s0 = 0;
+    b = 0;
+#pragma unroll
+    for (int q = 1; q < INSMOS_MAX_BATCH; ++q)
+        if (q < W.B && i >= W.start[q]) { b = q; base = W.p[q]; s0 = W.start[q]; }
+    return base + (i - s0) * ld;
+}
+// window of row i given B+1 ascending row starts in device memory (B <= INSMOS_MAX_BATCH; the loads are wave-uniform)
+__device__ __forceinline__ int win_of_row(const int32_t* __restrict__ starts, int B, int64_t i) {
+    int b = 0;
+    for (int q = 1; q < B; ++q)
+        if (i >= starts[q]) b = q;
+    return b;
+}
+int make_win_pts(const float* const* pts_host, const int64_t* n_pts_host, int B, WinPts* out, int64_t* total);
+
 // lower-bound binary search; returns position or -1
 __device__ __forceinline__ int64_t find_key(const uint64_t* __restrict__ keys, int64_t n, uint64_t key) {
     int64_t lo = 0, hi = n;

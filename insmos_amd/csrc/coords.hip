@@ -117,16 +117,17 @@ __host__ __device__ __forceinline__ uint64_t ckey_expand_b(uint64_t c, int B) {
 }
 
 template <bool COMPACT>
-__global__ void k_quant_keys_b(const float* __restrict__ pts, int64_t n, int ld, float q0, float q1, float q2, float q3,
-                               const int32_t* __restrict__ bid, int B, uint64_t* __restrict__ keys,
-                               uint32_t* __restrict__ idx, int32_t* __restrict__ tflag, int32_t* __restrict__ counts) {
+__global__ void k_quant_keys_b(WinPts W, int64_t n, int ld, float q0, float q1, float q2, float q3,
+                               uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int32_t* __restrict__ tflag,
+                               int32_t* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* p = pts + i * ld;
+    int b;
+    const float* p = win_point(W, i, ld, b);
+    const int B = W.B;
     float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;   // the same fp32 ops as k_quant_keys
     const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz), tq = (int)floorf(ft);
-    const int b = bid[i];
-    const bool t_ok = tq > -4096 && tq < 4096 && b >= 0 && b < B;           // t' must fit the 16-bit biased time field
+    const bool t_ok = tq > -2000 && tq < 2000;                              // t' must fit the 16-bit biased time field
     uint64_t k = t_ok ? key4_encode(x, y, z, tq * B + b) : INSMOS_INVALID_KEY;
     if (k == INSMOS_INVALID_KEY) atomicAdd(&counts[2], 1);
     if (COMPACT && k != INSMOS_INVALID_KEY) {
@@ -143,6 +144,18 @@ __global__ void k_quant_keys_b(const float* __restrict__ pts, int64_t n, int ld,
     keys[i] = k;
     idx[i] = (uint32_t)i;
     tflag[i] = (ft == 0.0f) ? 1 : 0;
+}
+
+// cur_start[b] = number of current-scan points (t == 0) in the windows before b: the inclusive scan of the t-flags read at
+// the window boundaries.  out[0 .. B] (out[B] = all of them)
+__global__ void k_cur_starts(WinPts W, const int32_t* __restrict__ tscan, int32_t* __restrict__ out) {
+    const int b = threadIdx.x;
+    if (b > W.B) return;
+    int64_t s = 0;
+#pragma unroll
+    for (int q = 1; q <= INSMOS_MAX_BATCH; ++q)
+        if (q == b) s = W.start[q];
+    out[b] = s > 0 ? tscan[s - 1] : 0;
 }
 
 template <bool COMPACT>
@@ -339,7 +352,7 @@ __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ o
     int32_t r = -1;
     if (ok) {
         uint64_t key = (KEY_MODE == 0) ? key4_encode(q[0], q[1], q[2], q[3])
-                                       : key3_encode(q[1], q[2], q[3], P.shape[0], P.shape[1], P.shape[2]);
+                                       : key3b_encode(q[0], q[1], q[2], q[3], P.shape[0], P.shape[1], P.shape[2]);
         if (key != INSMOS_INVALID_KEY) {
             int64_t pos = find_key(in_keys, n_in, key);
             if (pos >= 0) r = in_perm ? in_perm[pos] : (int32_t)pos;
@@ -357,11 +370,15 @@ __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ o
 // ---------------------------------------------------------------------------------------------------
 // 3D hard voxelisation + mean VFE (voxel_generate.py:19-28, mean_vfe.py:47-52)
 // ---------------------------------------------------------------------------------------------------
-#define VOX_IDX_BITS 21
+#define VOX_IDX_BITS 23
 
-__global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, float lx, float ly, float lz, float vx,
-                           float vy, float vz, int gx, int gy, int gz, uint64_t* __restrict__ keys,
-                           int64_t* __restrict__ pcid, int32_t* __restrict__ mark, int32_t* __restrict__ counts) {
+// Windows of a batch (B >= 1): points are window-major, win_start[0 .. B] (device) are the windows' first points; the
+// window index is the leading digit of the cell key (key = b * cells + lin), first-seen order and the voxel cap are PER
+// WINDOW, as the reference calls VoxelGenerate once per batch item (models/models.py:326).
+__global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, const int32_t* __restrict__ win_start, int B,
+                           float lx, float ly, float lz, float vx, float vy, float vz, int gx, int gy, int gz,
+                           uint64_t* __restrict__ keys, int64_t* __restrict__ pcid, int32_t* __restrict__ mark,
+                           int32_t* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = pts + i * ld;
@@ -370,7 +387,9 @@ __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, flo
     bool in = cx >= 0.f && cx < (float)gx && cy >= 0.f && cy < (float)gy && cz >= 0.f && cz < (float)gz;
     uint64_t k = INSMOS_INVALID_KEY;
     if (in) {
+        const uint64_t b = win_start ? (uint64_t)win_of_row(win_start, B, i) : 0ull;
         uint64_t lin = ((uint64_t)(int)cz * (uint64_t)gy + (uint64_t)(int)cy) * (uint64_t)gx + (uint64_t)(int)cx;
+        lin += b * ((uint64_t)gx * (uint64_t)gy * (uint64_t)gz);
         k = (lin << VOX_IDX_BITS) | (uint64_t)i;
         atomicAdd(&counts[2], 1);
     }
@@ -393,33 +412,55 @@ __global__ void k_vox_heads(const uint64_t* __restrict__ keys_s, const int32_t* 
     }
 }
 
+// per-window first-seen base ranks and voxel row starts (one small block):
+//   woff[b] = voxels first seen in the windows before b, woff[B+1+b] = first voxel ROW of window b (caps applied)
+__global__ void k_vox_offsets(const int32_t* __restrict__ win_start, int B, int64_t n, const int32_t* __restrict__ rank_scan,
+                              const int32_t* __restrict__ sid_scan, int max_voxels, int32_t* __restrict__ woff,
+                              int32_t* __restrict__ counts) {
+    if (threadIdx.x != 0) return;
+    int row = 0;
+    for (int b = 0; b <= B; ++b) {
+        const int64_t s = b == B ? n : (win_start ? (int64_t)win_start[b] : 0);
+        const int base = s > 0 ? rank_scan[s - 1] : 0;
+        woff[b] = base;
+        if (b > 0) {
+            const int seen = base - woff[b - 1];
+            row += seen < max_voxels ? seen : max_voxels;
+        }
+        woff[B + 1 + b] = row;
+        if (win_start) counts[4 + b] = row;
+    }
+    counts[0] = row;               // voxel rows kept
+    counts[1] = sid_scan[n - 1];   // occupied cells (search-structure entries, dropped ones included)
+}
+
 __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat, const uint64_t* __restrict__ keys_s,
                                const int32_t* __restrict__ sid_scan, int64_t n, const int32_t* __restrict__ seg_start,
                                const int32_t* __restrict__ seg_first, const int32_t* __restrict__ rank_scan,
-                               int gx, int gy, int max_voxels, int max_pts, float* __restrict__ feat, int ld_feat,
-                               int32_t* __restrict__ coords, int32_t* __restrict__ num_points,
-                               int64_t* __restrict__ pcid, uint64_t* __restrict__ ukeys, int32_t* __restrict__ uperm,
-                               int32_t* __restrict__ counts) {
+                               const int32_t* __restrict__ woff, int B, int gx, int gy, int gz, int max_voxels, int max_pts,
+                               float* __restrict__ feat, int ld_feat, int32_t* __restrict__ coords,
+                               int32_t* __restrict__ num_points, int64_t* __restrict__ pcid, uint64_t* __restrict__ ukeys,
+                               int32_t* __restrict__ uperm, const int32_t* __restrict__ counts) {
     int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int S = sid_scan[n - 1];
     int n_valid = counts[2];
-    if (sid == 0) {
-        counts[0] = S < max_voxels ? S : max_voxels;
-        counts[1] = S;
-    }
     if (sid >= S) return;
     int start = seg_start[sid];
     int end = (sid + 1 < S) ? seg_start[sid + 1] : n_valid;
-    int vid = rank_scan[seg_first[sid]] - 1;  // first-come order
-    uint64_t lin = keys_s[start] >> VOX_IDX_BITS;
+    uint64_t lin = keys_s[start] >> VOX_IDX_BITS;   // b * cells + cell
     ukeys[sid] = lin;
-    bool kept = vid < max_voxels;
+    const uint64_t cells = (uint64_t)gx * (uint64_t)gy * (uint64_t)gz;
+    const int b = (int)(lin / cells);
+    lin -= (uint64_t)b * cells;
+    const int local = rank_scan[seg_first[sid]] - 1 - woff[b];  // first-come order inside the window
+    const bool kept = local < max_voxels;
+    const int vid = woff[B + 1 + b] + local;
     uperm[sid] = kept ? vid : -1;
     if (kept) {
         int x = (int)(lin % (uint64_t)gx);
         int y = (int)((lin / (uint64_t)gx) % (uint64_t)gy);
         int z = (int)(lin / ((uint64_t)gx * (uint64_t)gy));
-        *(int4*)(coords + (int64_t)vid * 4) = make_int4(0, z, y, x);
+        *(int4*)(coords + (int64_t)vid * 4) = make_int4(b, z, y, x);
         int cnt = end - start;
         int m = cnt < max_pts ? cnt : max_pts;
         num_points[vid] = m;
@@ -446,7 +487,7 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
 // ---------------------------------------------------------------------------------------------------
 // strided SparseConv3d output coordinate set
 // ---------------------------------------------------------------------------------------------------
-struct DownParams { int ks[3], st[3], pd[3], oshape[3]; };
+struct DownParams { int ks[3], st[3], pd[3], oshape[3]; };   // (cells of a batch: window b owns bits [b*cells, (b+1)*cells))
 
 // mark every output cell some tap of some active input reaches, in an occupancy bitmap of the output grid
 __global__ void k_down_mark(const int32_t* __restrict__ in_coords, int64_t n_in, int K, DownParams P,
@@ -459,7 +500,7 @@ __global__ void k_down_mark(const int32_t* __restrict__ in_coords, int64_t n_in,
     int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
     int nz = c.y + P.pd[0] - kz, ny = c.z + P.pd[1] - ky, nx = c.w + P.pd[2] - kx;
     if (nz >= 0 && ny >= 0 && nx >= 0 && nz % P.st[0] == 0 && ny % P.st[1] == 0 && nx % P.st[2] == 0) {
-        uint64_t key = key3_encode(nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
+        uint64_t key = key3b_encode(c.x, nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
         if (key != INSMOS_INVALID_KEY) atomicOr(&bitmap[key >> 5], 1u << (unsigned)(key & 31));
     }
 }
@@ -469,7 +510,7 @@ __global__ void k_word_popc(const uint32_t* __restrict__ bitmap, int64_t nwords,
 }
 // ascending linear order falls out of the bitmap: row of a cell = (#set bits in lower words) + rank inside its word
 __global__ void k_down_expand(const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ scan, int64_t nwords,
-                              int H, int W, int64_t cap, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                              int D, int H, int W, int64_t cap, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
                               int32_t* __restrict__ counts) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
@@ -481,8 +522,9 @@ __global__ void k_down_expand(const uint32_t* __restrict__ bitmap, const int32_t
         if (base < cap) {
             uint64_t k = (uint64_t)w * 32 + b;
             okeys[base] = k;
-            int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(k / ((uint64_t)W * H));
-            *(int4*)(ocoords + (int64_t)base * 4) = make_int4(0, z, y, x);
+            const uint64_t zz = k / ((uint64_t)W * H);   // b * D + z
+            int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(zz % (uint64_t)D);
+            *(int4*)(ocoords + (int64_t)base * 4) = make_int4((int)(zz / (uint64_t)D), z, y, x);
         }
         ++base;
     }
@@ -688,13 +730,36 @@ extern "C" int insmos_quantize4d_ex(const float* points, int64_t n, int ld_pts, 
     return INSMOS_OK;
 }
 
-// Several windows in one coordinate set: bid[i] = window of point i (0 .. B-1), see k_quant_keys_b.  Same outputs as
-// insmos_quantize4d_ex; the t column of `coords` and the time field of `keys` hold t' = floor(t / dt) * B + b.
-extern "C" int insmos_quantize4d_batched(const float* points, int64_t n, int ld_pts, const float* quant_host,
-                                         const int32_t* bid, int B, uint64_t* keys, int32_t* coords, int32_t* inverse,
+int insmos::make_win_pts(const float* const* pts_host, const int64_t* n_pts_host, int B, WinPts* out, int64_t* total) {
+    if (!pts_host || !n_pts_host || B < 1 || B > INSMOS_MAX_BATCH) return INSMOS_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->B = B;
+    int64_t acc = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!pts_host[b] || n_pts_host[b] <= 0) return INSMOS_EINVAL;
+        out->p[b] = pts_host[b];
+        out->start[b] = acc;
+        acc += n_pts_host[b];
+    }
+    for (int b = B; b <= INSMOS_MAX_BATCH; ++b) out->start[b] = acc;
+    *total = acc;
+    return INSMOS_OK;
+}
+
+// B windows in one coordinate set (k_quant_keys_b): pts_host[b] / n_pts_host[b] = device pointer and point count of window
+// b (same leading dimension).  Outputs as insmos_quantize4d_ex over the concatenation of the windows' points (window-major
+// point index); the t column of `coords` and the time field of `keys` hold t' = floor(t / dt) * B + b.
+// counts: [0] voxels, [1] current points, [2] outside the key window, [3] outside the compact-key box, [4 .. 4+B] start
+// of each window's current points in `cur_index` ([4+B] = all of them): 5 + B int32 slots.
+extern "C" int insmos_quantize4d_windows(const float* const* pts_host, const int64_t* n_pts_host, int B, int ld_pts,
+                                         const float* quant_host, uint64_t* keys, int32_t* coords, int32_t* inverse,
                                          int32_t* cur_index, int32_t* counts, void* ws, size_t ws_bytes, int compact_keys,
                                          void* stream) {
-    if (n <= 0 || ld_pts < 5 || !points || !quant_host || !bid || B < 1 || B > 64) return INSMOS_EINVAL;
+    WinPts W;
+    int64_t n = 0;
+    int rc = make_win_pts(pts_host, n_pts_host, B, &W, &n);
+    if (rc) return rc;
+    if (n >= (1ll << 31) || ld_pts < 5 || !quant_host) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     Bump b(ws, ws_bytes);
     size_t N = (size_t)n;
@@ -715,14 +780,14 @@ extern "C" int insmos_quantize4d_batched(const float* points, int64_t n, int ld_
     {
         ProfScope ps(KK_QUANT_KEYS, s);
         if (compact_keys)
-            INSMOS_LAUNCH(k_quant_keys_b<true>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
-                          quant_host[2], quant_host[3], bid, B, k_in, i_in, tflag, counts);
+            INSMOS_LAUNCH(k_quant_keys_b<true>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
         else
-            INSMOS_LAUNCH(k_quant_keys_b<false>, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, quant_host[0], quant_host[1],
-                          quant_host[2], quant_host[3], bid, B, k_in, i_in, tflag, counts);
+            INSMOS_LAUNCH(k_quant_keys_b<false>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
+                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
     }
     const int end_bit = compact_keys ? 36 + bits_for((uint64_t)(16 * B - 1)) : 64;
-    int rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, end_bit, s);
+    rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, end_bit, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
@@ -744,6 +809,7 @@ extern "C" int insmos_quantize4d_batched(const float* points, int64_t n, int ld_
     {
         ProfScope ps(KK_QUANT_SCATTER, s);
         INSMOS_LAUNCH(k_compact_index, dim3(g), dim3(TPB), 0, s, tflag, tscan, n, cur_index, counts + 1);
+        INSMOS_LAUNCH(k_cur_starts, dim3(1), dim3(64), 0, s, W, tscan, counts + 4);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -831,22 +897,28 @@ extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const 
 extern "C" size_t insmos_voxelize_mean_ws_bytes(int64_t n) {
     size_t N = (size_t)n;
     size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
-    return pad256(N * 8) * 2 + pad256((N + 1) * 4) * 6 + (st > sc ? st : sc) + 1024;
+    return pad256(N * 8) * 2 + pad256((N + 1) * 4) * 6 + (st > sc ? st : sc) + 2048;
 }
 
-extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, int n_feat, const float* range_host,
-                                    const float* vsize_host, int max_voxels, int max_pts, float* feat, int ld_feat,
-                                    int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
-                                    int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+// win_start (device, B + 1 int32, or null for one window): first point of each window in the window-major point array.
+// Voxel rows are window-major: window b owns rows [counts[4+b], counts[4+b+1]), each window in its own first-seen order and
+// capped at max_voxels on its own; coords column 0 = b; pc_voxel_id holds batch-wide rows; ukeys = b * cells + cell.
+// counts: [0] voxel rows, [1] occupied cells, [2] in-range points, and when win_start is given [4 .. 4+B] row starts
+// (5 + B int32 slots).
+extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start,
+                                            int B, const float* range_host, const float* vsize_host, int max_voxels,
+                                            int max_pts, float* feat, int ld_feat, int32_t* coords, int32_t* num_points,
+                                            int64_t* pc_voxel_id, uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws,
+                                            size_t ws_bytes, void* stream) {
     if (n <= 0 || n >= (1ll << VOX_IDX_BITS) || n_feat < 3 || n_feat > 8 || ld_pts < n_feat || ld_feat < n_feat ||
-        max_voxels <= 0 || max_pts <= 0)
+        max_voxels <= 0 || max_pts <= 0 || B < 1 || B > INSMOS_MAX_BATCH || (B > 1 && !win_start))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // grid = round((hi - lo) / vsize), as models.py:281-282 / spconv compute it (float64 on the host)
     int g3[3];
     for (int d = 0; d < 3; ++d)
         g3[d] = (int)llround(((double)range_host[3 + d] - (double)range_host[d]) / (double)vsize_host[d]);
-    uint64_t max_lin = (uint64_t)g3[0] * g3[1] * g3[2];
+    uint64_t max_lin = (uint64_t)g3[0] * g3[1] * g3[2] * (uint64_t)B;
     int end_bit = VOX_IDX_BITS + bits_for(max_lin);
     if (end_bit > 63) return INSMOS_EINVAL;
     Bump b(ws, ws_bytes);
@@ -859,6 +931,7 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     int32_t* rank_scan = b.take<int32_t>(N + 1);
     int32_t* seg_start = b.take<int32_t>(N + 1);
     int32_t* seg_first = b.take<int32_t>(N + 1);
+    int32_t* woff = b.take<int32_t>(2 * (INSMOS_MAX_BATCH + 1));
     size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
     char* tmp = b.take<char>(st > sc ? st : sc);
     if (!b.ok) return INSMOS_EWORKSPACE;
@@ -866,9 +939,9 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_VOX_KEYS, s);
-        INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, range_host[0], range_host[1],
-                           range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1], g3[2], k_in,
-                           pc_voxel_id, mark, counts);
+        INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, win_start, B,
+                      range_host[0], range_host[1], range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1],
+                      g3[2], k_in, pc_voxel_id, mark, counts);
     }
     // invalid keys are all-ones; they must sort last, so sort the full 64 bits when any may exist
     int rc = sort_keys_u64(tmp, st, k_in, k_s, N, 0, 64, s);
@@ -887,24 +960,40 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_MEAN, s);
+        INSMOS_LAUNCH(k_vox_offsets, dim3(1), dim3(64), 0, s, win_start, B, n, rank_scan, sid_scan,
+                      max_voxels, woff, counts);
         INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
-                           seg_first, rank_scan, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords, num_points,
-                           pc_voxel_id, ukeys, uperm, counts);
+                      seg_first, rank_scan, woff, B, g3[0], g3[1], g3[2], max_voxels, max_pts, feat, ld_feat, coords,
+                      num_points, pc_voxel_id, ukeys, uperm, counts);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
 
-extern "C" size_t insmos_down_coords3d_ws_bytes(const int32_t* out_shape_host) {
-    size_t nwords = ((size_t)out_shape_host[0] * out_shape_host[1] * out_shape_host[2] + 31) / 32;
-    return pad256(nwords * 4) * 3 + scan_i32_temp(nwords) + 1024;
+// one window (the reference's single VoxelGenerate call): counts = 4 int32 slots ([0] voxels, [1] cells, [2] points)
+extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, int n_feat, const float* range_host,
+                                    const float* vsize_host, int max_voxels, int max_pts, float* feat, int ld_feat,
+                                    int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
+                                    int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    return insmos_voxelize_mean_windows(points, n, ld_pts, n_feat, nullptr, 1, range_host, vsize_host, max_voxels, max_pts, feat,
+                                        ld_feat, coords, num_points, pc_voxel_id, ukeys, uperm, counts, ws, ws_bytes, stream);
 }
 
-extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
-                                    const int32_t* stride_host, const int32_t* pad_host,
-                                    const int32_t* out_shape_host, uint64_t* out_keys, int32_t* out_coords,
-                                    int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
-    if (n_in <= 0) return INSMOS_EINVAL;
+extern "C" size_t insmos_down_coords3d_ws_bytes_b(const int32_t* out_shape_host, int B) {
+    size_t nwords = ((size_t)out_shape_host[0] * out_shape_host[1] * out_shape_host[2] * (size_t)(B < 1 ? 1 : B) + 31) / 32;
+    return pad256(nwords * 4) * 3 + scan_i32_temp(nwords) + 1024;
+}
+extern "C" size_t insmos_down_coords3d_ws_bytes(const int32_t* out_shape_host) {
+    return insmos_down_coords3d_ws_bytes_b(out_shape_host, 1);
+}
+
+// B windows stacked along the batch column of the indices (in_coords[:, 0] in [0, B)): one occupancy bitmap of
+// B * cells bits, rows come out in ascending (b, z, y, x) order -- window-major, each window exactly as it comes out alone.
+extern "C" int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
+                                      const int32_t* stride_host, const int32_t* pad_host, const int32_t* out_shape_host,
+                                      int B, uint64_t* out_keys, int32_t* out_coords, int32_t* counts, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    if (n_in <= 0 || B < 1 || B > INSMOS_MAX_BATCH) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     DownParams P;
     int K = 1;
@@ -912,7 +1001,7 @@ extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, cons
         P.ks[d] = ksize_host[d]; P.st[d] = stride_host[d]; P.pd[d] = pad_host[d]; P.oshape[d] = out_shape_host[d];
         K *= ksize_host[d];
     }
-    const int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2];
+    const int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2] * B;
     if (cells <= 0 || cells >= (1ll << 36)) return INSMOS_EINVAL;
     const int64_t N = n_in * K;
     const int64_t cap = N < cells ? N : cells;
@@ -934,11 +1023,19 @@ extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, cons
     if (rc) return rc;
     {
         ProfScope ps(KK_DOWN_UNIQUE, s);
-        INSMOS_LAUNCH(k_down_expand, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, scan, nwords, P.oshape[1],
+        INSMOS_LAUNCH(k_down_expand, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, scan, nwords, P.oshape[0], P.oshape[1],
                            P.oshape[2], cap, out_keys, out_coords, counts);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
+                                    const int32_t* stride_host, const int32_t* pad_host,
+                                    const int32_t* out_shape_host, uint64_t* out_keys, int32_t* out_coords,
+                                    int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    return insmos_down_coords3d_b(in_coords, n_in, ksize_host, stride_host, pad_host, out_shape_host, 1, out_keys, out_coords,
+                                  counts, ws, ws_bytes, stream);
 }
 
 extern "C" int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,

@@ -1,7 +1,11 @@
-// insmos_amd/csrc/forward.hip -- native host orchestration of ONE InsMOS window (InsMOS_Model.forward, 'test'):
-// the same sequence of C-ABI operator calls insmos_amd/engine.py issues step by step, driven from C++ so that a
-// window costs ONE foreign call (no interpreter work, no GIL) and several windows can be in flight on different
-// HIP streams from different host threads.  Layer order and channel widths follow the reference modules
+// insmos_amd/csrc/forward.hip -- native host orchestration of the InsMOS forward (InsMOS_Model.forward, 'test') for a
+// BATCH of B windows in ONE set of launches: the same sequence of C-ABI operator calls insmos_amd/engine.py issues step
+// by step for one window, driven from C++ so that a batch costs ONE foreign call (no interpreter work, no GIL).
+// Where the reference walks its batch list window by window (models/models.py:313), here the B windows share every
+// launch: in the 4D branch the window index is folded into the time coordinate (t' = t * B + b: time has no bounds and
+// no striding, so windows never meet and the rows of the newest scans of ALL windows stay one suffix), in the 3D branch
+// it is spconv's batch column, the BEV images are stacked along the row axis, and the head / NMS / instance kernels
+// run over a (window, .) grid.  Every window gets exactly the bits it gets alone (tests/test_gpu_batched.py).  Layer order and channel widths follow the reference modules
 // (models/backbones_3d/motionnet.py:21-50, models/MinkowskiEngine/minkunet.py:139-181,
 // models/backbones_3d/spconv_unet.py:267-416, models/backbones_2d/*.py, models/post_process.py:112-224);
 // insmos_amd/engine.py carries the same graph in inspectable form and tests/test_gpu_model.py asserts that both
@@ -105,13 +109,20 @@ extern "C" int insmos_ctx_destroy(void* ctx) {
     return INSMOS_OK;
 }
 
-extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int ld, void* arena, size_t arena_bytes,
-                                     void* stream, InsmosForwardOut* out) {
-    if (!ctx || !pts || N <= 0 || ld < 5 || !arena || !out) return INSMOS_EINVAL;
+static int forward_windows_impl(void* ctx, const float* const* pts_host, const int64_t* n_pts_host, int B, int ld,
+                                void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs) {
+    if (!ctx || !pts_host || !n_pts_host || B < 1 || B > INSMOS_MAX_BATCH || ld < 5 || !arena || !outs) return INSMOS_EINVAL;
+    int64_t N = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!pts_host[b] || n_pts_host[b] <= 0) return INSMOS_EINVAL;
+        N += n_pts_host[b];
+    }
     const Ctx& C = *(const Ctx*)ctx;
     const InsmosNetCfg& g = C.cfg;
     hipStream_t s = (hipStream_t)stream;
-    memset(out, 0, sizeof(*out));
+    memset(outs, 0, sizeof(*outs) * (size_t)B);
+    InsmosForwardOut* out = outs;  // batch-wide figures and error details go to the first entry
+    for (int b = 0; b < B; ++b) outs[b].batch = B;
     Arena A{(char*)arena, arena_bytes};
     auto Lr = [&](const std::string& name) -> const InsmosConvW* {
         auto it = C.L.find(name);
@@ -137,8 +148,8 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         t.n = n;
         return t;
     };
-    int32_t hc[4];
-    int32_t* counts = A.take<int32_t>(4);
+    int32_t hc[8 + INSMOS_MAX_BATCH];
+    int32_t* counts = A.take<int32_t>(8 + INSMOS_MAX_BATCH);
     NEED_ARENA();
 
     // =============================== MotionNet (4D) ===============================
@@ -157,21 +168,31 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
         const float quant[4] = {g.vs[0], g.vs[0], g.vs[0], g.dt};
-        // 40-bit sort keys first; the full-width sort only for windows wider than +-2048 voxels / 16 time steps
-        CK(insmos_quantize4d_ex(pts, N, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb, 1, s));
-        CK(read_counts(counts, hc, 4, s));
+        // compact sort keys first; the full-width sort only for windows wider than +-2048 voxels / 16 time steps
+        CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb,
+                                     1, s));
+        CK(read_counts(counts, hc, 5 + B, s));
         if (hc[3] != 0) {
-            CK(insmos_quantize4d_ex(pts, N, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb, 0, s));
-            CK(read_counts(counts, hc, 4, s));
+            CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws,
+                                         wsb, 0, s));
+            CK(read_counts(counts, hc, 5 + B, s));
         }
         A.off = mark;  // the sort workspace is dead once the counts are back
     }
     n[0] = hc[0];
     const int64_t ncur = hc[1];
+    int64_t cur_start[INSMOS_MAX_BATCH + 1];
+    for (int b = 0; b <= B; ++b) cur_start[b] = hc[4 + b];
+    for (int b = 0; b < B; ++b) outs[b].n_cur = cur_start[b + 1] - cur_start[b];
+    // the windows' current-point starts stay on the device for the voxeliser (the counts slots are reused below)
+    int32_t* cur_start_dev = A.take<int32_t>(INSMOS_MAX_BATCH + 1);
+    NEED_ARENA();
+    HIP_TRY(hipMemcpyAsync(cur_start_dev, counts + 4, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if (hc[2] != 0) { out->n_out_of_window = hc[2]; return INSMOS_EINVAL; }
     out->me_voxels[0] = n[0];
-    out->n_cur = ncur;
-    if (ncur == 0 || n[0] == 0) return INSMOS_EINVAL;  // (the caller tells the two apart by the counts above)
+    if (n[0] == 0) return INSMOS_EINVAL;
+    for (int b = 0; b < B; ++b)
+        if (outs[b].n_cur == 0) return INSMOS_EINVAL;  // (a window without t == 0 points; the caller reads n_cur)
     for (int l = 1; l <= 3; ++l) {
         const int64_t np = n[l - 1];
         keys[l] = A.take<uint64_t>(np);
@@ -189,15 +210,15 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         A.off = mark;
         n[l] = hc[0];
     }
-    for (int l = 0; l < 4; ++l) out->me_voxels[l] = n[l];
-    out->n_cur = ncur;
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < 4; ++l) outs[b].me_voxels[l] = n[l];  // batch totals
     // Dead-row elimination (same as Engine.motionnet): starts[l][d] = first level-l row with
     // t >= t_last - d; a layer whose output is needed d scans back computes rows [starts[l][d], n[l]) only.
     int32_t starts[4][16];
     {
         int32_t* sd = A.take<int32_t>(64);
         NEED_ARENA();
-        for (int l = 0; l < 4; ++l) CK(insmos_tslice_starts(keys[l], n[l], 16, sd + 16 * l, s));
+        for (int l = 0; l < 4; ++l) CK(insmos_tslice_starts_batched(keys[l], n[l], 16, B, sd + 16 * l, s));
         CK(read_counts(sd, &starts[0][0], 64, s));
     }
     auto row_from = [&](int l, int d) -> int64_t { return d < 16 ? starts[l][d] : 0; };
@@ -208,7 +229,10 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     NEED_ARENA();
     {
         const int32_t one[4] = {1, 1, 1, 1};
-        CK(insmos_build_nbr(coords[3], n[3], keys[3], nullptr, n[3], 0, nullptr, C.off81[3].data(), 81, one, one, nbr81[3].nbr,
+        // the only arithmetic on t in the whole branch: the searched table's time offsets move by B (t' = t * B + b)
+        std::vector<int32_t> off = C.off81[3];
+        for (size_t k = 0; k < off.size() / 4; ++k) off[4 * k + 3] *= B;
+        CK(insmos_build_nbr(coords[3], n[3], keys[3], nullptr, n[3], 0, nullptr, off.data(), 81, one, one, nbr81[3].nbr,
                             nbr81[3].mask, s));
     }
     for (int l = 2; l >= 0; --l) {
@@ -274,11 +298,11 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     CK(conv("convtr7p2s2", b7, n[1], 16, 0, &up[0], n[0], cat8, 16, 0, nullptr, 0, 0, 0, 0, 1, row_from(0, 2)));
     CK(block("block8.0", cat8, n[0], 16, 0, &nbr81[0], 8, b8, 8, 0, 0, 0));
     CK(conv("final", b8, n[0], 8, 0, nullptr, n[0], motion, 4, 0, nullptr, 0, 0, 0, 0, 0, row_from(0, 0)));
-    CK(insmos_build_current_points(pts, ld, motion, 4, inverse, cur_index, ncur, cur, 8, s));
+    CK(insmos_build_current_points_windows(pts_host, n_pts_host, B, ld, motion, 4, inverse, cur_index, ncur, cur, 8, s));
 
     // =============================== UNetV2 (3D) ===============================
     const int ncls = g.ncls;
-    const int64_t Vcap = g.max_voxels;
+    const int64_t Vcap = (int64_t)g.max_voxels * B;
     float* feat = A.take<float>(Vcap * 8);
     int32_t* coords1 = A.take<int32_t>(Vcap * 4);
     int32_t* num_points = A.take<int32_t>(Vcap);
@@ -290,11 +314,12 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         const size_t mark = A.off;
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
-        CK(insmos_voxelize_mean(cur, ncur, 8, g.in_ch, g.range, g.vs, g.max_voxels, g.max_points, feat, 8, coords1, num_points,
-                                pcid, ukeys, uperm, counts, ws, wsb, s));
-        CK(read_counts(counts, hc, 2, s));
+        CK(insmos_voxelize_mean_windows(cur, ncur, 8, g.in_ch, cur_start_dev, B, g.range, g.vs, g.max_voxels, g.max_points, feat,
+                                        8, coords1, num_points, pcid, ukeys, uperm, counts, ws, wsb, s));
+        CK(read_counts(counts, hc, 5 + B, s));
         A.off = mark;
     }
+    for (int b = 0; b < B; ++b) outs[b].unet_voxels[0] = hc[4 + b + 1] - hc[4 + b];
     int64_t nv[6] = {0}, nkeys[6] = {0};
     const int32_t* co[6] = {nullptr};
     const uint64_t* ky[6] = {nullptr};
@@ -308,7 +333,7 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
                            int lvl_out) -> int {
         const int64_t n_in = nv[lvl_in];
         const int64_t K = (int64_t)ks[0] * ks[1] * ks[2];
-        const int64_t cells = (int64_t)oshape[0] * oshape[1] * oshape[2];
+        const int64_t cells = (int64_t)oshape[0] * oshape[1] * oshape[2] * B;
         const int64_t cap = std::max<int64_t>(std::min(n_in * K, cells), 1);
         uint64_t* ok = A.take<uint64_t>(cap);
         int32_t* oc = A.take<int32_t>(cap * 4);
@@ -316,11 +341,11 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         ky[lvl_out] = ok;
         pm[lvl_out] = nullptr;
         if (n_in == 0) { nv[lvl_out] = nkeys[lvl_out] = 0; NEED_ARENA(); return INSMOS_OK; }
-        const size_t wsb = insmos_down_coords3d_ws_bytes(oshape);
+        const size_t wsb = insmos_down_coords3d_ws_bytes_b(oshape, B);
         const size_t mark = A.off;
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
-        CK(insmos_down_coords3d(co[lvl_in], n_in, ks, st, pd, oshape, ok, oc, counts, ws, wsb, s));
+        CK(insmos_down_coords3d_b(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
         CK(read_counts(counts, hc, 1, s));
         A.off = mark;
         nv[lvl_out] = nkeys[lvl_out] = hc[0];
@@ -332,7 +357,8 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         const int32_t k311[3] = {3, 1, 1}, s211[3] = {2, 1, 1}, p000[3] = {0, 0, 0};
         CK(down_coords(4, k311, s211, p000, g.shape[5], 5));
     }
-    for (int l = 1; l <= 5; ++l) out->unet_voxels[l - 1] = nv[l];
+    for (int b = 0; b < B; ++b)
+        for (int l = (B == 1 ? 1 : 2); l <= 5; ++l) outs[b].unet_voxels[l - 1] = nv[l];  // levels 2..5: batch totals
     const int64_t V = nv[1];
     auto build = [&](Table& t, int lvl_out, int lvl_in, const std::vector<int32_t>& delta, const int32_t* mul,
                      const int32_t* div) -> int {
@@ -377,7 +403,7 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     CK(conv("conv_out.0", xc[4], nv[4], 128, 0, &down5, nv[5], enc, 128, 0, nullptr, 0, 0, 0, 0, 1));
 
     // ---- BEV detection head in NHWC (height_compression.py:24-31, base_bev_backbone.py:84-115)
-    const int64_t nsite = (int64_t)g.bevH * g.bevW;
+    const int64_t nsite = (int64_t)g.bevH * g.bevW * B;  // B images stacked along the row axis
     const InsmosConvW* wb0 = Lr("bev0");
     if (!wb0 || !g.nbr_bev) return INSMOS_EINVAL;
     const int nf = wb0->cout;
@@ -388,19 +414,21 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     float* upf = A.take<float>(nsite * 4 * upc);  // rows [y][x], columns [ky][kx][co] == (4*nsite, upc) sub-site rows
     const int64_t ncell = 4 * nsite;
     float* head = A.take<float>(ncell * g.head_ld);
-    float* cb = A.take<float>((size_t)g.pre_max * 7);
-    float* cs = A.take<float>(g.pre_max);
-    int32_t* cl = A.take<int32_t>(g.pre_max);
-    int32_t* cc = A.take<int32_t>(g.pre_max);
-    int32_t* cnt_c = A.take<int32_t>(4);
-    int32_t* keep = A.take<int32_t>(g.post_max);
-    int32_t* cnt_k = A.take<int32_t>(4);
-    float* pb = A.take<float>((size_t)g.post_max * 7);
-    float* psc = A.take<float>(g.post_max);
-    int64_t* pl = A.take<int64_t>(g.post_max);
+    float* cb = A.take<float>((size_t)g.pre_max * 7 * B);   // candidate / prediction arrays: (B, max, .)
+    float* cs = A.take<float>((size_t)g.pre_max * B);
+    int32_t* cl = A.take<int32_t>((size_t)g.pre_max * B);
+    int32_t* cc = A.take<int32_t>((size_t)g.pre_max * B);
+    int32_t* cnt_c = A.take<int32_t>(4 * B);
+    int32_t* keep = A.take<int32_t>((size_t)g.post_max * B);
+    int32_t* cnt_k = A.take<int32_t>(4 * B);
+    float* pb = A.take<float>((size_t)g.post_max * 7 * B);
+    float* psc = A.take<float>((size_t)g.post_max * B);
+    int64_t* pl = A.take<int64_t>((size_t)g.post_max * B);
+    int32_t* nbr_bev_b = B > 1 ? A.take<int32_t>((size_t)9 * nsite) : nullptr;
     NEED_ARENA();
-    CK(insmos_sparse_to_bev(enc, 128, 128, co[5], nv[5], g.bevD, g.bevH, g.bevW, bev, s));
-    Table tb{const_cast<int32_t*>(g.nbr_bev), nullptr, 9, nsite};
+    CK(insmos_sparse_to_bev_b(enc, 128, 128, co[5], nv[5], g.bevD, g.bevH, g.bevW, B, bev, s));
+    if (B > 1) CK(insmos_dense_nbr2d_b(g.bevH, g.bevW, B, nbr_bev_b, s));
+    Table tb{B > 1 ? nbr_bev_b : const_cast<int32_t*>(g.nbr_bev), nullptr, 9, nsite};
     CK(conv("bev0", bev, nsite, g.nbev, 0, &tb, nsite, fa, nf, 0, nullptr, 0, 0, 0, 0, 1));
     for (int k = 0; k < g.n_bev_layers; ++k) {
         CK(conv(("bev" + std::to_string(k + 1)).c_str(), fa, nsite, nf, 0, &tb, nsite, fb, nf, 0, nullptr, 0, 0, 0, 0, 1));
@@ -423,25 +451,25 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
         const size_t mark = A.off;
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
-        CK(insmos_center_decode_select(head, g.head_ld, ncls, 2 * g.bevH, 2 * g.bevW, 2, g.out_factor, g.tvs[0], g.tvs[1],
-                                       g.range[0], g.range[1], g.score_thresh, g.pre_max, cb, cs, cl, cc, cnt_c, ws, wsb, s));
+        CK(insmos_center_decode_select_b(head, g.head_ld, ncls, 2 * g.bevH, 2 * g.bevW, 2, B, g.out_factor, g.tvs[0], g.tvs[1],
+                                         g.range[0], g.range[1], g.score_thresh, g.pre_max, cb, cs, cl, cc, cnt_c, ws, wsb, s));
         A.off = mark;
-        const size_t wsn = insmos_nms_ws_bytes(g.pre_max);
+        const size_t wsn = insmos_nms_ws_bytes_b(g.pre_max, B);
         ws = A.take<char>(wsn);
         NEED_ARENA();
-        CK(insmos_nms_rotated_bev(cb, cnt_c, g.pre_max, g.nms_thresh, g.post_max, keep, cnt_k, ws, wsn, s));
+        CK(insmos_nms_rotated_bev_b(cb, cnt_c, g.pre_max, g.nms_thresh, g.post_max, B, keep, cnt_k, ws, wsn, s));
         // (the NMS workspace stays allocated: kernels below are stream-ordered after it, but keep it simple)
     }
-    CK(insmos_gather_preds(cb, cs, cl, keep, cnt_k, g.post_max, pb, psc, pl, s));
+    CK(insmos_gather_preds_b(cb, cs, cl, keep, cnt_k, g.pre_max, g.post_max, B, pb, psc, pl, s));
 
     // ---- upsample fusion (spconv_unet.py:319-402)
     int64_t nvmax = 0;
     for (int l = 1; l <= 5; ++l) nvmax = std::max(nvmax, nv[l]);
-    int32_t* scratch = A.take<int32_t>(insmos_boxes_to_onehot_scratch_ints(g.post_max, nvmax));
+    int32_t* scratch = A.take<int32_t>(insmos_boxes_to_onehot_scratch_ints_b(g.post_max, B, nvmax));
     auto onehot = [&](int level, float mult, float* o, int ldo, int col) -> int {
         if (nv[level] == 0) return INSMOS_OK;
-        return insmos_boxes_to_onehot(pb, pl, cnt_k, g.post_max, g.range, g.vs, 8.0f, mult, co[level], nv[level], ncls, 16,
-                                      g.quirk_exact, o + col, ldo, scratch, s);
+        return insmos_boxes_to_onehot_b(pb, pl, cnt_k, g.post_max, B, g.range, g.vs, 8.0f, mult, co[level], nv[level], ncls, 16,
+                                        g.quirk_exact, o + col, ldo, scratch, s);
     };
     // UR_block_forward up to (not including) conv_inv; catm[:, 0:C] already holds x_bottom
     auto ur_block = [&](int lvl, int Cc, const float* x_lat, int ld_lat, float* catm, float* m) -> int {
@@ -492,20 +520,35 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
     CK(conv("conv_up_instance_block_up1.0", ci0, V, 32, 0, &subm[1], V, seg, 16, 0, nullptr, 0, 0, 0, 0, 1));
     CK(conv("mos_seg", seg, V, 16, 0, nullptr, V, vox_logits, 4, 0, nullptr, 0, 0, 0, 0, 0));
     CK(insmos_gather_rows(vox_logits, 4, 3, pcid, ncur, logits, 3, s));
-    // the one unavoidable read-back: the caller's output tensors are sized by the box count
+    // the one unavoidable read-back: the caller's output tensors are sized by the box counts
     {
-        int32_t h2[2];
-        HIP_TRY(hipMemcpyAsync(&h2[0], cnt_k, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&h2[1], cnt_c, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        int32_t hk[4 * INSMOS_MAX_BATCH], hcand[4 * INSMOS_MAX_BATCH];
+        HIP_TRY(hipMemcpyAsync(hk, cnt_k, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hcand, cnt_c, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        out->n_boxes = h2[0];
-        out->n_candidates = h2[1];
+        for (int b = 0; b < B; ++b) {
+            outs[b].n_boxes = hk[4 * b];
+            outs[b].n_candidates = hcand[4 * b];
+        }
     }
-    out->logits_off = (int64_t)((char*)logits - (char*)arena);
-    out->boxes_off = (int64_t)((char*)pb - (char*)arena);
-    out->scores_off = (int64_t)((char*)psc - (char*)arena);
-    out->labels_off = (int64_t)((char*)pl - (char*)arena);
-    out->arena_needed = (int64_t)A.off;
-    out->cur_points_off = (int64_t)((char*)cur - (char*)arena);
+    for (int b = 0; b < B; ++b) {
+        InsmosForwardOut& o = outs[b];
+        o.logits_off = (int64_t)((char*)(logits + cur_start[b] * 3) - (char*)arena);
+        o.boxes_off = (int64_t)((char*)(pb + (size_t)b * g.post_max * 7) - (char*)arena);
+        o.scores_off = (int64_t)((char*)(psc + (size_t)b * g.post_max) - (char*)arena);
+        o.labels_off = (int64_t)((char*)(pl + (size_t)b * g.post_max) - (char*)arena);
+        o.cur_points_off = (int64_t)((char*)(cur + cur_start[b] * 8) - (char*)arena);
+        o.arena_needed = (int64_t)A.off;
+    }
     return INSMOS_OK;
+}
+
+extern "C" int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B,
+                                      int ld_pts, void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs) {
+    return forward_windows_impl(ctx, points_host, n_points_host, B, ld_pts, arena, arena_bytes, stream, outs);
+}
+
+extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int ld, void* arena, size_t arena_bytes,
+                                     void* stream, InsmosForwardOut* out) {
+    return forward_windows_impl(ctx, &pts, &N, 1, ld, arena, arena_bytes, stream, out);
 }

@@ -25,11 +25,18 @@ __device__ __forceinline__ void cell_of_row(int64_t r, int W, int up, int& row, 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void k_score_keys(const float* __restrict__ head, int ld, int ncls, int64_t n_cells, int W, int up,
+// Candidate sort key, ascending = (window, score descending, cell ascending): window << 54 | (bits(1.0f) - bits(score)) << 24
+// | cell.  A sigmoid lies in [0, 1], so its float bits are <= 0x3F800000 and the inverted score fits 30 bits.
+#define CAND_CELL_BITS 24
+#define CAND_WIN_SHIFT 54
+
+// head rows of the B windows of a batch are stacked: row r = b * n_cells + (row inside the window)
+__global__ void k_score_keys(const float* __restrict__ head, int ld, int ncls, int64_t n_cells, int B, int W, int up,
                              float thresh, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
                              int32_t* __restrict__ counts) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_cells) return;
+    if (r >= n_cells * B) return;
+    const int b = (int)(r / n_cells);
     const float* h = head + r * ld;
     float best = sigmoidf_(h[0]);
     for (int c = 1; c < ncls; ++c) {
@@ -39,29 +46,34 @@ __global__ void k_score_keys(const float* __restrict__ head, int ld, int ncls, i
     uint64_t key = INSMOS_INVALID_KEY;
     if (best >= thresh) {
         int row, col;
-        cell_of_row(r, W, up, row, col);
+        cell_of_row(r - (int64_t)b * n_cells, W, up, row, col);
         uint32_t cell = (uint32_t)(row * W + col);
-        key = ((uint64_t)(0xFFFFFFFFu - __float_as_uint(best)) << 32) | cell;  // score desc, cell asc
-        atomicAdd(&counts[1], 1);
+        key = ((uint64_t)b << CAND_WIN_SHIFT) | ((uint64_t)(0x3F800000u - __float_as_uint(best)) << CAND_CELL_BITS) | cell;
+        atomicAdd(&counts[b * 4 + 1], 1);
     }
     keys[r] = key;
     vals[r] = (uint32_t)r;
 }
 
+// grid (candidate blocks, B): window b's candidates follow those of the windows before it in the sorted array
 __global__ void k_select_decode(const float* __restrict__ head, int ld, int ncls, int W, int up, float out_factor,
                                 float vx, float vy, float x0, float y0, const uint64_t* __restrict__ keys_s,
                                 const uint32_t* __restrict__ vals_s, int64_t n_cells, int pre_max,
                                 float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ labels,
                                 int32_t* __restrict__ cells, int32_t* __restrict__ counts) {
+    const int b = blockIdx.y;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) counts[0] = counts[1] < pre_max ? counts[1] : pre_max;
+    int64_t seg = 0;
+    for (int q = 0; q < b; ++q) seg += counts[q * 4 + 1];
+    const int n_cand = counts[b * 4 + 1];
+    if (t == 0) counts[b * 4] = n_cand < pre_max ? n_cand : pre_max;
     if (t >= pre_max) return;
-    bool valid = t < n_cells && keys_s[t] != INSMOS_INVALID_KEY;
+    bool valid = t < n_cand;
     float b7[7] = {0, 0, 0, 0, 0, 0, 0};
     float sc = 0.f;
     int lab = 0, cell = -1;
     if (valid) {
-        int64_t r = vals_s[t];
+        int64_t r = vals_s[seg + t];
         const float* h = head + r * ld;
         float best = sigmoidf_(h[0]);
         int arg = 0;
@@ -70,7 +82,7 @@ __global__ void k_select_decode(const float* __restrict__ head, int ld, int ncls
             if (p > best) { best = p; arg = c; }
         }
         int row, col;
-        cell_of_row(r, W, up, row, col);
+        cell_of_row(r - (int64_t)b * n_cells, W, up, row, col);
         const float* bx = h + ncls;
         // center_head.py:263-267: (idx + reg) * OUT_SIZE_FACTOR * VOXEL_SIZE + range, left to right in fp32
         float xs = ((float)col + bx[0]) * out_factor * vx + x0;
@@ -80,10 +92,11 @@ __global__ void k_select_decode(const float* __restrict__ head, int ld, int ncls
         b7[6] = atan2f(bx[6], bx[7]);
         sc = best; lab = arg + 1; cell = row * W + col;
     }
-    for (int d = 0; d < 7; ++d) boxes[(int64_t)t * 7 + d] = b7[d];
-    scores[t] = sc;
-    labels[t] = lab;
-    cells[t] = cell;
+    const int64_t o = (int64_t)b * pre_max + t;
+    for (int d = 0; d < 7; ++d) boxes[o * 7 + d] = b7[d];
+    scores[o] = sc;
+    labels[o] = lab;
+    cells[o] = cell;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -208,10 +221,13 @@ __global__ void k_iou3d(const float* __restrict__ a, int na, const float* __rest
 // disjoint cannot overlap: the reference's clipping yields exactly 0 for them, so they are skipped.
 __global__ void __launch_bounds__(256) k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ n_dev,
                                                   int max_n, float thresh, uint64_t* __restrict__ mask) {
-    const int n = min(n_dev[0], max_n);
+    const int win = blockIdx.z;                    // one suppression matrix per window of the batch
+    const int n = min(n_dev[win * 4], max_n);
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
     const int cbs = (max_n + 63) / 64;
+    boxes += (int64_t)win * max_n * 7;
+    mask += (int64_t)win * max_n * cbs;
     __shared__ float rowb[64 * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < 64) {
@@ -248,9 +264,13 @@ __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ 
                                                    int max_n, int post_max, int32_t* __restrict__ keep,
                                                    int32_t* __restrict__ counts) {
     const int lane = threadIdx.x;
-    const int n = min(n_dev[0], max_n);
+    const int win = blockIdx.x;                    // one wave per window of the batch
+    const int n = min(n_dev[win * 4], max_n);
     const int cbs = (max_n + 63) / 64;
     const int nb = (n + 63) / 64;
+    mask += (int64_t)win * max_n * cbs;
+    keep += (int64_t)win * post_max;
+    counts += win * 4;
     uint64_t remv = 0;  // word `lane`
     int nk = 0;
     for (int blk = 0; blk < nb && nk < post_max; ++blk) {
@@ -292,11 +312,15 @@ __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ 
 }
 
 __global__ void k_gather_preds(const float* __restrict__ cb, const float* __restrict__ cs, const int32_t* __restrict__ cl,
-                               const int32_t* __restrict__ keep, const int32_t* __restrict__ nk_dev, int post_max,
+                               const int32_t* __restrict__ keep, const int32_t* __restrict__ nk_dev, int pre_max, int post_max,
                                float* __restrict__ pb, float* __restrict__ psc, int64_t* __restrict__ pl) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= post_max) return;
-    int nk = nk_dev[0];
+    const int win = blockIdx.y;
+    int nk = nk_dev[win * 4];
+    cb += (int64_t)win * pre_max * 7; cs += (int64_t)win * pre_max; cl += (int64_t)win * pre_max;
+    keep += (int64_t)win * post_max;
+    pb += (int64_t)win * post_max * 7; psc += (int64_t)win * post_max; pl += (int64_t)win * post_max;
     if (t < nk) {
         int s = keep[t];
         for (int d = 0; d < 7; ++d) pb[t * 7 + d] = cb[(int64_t)s * 7 + d];
@@ -326,14 +350,15 @@ __device__ __forceinline__ bool inside_box(const BoxVox& b, int x, int y, int z)
 
 struct OneHotP { float lo[3], iv[3]; float istr, mult; };
 
-// boxes -> voxel units of the level (one thread per box)
+// boxes -> voxel units of the level (one thread per box of every window: box slot = window * max_boxes + i)
 __global__ void k_onehot_boxes(const float* __restrict__ boxes, const int64_t* __restrict__ labels,
-                               const int32_t* __restrict__ m_dev, int max_boxes, OneHotP P, int32_t* __restrict__ first,
+                               const int32_t* __restrict__ m_dev, int max_boxes, int B, OneHotP P, int32_t* __restrict__ first,
                                BoxVox* __restrict__ bv) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= max_boxes) return;
+    if (b >= max_boxes * B) return;
     first[b] = 0x7fffffff;
-    if (b >= min(m_dev[0], max_boxes)) return;
+    const int win = b / max_boxes;
+    if (b - win * max_boxes >= min(m_dev[win * 4], max_boxes)) return;
     BoxVox sb;
     const float* bx = boxes + (int64_t)b * 7;
     for (int d = 0; d < 3; ++d) {
@@ -354,65 +379,76 @@ __global__ void k_onehot_boxes(const float* __restrict__ boxes, const int64_t* _
 
 // grid (voxel blocks, box chunks of 64): the chunk's boxes sit in LDS, each thread owns one voxel.
 // PASS 0: first hit per box (min voxel row inside) -> atomicMin.   PASS 1: class bits per voxel -> atomicOr.
+// Batches: voxel rows are window-major (coords[:, 0] ascending) and a voxel meets the boxes of ITS window only; a block whose
+// 256 rows straddle a window boundary walks the windows it touches, one box chunk in LDS at a time.
 template <int PASS>
 __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__ m_dev, int max_boxes,
                                                      const int32_t* __restrict__ coords, int64_t n,
                                                      int32_t* __restrict__ first, const BoxVox* __restrict__ bv, int ncls,
                                                      int quirk, uint32_t* __restrict__ vbits,
                                                      unsigned long long* __restrict__ inside) {
-    const int m = min(m_dev[0], max_boxes);
     const int b0 = blockIdx.y * 64;
-    if (b0 >= m) return;
-    const int nb = min(64, m - b0);
     __shared__ BoxVox sb[64];
     __shared__ int sfirst[64];
     __shared__ int sfx[64], sfy[64], sfz[64];
-    if ((int)threadIdx.x < nb) {
-        sb[threadIdx.x] = bv[b0 + threadIdx.x];
-        if (PASS == 1) {
-            const int f = first[b0 + threadIdx.x];
-            sfirst[threadIdx.x] = f;
-            if (f != 0x7fffffff) {
-                int4 fq = *(const int4*)(coords + (int64_t)f * 4);
-                sfx[threadIdx.x] = fq.w; sfy[threadIdx.x] = fq.z; sfz[threadIdx.x] = fq.y;
-            }
-        }
-    }
-    __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int4 q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
+    const int64_t jb = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t jl = (jb + blockDim.x - 1 < n ? jb + blockDim.x - 1 : n - 1);
+    const int w_lo = coords[jb * 4], w_hi = coords[jl * 4];   // block-uniform window range
+    const int64_t j = jb + threadIdx.x;
+    const bool livej = j < n;
+    int4 q = make_int4(-1, 0, 0, 0);
+    if (livej) q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
     const int x = q.w, y = q.z, z = q.y;
     // PASS 0 does the geometry once and leaves, per voxel and 64-box chunk, the bitmask of boxes containing it;
     // PASS 1 only walks those bits (typically none) and applies the order-dependent rule.
-    unsigned long long* im = inside + (size_t)blockIdx.y * (size_t)n + j;
-    if (PASS == 0) {
-        unsigned long long hit = 0ull;
-        for (int i = 0; i < nb; ++i) {
-            if (inside_box(sb[i], x, y, z)) {
-                hit |= 1ull << i;
-                atomicMin(&first[b0 + i], (int)j);
+    unsigned long long* im = inside + (size_t)blockIdx.y * (size_t)n + (livej ? j : 0);
+    for (int win = w_lo; win <= w_hi; ++win) {
+        const int m = min(m_dev[win * 4], max_boxes);
+        if (b0 >= m) continue;  // block-uniform
+        const int nb = min(64, m - b0);
+        const int g0 = win * max_boxes + b0;  // first box slot of this chunk
+        __syncthreads();        // the previous window's boxes are no longer read
+        if ((int)threadIdx.x < nb) {
+            sb[threadIdx.x] = bv[g0 + threadIdx.x];
+            if (PASS == 1) {
+                const int f = first[g0 + threadIdx.x];
+                sfirst[threadIdx.x] = f;
+                if (f != 0x7fffffff) {
+                    int4 fq = *(const int4*)(coords + (int64_t)f * 4);
+                    sfx[threadIdx.x] = fq.w; sfy[threadIdx.x] = fq.z; sfz[threadIdx.x] = fq.y;
+                }
             }
         }
-        *im = hit;
-    } else {
-        unsigned long long hit = *im;
-        unsigned bits = 0;
-        while (hit) {
-            const int i = __ffsll(hit) - 1;
-            hit &= hit - 1;
-            const BoxVox& bb = sb[i];
-            const int f = sfirst[i];
-            if (quirk && j != f) {
-                // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
-                // extend[d] from the first-hit voxel.  (f <= j here: f is the smallest inside row.)
-                if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
-                    z > (sfz[i] + bb.e[2]) || z < (sfz[i] - bb.e[2]))
-                    continue;
+        __syncthreads();
+        if (!livej || q.x != win) continue;
+        if (PASS == 0) {
+            unsigned long long hit = 0ull;
+            for (int i = 0; i < nb; ++i) {
+                if (inside_box(sb[i], x, y, z)) {
+                    hit |= 1ull << i;
+                    atomicMin(&first[g0 + i], (int)j);
+                }
             }
-            if (bb.label > 0 && bb.label <= ncls) bits |= 1u << (bb.label - 1);
+            *im = hit;
+        } else {
+            unsigned long long hit = *im;
+            unsigned bits = 0;
+            while (hit) {
+                const int i = __ffsll(hit) - 1;
+                hit &= hit - 1;
+                const BoxVox& bb = sb[i];
+                const int f = sfirst[i];
+                if (quirk && j != f) {
+                    // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
+                    // extend[d] from the first-hit voxel.  (f <= j here: f is the smallest inside row.)
+                    if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
+                        z > (sfz[i] + bb.e[2]) || z < (sfz[i] - bb.e[2]))
+                        continue;
+                }
+                if (bb.label > 0 && bb.label <= ncls) bits |= 1u << (bb.label - 1);
+            }
+            if (bits) atomicOr(&vbits[j], bits);
         }
-        if (bits) atomicOr(&vbits[j], bits);
     }
 }
 
@@ -530,16 +566,18 @@ extern "C" size_t insmos_center_decode_select_ws_bytes(int64_t n_cells) {
     return pad256(N * 8) * 2 + pad256(N * 4) * 2 + sort_pairs_u64_u32_temp(N) + 1024;
 }
 
-extern "C" int insmos_center_decode_select(const float* head, int ld_head, int ncls, int H, int W, int up,
-                                           float out_factor, float vx, float vy, float x0, float y0,
-                                           float score_thresh, int pre_max, float* cand_boxes, float* cand_scores,
-                                           int32_t* cand_labels, int32_t* cand_cell, int32_t* counts, void* ws,
-                                           size_t ws_bytes, void* stream) {
-    if (!head || ncls <= 0 || ld_head < ncls + 8 || H <= 0 || W <= 0 || (up != 1 && up != 2) || pre_max <= 0)
+// B windows: head rows stacked window-major (B * H * W rows); candidate arrays are (B, pre_max, .), counts (B, 4) int32 with
+// [b][0] = candidates kept (<= pre_max), [b][1] = cells above the threshold.  The workspace is sized for B * H * W cells.
+extern "C" int insmos_center_decode_select_b(const float* head, int ld_head, int ncls, int H, int W, int up, int B,
+                                             float out_factor, float vx, float vy, float x0, float y0, float score_thresh,
+                                             int pre_max, float* cand_boxes, float* cand_scores, int32_t* cand_labels,
+                                             int32_t* cand_cell, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (!head || ncls <= 0 || ld_head < ncls + 8 || H <= 0 || W <= 0 || (up != 1 && up != 2) || pre_max <= 0 || B < 1 ||
+        B > INSMOS_MAX_BATCH || (int64_t)H * W >= (1ll << CAND_CELL_BITS))
         return INSMOS_EINVAL;
     if (up == 2 && ((H & 1) || (W & 1))) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t n = (int64_t)H * W;
+    const int64_t nc = (int64_t)H * W, n = nc * B;
     Bump b(ws, ws_bytes);
     uint64_t* keys = b.take<uint64_t>((size_t)n);
     uint64_t* keys_s = b.take<uint64_t>((size_t)n);
@@ -548,47 +586,66 @@ extern "C" int insmos_center_decode_select(const float* head, int ld_head, int n
     size_t st = sort_pairs_u64_u32_temp((size_t)n);
     char* tmp = b.take<char>(st);
     if (!b.ok) return INSMOS_EWORKSPACE;
-    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)B * 4 * sizeof(int32_t), s));
     {
         ProfScope ps(KK_DECODE, s);
-        INSMOS_LAUNCH(k_score_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, head, ld_head, ncls, n, W, up, score_thresh,
+        INSMOS_LAUNCH(k_score_keys, dim3(cdiv(n, 256)), dim3(256), 0, s, head, ld_head, ncls, nc, B, W, up, score_thresh,
                            keys, vals, counts);
     }
-    int rc = sort_pairs_u64_u32(tmp, st, keys, keys_s, vals, vals_s, (size_t)n, 0, 64, s);
+    // (cells below the threshold carry the all-ones key: last in any key width)
+    int end_bit = CAND_WIN_SHIFT;
+    while ((1 << (end_bit - CAND_WIN_SHIFT)) < B) ++end_bit;
+    int rc = sort_pairs_u64_u32(tmp, st, keys, keys_s, vals, vals_s, (size_t)n, 0, end_bit, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_SELECT, s);
-        INSMOS_LAUNCH(k_select_decode, dim3(cdiv(pre_max, 256)), dim3(256), 0, s, head, ld_head, ncls, W, up,
-                           out_factor, vx, vy, x0, y0, keys_s, vals_s, n, pre_max, cand_boxes, cand_scores, cand_labels,
+        INSMOS_LAUNCH(k_select_decode, dim3(cdiv(pre_max, 256), B), dim3(256), 0, s, head, ld_head, ncls, W, up,
+                           out_factor, vx, vy, x0, y0, keys_s, vals_s, nc, pre_max, cand_boxes, cand_scores, cand_labels,
                            cand_cell, counts);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
 
-extern "C" size_t insmos_nms_ws_bytes(int max_n) {
+extern "C" int insmos_center_decode_select(const float* head, int ld_head, int ncls, int H, int W, int up,
+                                           float out_factor, float vx, float vy, float x0, float y0,
+                                           float score_thresh, int pre_max, float* cand_boxes, float* cand_scores,
+                                           int32_t* cand_labels, int32_t* cand_cell, int32_t* counts, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return insmos_center_decode_select_b(head, ld_head, ncls, H, W, up, 1, out_factor, vx, vy, x0, y0, score_thresh, pre_max,
+                                         cand_boxes, cand_scores, cand_labels, cand_cell, counts, ws, ws_bytes, stream);
+}
+
+extern "C" size_t insmos_nms_ws_bytes_b(int max_n, int B) {
     size_t cbs = ((size_t)max_n + 63) / 64;
-    return pad256((size_t)max_n * cbs * 8) + 1024;
+    return pad256((size_t)max_n * cbs * 8 * (size_t)(B < 1 ? 1 : B)) + 1024;
+}
+extern "C" size_t insmos_nms_ws_bytes(int max_n) { return insmos_nms_ws_bytes_b(max_n, 1); }
+
+// B independent candidate sets: boxes (B, max_n, 7), n_dev / counts (B, 4) int32 (slot 0 used), keep (B, post_max)
+extern "C" int insmos_nms_rotated_bev_b(const float* boxes, const int32_t* n_dev, int max_n, float thresh, int post_max, int B,
+                                        int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    if (!boxes || !n_dev || max_n <= 0 || max_n > 4096 || post_max <= 0 || B < 1 || B > INSMOS_MAX_BATCH) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    const int cbs = (max_n + 63) / 64;
+    uint64_t* mask = b.take<uint64_t>((size_t)max_n * cbs * B);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    {
+        ProfScope ps(KK_NMS_MASK, s);
+        INSMOS_LAUNCH(k_nms_mask, dim3(cbs, cbs, B), dim3(256), 0, s, boxes, n_dev, max_n, thresh, mask);
+    }
+    {
+        ProfScope ps(KK_NMS_REDUCE, s);
+        INSMOS_LAUNCH(k_nms_reduce, dim3(B), dim3(64), 0, s, mask, n_dev, max_n, post_max, keep, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
 }
 
 extern "C" int insmos_nms_rotated_bev(const float* boxes, const int32_t* n_dev, int max_n, float thresh, int post_max,
                                       int32_t* keep, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
-    if (!boxes || !n_dev || max_n <= 0 || max_n > 4096 || post_max <= 0) return INSMOS_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    Bump b(ws, ws_bytes);
-    const int cbs = (max_n + 63) / 64;
-    uint64_t* mask = b.take<uint64_t>((size_t)max_n * cbs);
-    if (!b.ok) return INSMOS_EWORKSPACE;
-    {
-        ProfScope ps(KK_NMS_MASK, s);
-        INSMOS_LAUNCH(k_nms_mask, dim3(cbs, cbs), dim3(256), 0, s, boxes, n_dev, max_n, thresh, mask);
-    }
-    {
-        ProfScope ps(KK_NMS_REDUCE, s);
-        INSMOS_LAUNCH(k_nms_reduce, dim3(1), dim3(64), 0, s, mask, n_dev, max_n, post_max, keep, counts);
-    }
-    HIP_TRY(hipGetLastError());
-    return INSMOS_OK;
+    return insmos_nms_rotated_bev_b(boxes, n_dev, max_n, thresh, post_max, 1, keep, counts, ws, ws_bytes, stream);
 }
 
 extern "C" int insmos_iou_bev(const float* a, int na, const float* b, int nb, float* out, void* stream) {
@@ -610,29 +667,43 @@ extern "C" int insmos_iou3d(const float* a, int na, const float* b, int nb, floa
     return INSMOS_OK;
 }
 
-extern "C" int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
-                                   const int32_t* keep, const int32_t* n_keep_dev, int post_max, float* pred_boxes,
-                                   float* pred_scores, int64_t* pred_labels, void* stream) {
+// candidate arrays (B, pre_max, .), keep (B, post_max), n_keep_dev (B, 4) -> pred arrays (B, post_max, .)
+extern "C" int insmos_gather_preds_b(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                                     const int32_t* keep, const int32_t* n_keep_dev, int pre_max, int post_max, int B,
+                                     float* pred_boxes, float* pred_scores, int64_t* pred_labels, void* stream) {
+    if (B < 1 || B > INSMOS_MAX_BATCH || post_max <= 0) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_GATHER_PREDS, s);
-    INSMOS_LAUNCH(k_gather_preds, dim3(cdiv(post_max, 256)), dim3(256), 0, s, cand_boxes, cand_scores, cand_labels,
-                       keep, n_keep_dev, post_max, pred_boxes, pred_scores, pred_labels);
+    INSMOS_LAUNCH(k_gather_preds, dim3(cdiv(post_max, 256), B), dim3(256), 0, s, cand_boxes, cand_scores, cand_labels,
+                       keep, n_keep_dev, pre_max, post_max, pred_boxes, pred_scores, pred_labels);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
 
-extern "C" size_t insmos_boxes_to_onehot_scratch_ints(int max_boxes, int64_t n) {
-    if (max_boxes <= 0 || n < 0) return 0;
-    return 20 * (size_t)max_boxes + (((size_t)n + 1) & ~(size_t)1) + 2 * (size_t)n * (size_t)cdiv(max_boxes, 64);
+extern "C" int insmos_gather_preds(const float* cand_boxes, const float* cand_scores, const int32_t* cand_labels,
+                                   const int32_t* keep, const int32_t* n_keep_dev, int post_max, float* pred_boxes,
+                                   float* pred_scores, int64_t* pred_labels, void* stream) {
+    return insmos_gather_preds_b(cand_boxes, cand_scores, cand_labels, keep, n_keep_dev, 0, post_max, 1, pred_boxes, pred_scores,
+                                 pred_labels, stream);
 }
 
-extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
-                                      int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
-                                      float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
-                                      int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
+extern "C" size_t insmos_boxes_to_onehot_scratch_ints_b(int max_boxes, int B, int64_t n) {
+    if (max_boxes <= 0 || n < 0 || B < 1) return 0;
+    return 20 * (size_t)max_boxes * (size_t)B + (((size_t)n + 1) & ~(size_t)1) + 2 * (size_t)n * (size_t)cdiv(max_boxes, 64);
+}
+extern "C" size_t insmos_boxes_to_onehot_scratch_ints(int max_boxes, int64_t n) {
+    return insmos_boxes_to_onehot_scratch_ints_b(max_boxes, 1, n);
+}
+
+// B windows: pred arrays (B, max_boxes, .), n_boxes_dev (B, 4) int32 (slot 0), voxel rows window-major with the window in
+// coords[:, 0]; a voxel is tested against its own window's boxes only.
+extern "C" int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                                        int max_boxes, int B, const float* range_lo_host, const float* vsize_host, float stride,
+                                        float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
+                                        int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
     if (n <= 0) return INSMOS_OK;
     if (!pred_boxes || !pred_labels || !n_boxes_dev || max_boxes <= 0 || !coords || !out || !scratch || ncls <= 0 ||
-        ncls > 31 || pad_to < ncls || ld_out < pad_to)
+        ncls > 31 || pad_to < ncls || ld_out < pad_to || B < 1 || B > INSMOS_MAX_BATCH)
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     OneHotP P;
@@ -642,14 +713,15 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     }
     P.istr = 1.0f / stride;
     P.mult = mult;
+    const size_t nbx = (size_t)max_boxes * (size_t)B;
     int32_t* first = scratch;
-    BoxVox* bv = (BoxVox*)(scratch + ((max_boxes + 3) & ~3));  // 16 ints per box
-    uint32_t* vbits = (uint32_t*)(scratch + 20 * (size_t)max_boxes);
-    unsigned long long* inside = (unsigned long long*)(scratch + 20 * (size_t)max_boxes + (((size_t)n + 1) & ~(size_t)1));
+    BoxVox* bv = (BoxVox*)(scratch + ((nbx + 3) & ~(size_t)3));  // 16 ints per box
+    uint32_t* vbits = (uint32_t*)(scratch + 20 * nbx);
+    unsigned long long* inside = (unsigned long long*)(scratch + 20 * nbx + (((size_t)n + 1) & ~(size_t)1));
     ProfScope ps(KK_ONEHOT, s);
     HIP_TRY(hipMemsetAsync(vbits, 0, (size_t)n * sizeof(uint32_t), s));
-    INSMOS_LAUNCH(k_onehot_boxes, dim3(cdiv(max_boxes, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
-                       max_boxes, P, first, bv);
+    INSMOS_LAUNCH(k_onehot_boxes, dim3(cdiv((int64_t)nbx, 64)), dim3(64), 0, s, pred_boxes, pred_labels, n_boxes_dev,
+                       max_boxes, B, P, first, bv);
     dim3 grid(cdiv(n, 256), cdiv(max_boxes, 64));
     INSMOS_LAUNCH(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
                        quirk_exact, vbits, inside);
@@ -658,6 +730,14 @@ extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pr
     INSMOS_LAUNCH(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                                      int max_boxes, const float* range_lo_host, const float* vsize_host, float stride,
+                                      float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
+                                      int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
+    return insmos_boxes_to_onehot_b(pred_boxes, pred_labels, n_boxes_dev, max_boxes, 1, range_lo_host, vsize_host, stride, mult,
+                                    coords, n, ncls, pad_to, quirk_exact, out, ld_out, scratch, stream);
 }
 
 extern "C" int insmos_points_in_instance_boxes(const float* points, int64_t n, int ld_pts, const float* boxes,

@@ -40,6 +40,8 @@ struct ConvP {
     uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
     int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
+    int tap_mod;  // tap-split tiles: 1 = wave ws owns the taps k with k % SPLIT == ws (a row's sum does not depend on which
+                  // rows share its tile), 0 = every SPLIT-th ACTIVE tap of the tile (evenest load, tile-dependent order)
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -156,8 +158,16 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         }
         int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
         if constexpr (SPLIT > 1 && !SPLITC) {
-            for (uint32_t q = 0; q < ws; ++q) (void)pop_or_keep(tlo, thi, 0);  // my taps: ranks ws, ws+SPLIT, ...
-            nt = (live && nt > (int)ws) ? (nt - (int)ws + SPLIT - 1) / SPLIT : 0;
+            static_assert(SPLIT == 4, "residue masks below are written for 4 waves per tile");
+            if (P.tap_mod) {
+                const uint64_t mine = 0x1111111111111111ull << ws;  // taps k with k % 4 == ws (64 % 4 == 0: same in both words)
+                tlo &= mine;
+                thi &= mine;
+                nt = live ? __builtin_popcountll(tlo) + __builtin_popcountll(thi) : 0;
+            } else {
+                for (uint32_t q = 0; q < ws; ++q) (void)pop_or_keep(tlo, thi, 0);  // my taps: ranks ws, ws+SPLIT, ...
+                nt = (live && nt > (int)ws) ? (nt - (int)ws + SPLIT - 1) / SPLIT : 0;
+            }
         } else if constexpr (SPLIT > 1) {
             nt = live ? nt : 0;
         }
@@ -165,8 +175,10 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         auto next_tap = [&](int keep) {
             const int k = pop_or_keep(tlo, thi, keep);
             if constexpr (SPLIT > 1 && !SPLITC) {
+                if (!P.tap_mod) {
 #pragma unroll
-                for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
+                    for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
+                }
             }
             return k;
         };
@@ -437,14 +449,16 @@ __global__ void __launch_bounds__(64) k_deconv_head(const float* __restrict__ x,
     }
 }
 
-__global__ void k_dense_nbr2d(int H, int W, int32_t* __restrict__ nbr) {
+// B images stacked along the row axis (site = (b*H + y)*W + x): a tap never leaves its image
+__global__ void k_dense_nbr2d(int H, int W, int B, int32_t* __restrict__ nbr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t n = (int64_t)H * W;
+    int64_t n = (int64_t)H * W * B;
     if (t >= n * 9) return;
     int k = (int)(t / n);
     int site = (int)(t % n);
-    int y = site / W + k / 3 - 1, x = site % W + k % 3 - 1;
-    nbr[t] = (y >= 0 && y < H && x >= 0 && x < W) ? y * W + x : -1;
+    int img = site / (H * W), loc = site % (H * W);
+    int y = loc / W + k / 3 - 1, x = loc % W + k % 3 - 1;
+    nbr[t] = (y >= 0 && y < H && x >= 0 && x < W) ? (img * H + y) * W + x : -1;
 }
 
 __global__ void k_sparse_to_bev(const float* __restrict__ feat, int ld_feat, int C, const int32_t* __restrict__ coords,
@@ -454,7 +468,7 @@ __global__ void k_sparse_to_bev(const float* __restrict__ feat, int ld_feat, int
     int64_t i = t / C;
     int c = (int)(t % C);
     int4 q = *(const int4*)(coords + i * 4);  // [b, d, y, x]
-    bev[((int64_t)q.z * W + q.w) * ((int64_t)C * D) + (int64_t)c * D + q.y] = feat[i * ld_feat + c];
+    bev[(((int64_t)q.x * H + q.z) * W + q.w) * ((int64_t)C * D) + (int64_t)c * D + q.y] = feat[i * ld_feat + c];
 }
 
 }  // namespace insmos
@@ -624,8 +638,9 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     if (split_env < 0) { split_env = env_int("INSMOS_CONV_SPLIT", 1); split_dense = env_int("INSMOS_CONV_SPLIT_DENSE", 1); }
     // (measured on S0: splitting pays when a tile carries >= ~100 (tap, chunk, channel-tile) MFMA groups -- the
     // 81-tap C >= 32 4D layers gain 20-30 % -- and costs 30-50 % on the small-C layers that already have 10k+ tiles)
-    static int split_work = -1;
-    if (split_work < 0) split_work = env_int("INSMOS_CONV_SPLIT_WORK", 100);
+    static int split_work = -1, tap_mod = -1;
+    if (split_work < 0) { split_work = env_int("INSMOS_CONV_SPLIT_WORK", 100); tap_mod = env_int("INSMOS_SPLIT_TAP_MOD", 1); }
+    P.tap_mod = tap_mod;
     const bool co_ok = P.ntile_co == 1 || P.ntile_co == 2 || P.ntile_co == 4 || P.ntile_co == 8;
     const bool wide = P.ntile_co >= 4;
     const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
@@ -712,23 +727,25 @@ extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {
     return INSMOS_OK;
 }
 
-extern "C" int insmos_dense_nbr2d(int H, int W, int32_t* nbr, void* stream) {
-    if (H <= 0 || W <= 0 || !nbr) return INSMOS_EINVAL;
+extern "C" int insmos_dense_nbr2d_b(int H, int W, int B, int32_t* nbr, void* stream) {
+    if (H <= 0 || W <= 0 || B < 1 || !nbr || (int64_t)H * W * B * 9 * 4 >= (1ll << 31)) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_DENSE_NBR, s);
-    int64_t n = (int64_t)H * W * 9;
-    INSMOS_LAUNCH(k_dense_nbr2d, dim3(cdiv(n, 256)), dim3(256), 0, s, H, W, nbr);
+    int64_t n = (int64_t)H * W * B * 9;
+    INSMOS_LAUNCH(k_dense_nbr2d, dim3(cdiv(n, 256)), dim3(256), 0, s, H, W, B, nbr);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
+extern "C" int insmos_dense_nbr2d(int H, int W, int32_t* nbr, void* stream) { return insmos_dense_nbr2d_b(H, W, 1, nbr, stream); }
 
-extern "C" int insmos_sparse_to_bev(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D,
-                                    int H, int W, float* bev, void* stream) {
-    if (!feat || !coords || !bev || C <= 0 || D <= 0) return INSMOS_EINVAL;
+// B stacked images: coords[:, 0] = image of the voxel, bev is (B, H, W, C*D)
+extern "C" int insmos_sparse_to_bev_b(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D,
+                                      int H, int W, int B, float* bev, void* stream) {
+    if (!feat || !coords || !bev || C <= 0 || D <= 0 || B < 1) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope ps(KK_MEMSET, s);
-        HIP_TRY(hipMemsetAsync(bev, 0, (size_t)H * W * C * D * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(bev, 0, (size_t)B * H * W * C * D * sizeof(float), s));
     }
     if (n > 0) {
         ProfScope ps(KK_TO_BEV, s);
@@ -737,4 +754,9 @@ extern "C" int insmos_sparse_to_bev(const float* feat, int ld_feat, int C, const
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_sparse_to_bev(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D,
+                                    int H, int W, float* bev, void* stream) {
+    return insmos_sparse_to_bev_b(feat, ld_feat, C, coords, n, D, H, W, 1, bev, stream);
 }

@@ -107,6 +107,9 @@ class NbrTable:
         return self.nbr >= other
 
 
+MAX_WINDOWS_PER_LAUNCH = 16  # INSMOS_MAX_BATCH of csrc/common.h
+
+
 class Engine:
     def __init__(self, cfg, state_dict, device="cuda:0", quirk_exact=True, max_voxels=100000, max_points=5, native=False):
         self.lib = _lib.load()
@@ -153,6 +156,7 @@ class Engine:
             raise NotImplementedError("BEV deconv stride 2 only (config.yaml:118)")
         self._ws = None
         self._conv_log = []
+        self._conv_nin = []
         self.const_input = True  # MotionNet input features are the constant 0.5 (motionnet.py:29-32)
         self.layer_timing = None  # set to [] to record per-conv (name, K, cin, cout, n_out, ev0, ev1)
         self._load_weights(state_dict)
@@ -276,6 +280,7 @@ class Engine:
             self._stream())
         _lib.check(rc, "insmos_sparse_conv_rows")
         self._conv_log.append((nbr, n_out, layer, row0))
+        self._conv_nin.append(int(x.shape[0] if n_in is None else n_in))
         if self.layer_timing is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
@@ -299,28 +304,34 @@ class Engine:
         return NbrTable(nbr, mask)
 
     # ------------------------------------------------------------------------------------------------
-    def motionnet(self, pts, bid=None, B=1):
+    def motionnet(self, pts, win_sizes=None):
         """pts (N, ld>=5) fp32 device [x,y,z,r,t] -> current_point (Ncur, 8) [x,y,z,r,m0,m1,m2,0].
-        bid / B (EXPERIMENTAL, docs/round2_batching_plan.md): pts holds B windows back to back, bid (N,) int32 names the
-        window of every point; the window index is folded into the time coordinate (t' = t * B + b), the searched table is
-        built on time offsets scaled by B, everything else runs unchanged on B x the rows -> current points of all windows
-        in input order (window-major)."""
+        win_sizes (docs/round2_batching_plan.md): pts holds B = len(win_sizes) windows back to back; the window index is
+        folded into the time coordinate (t' = t * B + b), the searched table is built on time offsets scaled by B,
+        everything else runs unchanged on B x the rows -> current points of all windows in input order (window-major).
+        (The product path for batches is the native runner, insmos_forward_windows; this is its inspectable 4D half.)"""
         lib, st = self.lib, self._stream()
-        batched = bid is not None and B > 1
+        B = len(win_sizes) if win_sizes is not None else 1
+        batched = B > 1
         N, ld = pts.shape[0], pts.stride(0)
+        if batched:
+            assert sum(win_sizes) == N
+            starts = np.concatenate([[0], np.cumsum(win_sizes)[:-1]]).astype(np.int64)
+            win_ptr = (ctypes.c_void_p * B)(*[pts.data_ptr() + 4 * ld * int(o) for o in starts])
+            win_n = (ctypes.c_int64 * B)(*[int(v) for v in win_sizes])
         ws = self._workspace(lib.insmos_quantize4d_ws_bytes(N))
         keys0 = self._empty((N,), torch.int64)
         coords0 = self._empty((N, 4), torch.int32)
         inverse = self._empty((N,), torch.int32)
         cur_index = self._empty((N,), torch.int32)
-        counts = self._empty((4,), torch.int32)
+        counts = self._empty((8 + B,), torch.int32)
         quant = np.array([self.vs[0], self.vs[0], self.vs[0], self.dt], dtype=np.float32)
         for compact in (1, 0):  # 40-bit sort keys first; the full-width sort only for windows wider than +-2048 voxels
             if batched:
-                _lib.check(lib.insmos_quantize4d_batched(pts.data_ptr(), N, ld, _hp(quant), bid.data_ptr(), B, keys0.data_ptr(),
+                _lib.check(lib.insmos_quantize4d_windows(win_ptr, win_n, B, ld, _hp(quant), keys0.data_ptr(),
                                                          coords0.data_ptr(), inverse.data_ptr(), cur_index.data_ptr(),
                                                          counts.data_ptr(), ws.data_ptr(), ws.numel(), compact, st),
-                           "insmos_quantize4d_batched")
+                           "insmos_quantize4d_windows")
             else:
                 _lib.check(lib.insmos_quantize4d_ex(pts.data_ptr(), N, ld, _hp(quant), keys0.data_ptr(), coords0.data_ptr(),
                                                     inverse.data_ptr(), cur_index.data_ptr(), counts.data_ptr(), ws.data_ptr(),
@@ -434,6 +445,7 @@ class Engine:
                                                             self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1, st),
                        "insmos_const_conv125_from_coarse")
             self._conv_log.append((None, n[0], L["conv0p1s1"], 0))
+            self._conv_nin.append(0)   # constant input: nothing is read
         else:
             self.conv(L["conv0p1s1"], x_in, 4, nbr125, n[0], cat8, 16, col_out=8, relu_post=1)
         x1 = E((n[1], 8))
@@ -491,9 +503,7 @@ class Engine:
         if B == 1:
             return [self.motionnet(pts_list[0])]
         pts = torch.cat([p[:, :5] for p in pts_list], 0).contiguous()
-        sizes = torch.tensor([int(p.shape[0]) for p in pts_list], device=pts.device)
-        bid = torch.repeat_interleave(torch.arange(B, device=pts.device, dtype=torch.int32), sizes)
-        cur = self.motionnet(pts, bid.contiguous(), B)
+        cur = self.motionnet(pts, [int(p.shape[0]) for p in pts_list])
         ncur = [int((p[:, 4] == 0).sum()) for p in pts_list]
         assert sum(ncur) == int(cur.shape[0]), (ncur, cur.shape)
         return list(torch.split(cur, ncur, 0))
@@ -649,6 +659,7 @@ class Engine:
                                               head.data_ptr(), self.head_ld, st), "insmos_deconv_head")
             self._conv_log.append((None, nsite, L["deconv"], 0))
             self._conv_log.append((None, ncell, L["head"], 0))
+            self._conv_nin += [nsite, 0]  # fused: the deconv output feeds the heads from the accumulators
         else:
             upf = E((nsite, 4 * upc))
             self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
@@ -725,15 +736,19 @@ class Engine:
         driven from C++, one foreign call, no interpreter work between launches); native=False issues the operators
         step by step from Python and keeps every intermediate for inspection (tests, profiling hooks).  Both give
         identical bits (tests/test_gpu_model.py).  Default: the engine's `native` attribute."""
-        if pts.dtype != torch.float32 or pts.device.type != "cuda" or pts.dim() != 2 or pts.shape[1] < 5:
-            raise ValueError("past_point_clouds must be a float32 CUDA tensor of shape (N, 5) [x,y,z,intensity,t]")
-        if pts.stride(1) != 1:
-            pts = pts.contiguous()
+        pts = self._check_points(pts)
         if self.native if native is None else native:
             return self._forward_native(pts)
         self._conv_log = []
+        self._conv_nin = []
         cur = self.motionnet(pts)
         return self.unet(cur)
+
+    @staticmethod
+    def _check_points(pts):
+        if pts.dtype != torch.float32 or pts.device.type != "cuda" or pts.dim() != 2 or pts.shape[1] < 5:
+            raise ValueError("past_point_clouds must be a float32 CUDA tensor of shape (N, 5) [x,y,z,intensity,t]")
+        return pts if pts.stride(1) == 1 else pts.contiguous()
 
     # ------------------------------------------------------------------------------------------------
     def _native_ctx(self):
@@ -768,49 +783,73 @@ class Engine:
         return self._ctx_box[0].handle
 
     def _forward_native(self, pts):
+        return self.forward_windows([pts])[0][:2]
+
+    def forward_windows(self, pts_list):
+        """The batch list of InsMOS_Model.forward(..., 'test') in ONE set of launches (insmos_forward_windows,
+        csrc/forward.hip): where the reference walks the list window by window (models/models.py:313), the B windows share
+        every launch -> [(logits (Ncur_b, 3), pred dict, current_point or None)] per window, each with the bits the window
+        gets alone (tests/test_gpu_batched.py)."""
         if not self.const_input:
             raise NotImplementedError("the native runner implements the constant-input first layer only")
+        B = len(pts_list)
+        if B < 1 or B > MAX_WINDOWS_PER_LAUNCH:
+            raise ValueError(f"1 .. {MAX_WINDOWS_PER_LAUNCH} windows per launch set, got {B}")
+        pts_list = [self._check_points(p) for p in pts_list]
+        ld = pts_list[0].stride(0)
+        if any(p.stride(0) != ld for p in pts_list):
+            pts_list = [p[:, :5].contiguous() for p in pts_list]
+            ld = 5
         ctx = self._native_ctx()
-        N = int(pts.shape[0])
+        N = sum(int(p.shape[0]) for p in pts_list)
         if self._arena is None:
             self._arena = torch.empty(640 * N + (192 << 20), dtype=torch.uint8, device=self.device)
-        out = _lib.ForwardOut()
+        win_ptr = (ctypes.c_void_p * B)(*[p.data_ptr() for p in pts_list])
+        win_n = (ctypes.c_int64 * B)(*[int(p.shape[0]) for p in pts_list])
+        outs = (_lib.ForwardOut * B)()
         for _ in range(12):
-            rc = self.lib.insmos_forward_window(ctx, pts.data_ptr(), N, pts.stride(0), self._arena.data_ptr(),
-                                                self._arena.numel(), self._stream(), ctypes.byref(out))
+            rc = self.lib.insmos_forward_windows(ctx, win_ptr, win_n, B, ld, self._arena.data_ptr(), self._arena.numel(),
+                                                 self._stream(), outs)
             if rc != -3:  # INSMOS_EWORKSPACE: grow the arena and retry
                 break
             self._arena = None
-            self._arena = torch.empty(max(int(out.arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
-        if rc == -1 and out.n_out_of_window:
-            raise ValueError(f"{int(out.n_out_of_window)} points fall outside the +-32768-voxel key window")
-        if rc == -1 and out.n_cur == 0 and out.me_voxels[0] > 0 and not out.n_out_of_window:
+            self._arena = torch.empty(max(int(outs[0].arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
+        if rc == -1 and outs[0].n_out_of_window:
+            raise ValueError(f"{int(outs[0].n_out_of_window)} points fall outside the +-32768-voxel key window")
+        if rc == -1 and outs[0].me_voxels[0] > 0 and any(int(o.n_cur) == 0 for o in outs):
             raise ValueError("window has no current-scan points (t == 0)")
-        _lib.check(rc, "insmos_forward_window")
-        ncur, K = int(out.n_cur), int(out.n_boxes)
-        self.last_counts = {"me_voxels": [int(v) for v in out.me_voxels], "n_cur": ncur,
-                            "unet_voxels": [int(v) for v in out.unet_voxels], "n_boxes": K,
-                            "n_candidates": int(out.n_candidates)}
+        _lib.check(rc, "insmos_forward_windows")
         a = self._arena
 
         def view(off, count, dtype, shape):
             nb = count * torch.empty((), dtype=dtype).element_size()
-            return a[off:off + nb].view(dtype).reshape(shape).clone()  # the arena is rewritten by the next window
+            return a[off:off + nb].view(dtype).reshape(shape).clone()  # the arena is rewritten by the next batch
 
-        logits = view(out.logits_off, ncur * 3, torch.float32, (ncur, 3))
-        pred = {"pred_boxes": view(out.boxes_off, K * 7, torch.float32, (K, 7)),
-                "pred_scores": view(out.scores_off, K, torch.float32, (K,)),
-                "pred_labels": view(out.labels_off, K, torch.int64, (K,))}
+        results = []
+        for out in outs:
+            ncur, K = int(out.n_cur), int(out.n_boxes)
+            logits = view(out.logits_off, ncur * 3, torch.float32, (ncur, 3))
+            pred = {"pred_boxes": view(out.boxes_off, K * 7, torch.float32, (K, 7)),
+                    "pred_scores": view(out.scores_off, K, torch.float32, (K,)),
+                    "pred_labels": view(out.labels_off, K, torch.int64, (K,))}
+            cur = view(out.cur_points_off, ncur * 8, torch.float32, (ncur, 8)) if self.keep_current_points else None
+            results.append((logits, pred, cur))
+        o0 = outs[0]
+        self.last_counts = {"me_voxels": [int(v) for v in o0.me_voxels], "n_cur": int(o0.n_cur),
+                            "unet_voxels": [int(v) for v in o0.unet_voxels], "n_boxes": int(o0.n_boxes),
+                            "n_candidates": int(o0.n_candidates), "batch": B,
+                            "per_window": [{"n_cur": int(o.n_cur), "voxels": int(o.unet_voxels[0]), "n_boxes": int(o.n_boxes),
+                                            "n_candidates": int(o.n_candidates)} for o in outs]}
         if self.keep_current_points:
-            self.last_current_points = view(out.cur_points_off, ncur * 8, torch.float32, (ncur, 8))
-        return logits, pred
+            self.last_current_points = results[0][2]
+        return results
 
     def clone_shared(self):
         """A second runner over the SAME device weights, tables and native context, with its own arena/workspace --
         one per window in flight (InsMOS_Model.forward with several batch items)."""
         import copy
         e = copy.copy(self)
-        e._ws, e._arena, e._conv_log, e.last_counts, e.layer_timing = None, None, [], {}, None
+        e._ws, e._arena, e._conv_log, e._conv_nin, e.last_counts, e.layer_timing = None, None, [], [], {}, None
         return e
 
     def algorithmic_work(self):
@@ -819,8 +858,8 @@ class Engine:
         entries of the layer's neighbour table (n_out for 1x1 layers).  Costs a device reduction per
         distinct table: bench/profiling only."""
         cache = {}
-        flops = gather = pairs_total = 0
-        for nbr, n_out, layer, row0 in self._conv_log:
+        flops = gather = pairs_total = compulsory = 0
+        for (nbr, n_out, layer, row0), n_in in zip(self._conv_log, self._conv_nin):
             if nbr is None:
                 pairs = n_out - row0
             else:
@@ -833,4 +872,8 @@ class Engine:
             flops += pairs * layer.flops_per_pair
             gather += 4 * pairs * (cin + layer.cout_real) + 8 * pairs
             pairs_total += pairs
-        return {"flops": flops, "gather_bytes": gather, "pairs": pairs_total, "launches": len(self._conv_log)}
+            # compulsory HBM bytes: input rows and output rows once, plus the table rows read
+            rows = n_out - row0
+            compulsory += 4 * (n_in * cin + rows * layer.cout_real) + (4 * layer.K * rows if nbr is not None else 0)
+        return {"flops": flops, "gather_bytes": gather, "pairs": pairs_total, "launches": len(self._conv_log),
+                "compulsory_bytes": compulsory}

@@ -19,7 +19,7 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 import yaml
 
-from .engine import Engine
+from .engine import Engine, MAX_WINDOWS_PER_LAUNCH
 from .metrics import generate_recall_record
 from . import params as P
 
@@ -41,13 +41,16 @@ def load_semantic_config(cfg):
 class InsMOS_Model:
     """models/models.py:269-376 (test mode).
 
-    The reference walks the batch list sequentially (models/models.py:313).  Here up to `windows_in_flight` (4) batch items
-    are processed concurrently -- one host thread, HIP stream and arena each, all sharing the device weights -- because
-    one window leaves a large part of an MI355X idle (few tiles per SIMD in the deep layers, count read-backs).  The
-    results are the same bits as the sequential walk; the caller's current stream waits for all of them."""
+    The reference walks the batch list sequentially (models/models.py:313).  Here the list is cut into groups of
+    `windows_per_launch` items and every group runs as ONE set of launches (Engine.forward_windows: the windows of a group
+    share every kernel launch and every count read-back), because one window leaves a large part of an MI355X idle (few
+    tiles per SIMD in the deep layers, host syncs).  Up to `windows_in_flight` groups are processed concurrently -- one
+    host thread, HIP stream and arena each, all sharing the device weights -- so that the read-backs of one group hide
+    behind the kernels of another.  Every item gets the same bits as in the sequential walk; the caller's current stream
+    waits for all of them."""
 
     def __init__(self, cfg, n_mos_classes, ignore_index, state_dict, device="cuda:0", quirk_exact=True,
-                 windows_in_flight=None):
+                 windows_in_flight=None, windows_per_launch=None):
         self.cfg = cfg
         self.mos_class = n_mos_classes
         self.ignore_index = ignore_index
@@ -55,8 +58,11 @@ class InsMOS_Model:
         self.device = device
         self.quirk_exact = quirk_exact
         if windows_in_flight is None:
-            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "4"))
-        self.windows_in_flight = max(1, int(windows_in_flight))
+            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "2"))
+        if windows_per_launch is None:
+            windows_per_launch = int(os.environ.get("INSMOS_WINDOWS_PER_LAUNCH", "4"))
+        self.windows_in_flight = max(1, int(windows_in_flight))         # launch sets (groups) in flight
+        self.windows_per_launch = max(1, min(int(windows_per_launch), MAX_WINDOWS_PER_LAUNCH))
         self._engine = None
         self._workers = None  # (engines, streams, executor)
 
@@ -94,28 +100,32 @@ class InsMOS_Model:
             raise ValueError(f"unknown Model_mode {Model_mode!r}")
         keep = Model_mode == "eval"
         n = len(list_batch_dict)
-        w = min(n, self.windows_in_flight)
+        wpl = self.windows_per_launch
+        groups = [list(range(i, min(i + wpl, n))) for i in range(0, n, wpl)]
+        w = min(len(groups), self.windows_in_flight)
+        results = [None] * n
 
-        def one(engine, b):
+        def one(engine, idxs):
             engine.keep_current_points = keep
-            logits, pred = engine.forward_window(b["past_point_clouds"])
-            cur_pts, engine.last_current_points = engine.last_current_points, None
-            return logits, pred, cur_pts
+            res = engine.forward_windows([list_batch_dict[i]["past_point_clouds"] for i in idxs])
+            engine.last_current_points = None
+            for i, r in zip(idxs, res):
+                results[i] = r
 
         if w <= 1:
-            results = [one(self.engine, b) for b in list_batch_dict]
+            for idxs in groups:
+                one(self.engine, idxs)
         else:
             engines, streams, pool = self._get_workers(w)
             dev = torch.device(self.device)
             cur = torch.cuda.current_stream(dev)
-            results = [None] * n
 
             def run(wi):
                 torch.cuda.set_device(dev)  # device and current stream are per host thread
                 streams[wi].wait_stream(cur)  # the inputs were produced on the caller's stream
                 with torch.cuda.stream(streams[wi]):
-                    for i in range(wi, n, w):
-                        results[i] = one(engines[wi], list_batch_dict[i])
+                    for gi in range(wi, len(groups), w):
+                        one(engines[wi], groups[gi])
 
             for f in [pool.submit(run, wi) for wi in range(w)]:
                 f.result()  # re-raises worker exceptions

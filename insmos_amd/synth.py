@@ -35,8 +35,8 @@ def make_scan(rng, ego_x, n_az, boxes, n_beams=64, sensor_h=1.73):
     t = np.full(len(d), np.inf)
     down = d[:, 2] < -1e-6
     t = np.minimum(t, np.where(down, -sensor_h / np.where(down, d[:, 2], -1), np.inf))
+    inv = 1.0 / np.where(np.abs(d) < 1e-9, 1e-9, d)  # (loop-invariant)
     for lo, hi in boxes:
-        inv = 1.0 / np.where(np.abs(d) < 1e-9, 1e-9, d)
         t0 = (lo - o) * inv
         t1 = (hi - o) * inv
         tmin = np.minimum(t0, t1).max(1)

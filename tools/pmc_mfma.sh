@@ -1,26 +1,24 @@
 #!/bin/bash
 # MFMA-pipe utilisation of the conv launches from PMC counters (one rocprofv3 pass, --kernel-trace only; one window in flight)
-R=$(pwd); TAG=${1:-r01}
+R=$(pwd); TAG=${1:-r02}; WPL=${2:-4}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_mfma
-( cd /tmp && INSMOS_WINDOWS_IN_FLIGHT=1 timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES \
-    -d $R/gpurun_out/pmc_mfma/p -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --windows-per-step 1 --no-cpu-baseline ) > $R/gpurun_out/pmc_mfma/p.log 2>&1
+( cd /tmp && INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES \
+    -d $R/gpurun_out/pmc_mfma/p -o p --output-format csv -- python $R/bench.py --timed-only --steps 1 --warmup 0 --windows-per-step $WPL ) > $R/gpurun_out/pmc_mfma/p.log 2>&1
 echo "rc=$?"
 python - <<PY
 import csv, glob, json, os
 f = glob.glob("$R/gpurun_out/pmc_mfma/p/**/*counter_collection.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-q = [i for i, r in enumerate(rows) if "k_quant_keys" in r["Kernel_Name"]]
-last = rows[q[-1]:]
-conv = [r for r in last if "k_sparse_conv" in r["Kernel_Name"] or "k_deconv_head" in r["Kernel_Name"]]
+conv = [r for r in rows if "k_sparse_conv" in r["Kernel_Name"] or "k_deconv_head" in r["Kernel_Name"]]
 tot = {}
 for r in conv:
     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 disp = len({r["Dispatch_Id"] for r in conv})
 gui = tot.get("GRBM_GUI_ACTIVE", 0.0)
-out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES -- bench.py (one window)",
-       "scope": "conv launches (k_sparse_conv*, k_deconv_head) of ONE window, cfg-2 S0, one window in flight (the profiler serialises kernels)",
+out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES -- bench.py --timed-only (one launch set)",
+       "scope": "conv launches (k_sparse_conv*, k_deconv_head) of ONE launch set of $WPL cfg-2 S0 windows (bench.py --timed-only; the profiler serialises kernels)", "windows_per_launch": $WPL,
        "launches": disp, "totals": tot,
        "mfma_busy_over_gpu_active": tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024 / 8) if gui else None,
        "note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_16x16x4_f32 "

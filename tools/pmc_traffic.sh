@@ -1,13 +1,16 @@
 #!/bin/bash
-# HBM traffic of the sparse-conv launches from PMC counters: one rocprofv3 pass per counter (--kernel-trace only), on a
-# single window (one in flight) -- tools/pmc_traffic.py sums the last window's conv launches and applies the gfx950
-# FETCH_SIZE correction of MI355X_MICROARCH.md.  Usage (GPU box): bash tools/pmc_traffic.sh r01
-R=$(pwd); TAG=${1:-r01}
+# HBM traffic of the convolution launches from PMC counters: one rocprofv3 pass per counter (--kernel-trace only, never
+# combined with other trace domains), over `bench.py --timed-only` with ONE launch set in flight -- every launch of the trace
+# belongs to a step.  tools/pmc_traffic.py sums the conv launches, applies the gfx950 FETCH_SIZE correction of
+# MI355X_MICROARCH.md and divides by the windows processed.  Usage (GPU box, after one plain bench.py run that cached the
+# head calibration):  bash tools/pmc_traffic.sh r02 [windows_per_launch]
+R=$(pwd); TAG=${1:-r02}; WPL=${2:-4}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_traffic
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && INSMOS_WINDOWS_IN_FLIGHT=1 timeout 170 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic/$c -o p --output-format csv -- \
-      python $R/bench.py --steps 1 --warmup 1 --windows-per-step 1 --no-cpu-baseline ) > $R/gpurun_out/pmc_traffic/$c.log 2>&1
+  rm -rf $R/gpurun_out/pmc_traffic/$c
+  ( cd /tmp && INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic/$c -o p --output-format csv -- \
+      python $R/bench.py --timed-only --steps 1 --warmup 0 --windows-per-step $WPL ) > $R/gpurun_out/pmc_traffic/$c.log 2>&1
   echo "$c rc=$?"
 done
-python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic $TAG
+python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic $TAG $WPL
