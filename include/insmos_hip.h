@@ -37,6 +37,9 @@ int insmos_last_hip_error(void);
 /* ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ---- */
 int insmos_prof_enable(int on);
 int insmos_prof_reset(void);
+/* per-launch durations (ms) of one kernel kind in record order + the four integers its launch site attached (convolutions:
+ * K, Cin, Cout, rows computed); returns the number of entries written (<= max) */
+int insmos_prof_read_spans(int kind_id, int max, double* ms_host, int64_t* meta4_host);
 /* Synchronises, then writes up to `max` entries; returns the number of kernel kinds. */
 int insmos_prof_read(int max, int* kind_ids_host, double* total_ms_host, int64_t* launches_host);
 const char* insmos_prof_name(int kind_id);
@@ -225,9 +228,11 @@ int insmos_build_current_points_windows(const float* const* points_host, const i
 /* win_start (device, B + 1 int32): first point of each window in the window-major point array (null: one window).  Every
  * window is voxelised in its own first-seen order and capped at max_voxels on its own (the reference calls VoxelGenerate
  * per batch item, models/models.py:326); voxel rows are window-major, pc_voxel_id holds batch-wide rows.
+ * ukeys = b * key_cells + cell: key_cells = D*H*W of the spatial shape the level-1 tables are searched with (one cell
+ * deeper than the voxel grid, spconv_unet.py:114); 0 = the voxel grid's own cell count.
  * counts: [0] voxel rows, [1] occupied cells, [2] in-range points, with win_start also [4 + b] = first row of window b. */
 int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start, int B,
-                                 const float* range_host, const float* vsize_host, int max_voxels, int max_pts, float* feat,
+                                 int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels, int max_pts, float* feat,
                                  int ld_feat, int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
                                  int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 size_t insmos_down_coords3d_ws_bytes_b(const int32_t* out_shape_host, int B);
@@ -254,6 +259,13 @@ int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels
                              const int32_t* coords, int64_t n, int ncls, int pad_to, int quirk_exact, float* out, int ld_out,
                              int32_t* scratch, void* stream);
 int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int B, int32_t* starts, void* stream);
+/* Dense BEV backbone convolution (base_bev_backbone.py:33-61: ZeroPad2d(1)+Conv2d(3x3) / Conv2d(3x3, padding 1), each with
+ * BatchNorm2d + ReLU) as an LDS-tiled implicit GEMM: x (B, H, W, cin) NHWC with row pitch ld_x -> out (B, H, W, cout) with row
+ * pitch ld_out; 3x3, stride 1, zero padding 1, + bias (folded BN) + optional ReLU.  wpacked / bias as
+ * insmos_pack_weights_host(taps (9, cin, cout)), tap = ky*3 + kx.  cin a multiple of 16, cout 64 or 128 (else EINVAL: use
+ * insmos_sparse_conv over insmos_dense_nbr2d).  Same result as that table path up to fp32 summation order. */
+int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                       float* out, int ld_out, int cout, int relu, void* stream);
 /* Fused BEV deblock + heads (base_bev_backbone.py:104-115, center_head.py:65-72): x (n_site, cin) NHWC BEV features;
  * wd_packed / bd = the ConvTranspose2d(k=2,s=2)+BN as a 1x1 layer with 4*cup outputs laid out [ky][kx][co] (cup = 256);
  * wh_packed / bh = the merged 1x1 heads (cup -> head_cout <= 16).  head ((4*n_site), ld_head): row site*4 + ky*2 + kx.

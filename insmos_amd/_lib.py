@@ -19,6 +19,7 @@ SIGNATURES = {
     "insmos_prof_reset": (c_int, []),
     "insmos_prof_read": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "insmos_prof_name": (ctypes.c_char_p, [c_int]),
+    "insmos_prof_read_spans": (c_int, [c_int, c_int, c_vp, c_vp]),
     "insmos_prof_read_union": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "insmos_quantize4d_ws_bytes": (c_sz, [c_i64]),
     "insmos_quantize4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "insmos_quantize4d_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "insmos_build_current_points_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
-    "insmos_voxelize_mean_windows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
+    "insmos_voxelize_mean_windows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
                                              c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_down_coords3d_ws_bytes_b": (c_sz, [c_vp, c_int]),
     "insmos_down_coords3d_b": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -62,6 +63,7 @@ SIGNATURES = {
                                          c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),

@@ -1,0 +1,181 @@
+// insmos_amd/csrc/bev.hip -- the dense BEV backbone convolution (base_bev_backbone.py:33-61: ZeroPad2d(1) + Conv2d(3x3) /
+// Conv2d(3x3, padding 1), each followed by BatchNorm2d + ReLU) as an LDS-tiled implicit GEMM on the matrix cores.
+//
+// 40 % of the window's flops are these six dense layers.  Run through the sparse gather kernel (a 9-tap table over all
+// sites) every tap re-gathers its 16 rows from global memory and every 16-row tile re-reads the whole 3x3xCinxCout weight
+// set from L2 -- the layer is L2-bandwidth bound at ~55 % of the MFMA peak.  Here a workgroup owns a TH x 16 patch of one
+// image and ALL output channels:
+//   * the patch's input halo ((TH+2) x 18 sites) is staged in LDS one 16-channel chunk at a time (double buffered: the next
+//     chunk's global loads are in flight during the current chunk's MFMAs), so every input element is read from global
+//     memory once per workgroup instead of nine times per output-channel group;
+//   * the four waves split the patch 2 (row halves) x 2 (output-channel halves): a wave keeps TH/2 row groups x COT channel
+//     tiles of accumulators, so each 1 KiB weight fragment it loads feeds TH/2 row groups (4x fewer weight bytes per
+//     flop than a 16-row tile) and each B fragment it reads from LDS feeds COT channel tiles;
+//   * B fragments are `ds_read_b128` at a 96-byte site pitch: with lane (g, j) reading the 16 bytes of channel group g
+//     of site j, a 6-slot pitch puts the 16 lanes of every hardware lane group of ds_read_b128 on 16 distinct 16-byte bank
+//     slots (brute-forced over the gfx950 lane groups, MI355X_MICROARCH.md section LDS): conflict-free.
+// Arithmetic: v_mfma_f32_16x16x4_f32, exact fp32, fixed summation order (chunk, tap, 4 channel steps): deterministic,
+// every output site a function of its own 3x3 neighbourhood only.  Weights are the same pre-packed A fragments
+// k_sparse_conv uses ([tap][chunk][channel tile][lane][4]); fragment roles as there: i = output channel, j = site.
+#include "common.h"
+
+namespace insmos {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define BEV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int BEV_TW = 16;           // sites per row group (x extent of a patch)
+constexpr int BEV_HW = BEV_TW + 2;   // halo width
+constexpr int BEV_PITCH = 24;        // floats per halo site in LDS: 16 channels + 8 pad = 96 bytes (conflict-free, see above)
+
+template <int TH, int COT>
+__global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty) {
+    constexpr int JT = TH / 2;                          // row groups per wave
+    constexpr int NSITE = (TH + 2) * BEV_HW;            // halo sites
+    constexpr int NQ = (NSITE * 4 + 255) / 256;         // float4 pieces per thread per chunk
+    __shared__ __attribute__((aligned(16))) float halo[2][NSITE * BEV_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wave & 1, ch = wave >> 1;            // row half, output-channel half
+    const int g = lane >> 4, j = lane & 15;
+    const int bid = blockIdx.x;
+    const int tx = bid % n_tx, ty = (bid / n_tx) % n_ty, img = bid / (n_tx * n_ty);
+    const int x0 = tx * BEV_TW, y0 = ty * TH;
+    const int ntile = 2 * COT;
+
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_img * H * W * ld_x * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((size_t)9 * n16 * ntile * 1024), 0x00020000);
+
+    // ---- the thread's pieces of a halo chunk: byte offset in x (out of range -> the buffer load returns 0: zero padding
+    // at the image border and beyond the patch list) and float offset in the LDS image
+    uint32_t src[NQ], dst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + 256 * q;
+        const int s = i >> 2, quarter = i & 3;
+        const int hy = s / BEV_HW, hx = s % BEV_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = i < NSITE * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        src[q] = ok ? (uint32_t)((((size_t)img * H + gy) * W + gx) * (size_t)ld_x * 4u + quarter * 16u) : 0xFFFFFFF0u;
+        dst[q] = i < NSITE * 4 ? (uint32_t)(s * BEV_PITCH + quarter * 4) : 0xFFFFFFFFu;
+    }
+    f32x4 pf[NQ];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            pf[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, src[q], (uint32_t)c * 64u, 0));
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (dst[q] != 0xFFFFFFFFu) *(f32x4*)(&halo[buf][dst[q]]) = pf[q];
+    };
+
+    f32x4 acc[COT][JT];
+#pragma unroll
+    for (int it = 0; it < COT; ++it)
+#pragma unroll
+        for (int r = 0; r < JT; ++r) acc[it][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS float offset of this lane's B fragment for tap (0, 0) of row group r: site (rh*JT + r, j), channels 4g..4g+3
+    uint32_t boff[JT];
+#pragma unroll
+    for (int r = 0; r < JT; ++r) boff[r] = (uint32_t)(((rh * JT + r) * BEV_HW + j) * BEV_PITCH + 4 * g);
+    // byte offset of this lane's A fragment inside a (tap, chunk) block of `ntile` fragments
+    const uint32_t aoff = (uint32_t)((ch * COT) * 1024 + lane * 16);
+    const uint32_t blk_bytes = (uint32_t)ntile * 1024u;          // one (tap, chunk) block
+    const uint32_t tap_bytes = (uint32_t)n16 * blk_bytes;
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    f32x4 a[3][COT];  // weight ring: item (c, k) lives in slot k % 3 (9 taps = 3 turns: the slot of a tap is chunk-independent)
+    auto load_a = [&](int slot, int k, int c) {
+        const uint32_t so = (uint32_t)k * tap_bytes + (uint32_t)c * blk_bytes;
+#pragma unroll
+        for (int it = 0; it < COT; ++it)
+            a[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, aoff + (uint32_t)it * 1024u, so, 0));
+    };
+    load_a(0, 0, 0);
+    for (int c = 0; c < n16; ++c) {
+        const int buf = c & 1;
+        const float* hb = halo[buf];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            // next item's weights: tap k+1 of this chunk, or tap 0 of the next chunk (clamped on the very last item)
+            if (k < 8) load_a((k + 1) % 3, k + 1, c);
+            else load_a(0, 0, c + 1 < n16 ? c + 1 : c);
+            // the next chunk's halo: requested behind the second tap's weights (so that the first tap's MFMAs wait for
+            // their own operands only), in flight during the rest of this chunk's MFMAs
+            if (k == 1 && c + 1 < n16) fetch(c + 1);
+            const int ky = k / 3, kx = k % 3;
+            f32x4 b[JT];
+#pragma unroll
+            for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (ky * BEV_HW + kx) * BEV_PITCH);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < JT; ++r)
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
+        }
+        if (c + 1 < n16) stage(buf ^ 1);  // (that buffer was last read in chunk c-1; every wave is past that barrier)
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (g, j) holds channels co0..co0+3 of site (y, x0 + j)
+    const int gx = x0 + j;
+#pragma unroll
+    for (int r = 0; r < JT; ++r) {
+        const int gy = y0 + rh * JT + r;
+        if (gy >= H || gx >= W) continue;
+        float* op = out + (((size_t)img * H + gy) * W + gx) * (size_t)ld_out;
+#pragma unroll
+        for (int it = 0; it < COT; ++it) {
+            const int co0 = (ch * COT + it) * 16 + 4 * g;
+            f32x4 v = acc[it][r] + *(const f32x4*)(bias + co0);
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *(f32x4*)(op + co0) = v;
+        }
+    }
+}
+
+}  // namespace insmos
+
+using namespace insmos;
+
+// x (B, H, W, cin) NHWC with row pitch ld_x floats -> out (B, H, W, cout) with row pitch ld_out: 3x3, stride 1, zero
+// padding 1, + bias (folded BatchNorm) + optional ReLU.  wpacked / bias as insmos_pack_weights_host(taps (9, cin, cout))
+// with tap = ky * 3 + kx.  Supported: cin a multiple of 16, cout = 128 or 64.
+extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                                  float* out, int ld_out, int cout, int relu, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
+    if (!x || !wpacked || !bias || !out || cin <= 0 || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || (cout != 128 && cout != 64) ||
+        ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
+        (int64_t)B * H * W * ld_x * 4 >= (1ll << 31))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int n16 = cin / 16;
+    const int n_tx = (W + BEV_TW - 1) / BEV_TW;
+    // 8-row patches when that still gives every CU a workgroup, else 4-row patches (a single image)
+    const bool tall = (int64_t)B * ((H + 7) / 8) * n_tx >= 256;
+    const int th = tall ? 8 : 4;
+    const int n_ty = (H + th - 1) / th;
+    const unsigned grid = (unsigned)((int64_t)B * n_ty * n_tx);
+    ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = 9; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = (int64_t)B * H * W;
+#define BEV_GO(TH_, COT_) \
+    INSMOS_LAUNCH((k_bev_conv3x3<TH_, COT_>), dim3(grid), dim3(256), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, out, ld_out, relu, n_tx, n_ty)
+    if (cout == 128) { if (tall) BEV_GO(8, 4); else BEV_GO(4, 4); }
+    else             { if (tall) BEV_GO(8, 2); else BEV_GO(4, 2); }
+#undef BEV_GO
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}

@@ -36,6 +36,7 @@ struct ProfScope {
     int kind;
     hipStream_t s;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    int64_t meta[4] = {0, 0, 0, 0};  // launch-site figures kept with the span (insmos_prof_read_spans)
     ProfScope(int kind, hipStream_t s);
     ~ProfScope();
 };

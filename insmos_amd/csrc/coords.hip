@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ o
 // window index is the leading digit of the cell key (key = b * cells + lin), first-seen order and the voxel cap are PER
 // WINDOW, as the reference calls VoxelGenerate once per batch item (models/models.py:326).
 __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, const int32_t* __restrict__ win_start, int B,
-                           float lx, float ly, float lz, float vx, float vy, float vz, int gx, int gy, int gz,
+                           uint64_t key_cells, float lx, float ly, float lz, float vx, float vy, float vz, int gx, int gy, int gz,
                            uint64_t* __restrict__ keys, int64_t* __restrict__ pcid, int32_t* __restrict__ mark,
                            int32_t* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -389,7 +389,7 @@ __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, con
     if (in) {
         const uint64_t b = win_start ? (uint64_t)win_of_row(win_start, B, i) : 0ull;
         uint64_t lin = ((uint64_t)(int)cz * (uint64_t)gy + (uint64_t)(int)cy) * (uint64_t)gx + (uint64_t)(int)cx;
-        lin += b * ((uint64_t)gx * (uint64_t)gy * (uint64_t)gz);
+        lin += b * key_cells;
         k = (lin << VOX_IDX_BITS) | (uint64_t)i;
         atomicAdd(&counts[2], 1);
     }
@@ -437,7 +437,8 @@ __global__ void k_vox_offsets(const int32_t* __restrict__ win_start, int B, int6
 __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat, const uint64_t* __restrict__ keys_s,
                                const int32_t* __restrict__ sid_scan, int64_t n, const int32_t* __restrict__ seg_start,
                                const int32_t* __restrict__ seg_first, const int32_t* __restrict__ rank_scan,
-                               const int32_t* __restrict__ woff, int B, int gx, int gy, int gz, int max_voxels, int max_pts,
+                               const int32_t* __restrict__ woff, int B, uint64_t key_cells, int gx, int gy, int max_voxels,
+                               int max_pts,
                                float* __restrict__ feat, int ld_feat, int32_t* __restrict__ coords,
                                int32_t* __restrict__ num_points, int64_t* __restrict__ pcid, uint64_t* __restrict__ ukeys,
                                int32_t* __restrict__ uperm, const int32_t* __restrict__ counts) {
@@ -449,9 +450,8 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
     int end = (sid + 1 < S) ? seg_start[sid + 1] : n_valid;
     uint64_t lin = keys_s[start] >> VOX_IDX_BITS;   // b * cells + cell
     ukeys[sid] = lin;
-    const uint64_t cells = (uint64_t)gx * (uint64_t)gy * (uint64_t)gz;
-    const int b = (int)(lin / cells);
-    lin -= (uint64_t)b * cells;
+    const int b = (int)(lin / key_cells);
+    lin -= (uint64_t)b * key_cells;
     const int local = rank_scan[seg_first[sid]] - 1 - woff[b];  // first-come order inside the window
     const bool kept = local < max_voxels;
     const int vid = woff[B + 1 + b] + local;
@@ -902,11 +902,13 @@ extern "C" size_t insmos_voxelize_mean_ws_bytes(int64_t n) {
 
 // win_start (device, B + 1 int32, or null for one window): first point of each window in the window-major point array.
 // Voxel rows are window-major: window b owns rows [counts[4+b], counts[4+b+1]), each window in its own first-seen order and
-// capped at max_voxels on its own; coords column 0 = b; pc_voxel_id holds batch-wide rows; ukeys = b * cells + cell.
+// capped at max_voxels on its own; coords column 0 = b; pc_voxel_id holds batch-wide rows; ukeys = b * key_cells + cell,
+// key_cells = cells per window of the keys the level-1 tables are searched with (the spconv spatial shape is one cell
+// deeper than the voxel grid, spconv_unet.py:114; 0 = the voxel grid's own cell count).
 // counts: [0] voxel rows, [1] occupied cells, [2] in-range points, and when win_start is given [4 .. 4+B] row starts
 // (5 + B int32 slots).
 extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start,
-                                            int B, const float* range_host, const float* vsize_host, int max_voxels,
+                                            int B, int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels,
                                             int max_pts, float* feat, int ld_feat, int32_t* coords, int32_t* num_points,
                                             int64_t* pc_voxel_id, uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws,
                                             size_t ws_bytes, void* stream) {
@@ -918,7 +920,10 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
     int g3[3];
     for (int d = 0; d < 3; ++d)
         g3[d] = (int)llround(((double)range_host[3 + d] - (double)range_host[d]) / (double)vsize_host[d]);
-    uint64_t max_lin = (uint64_t)g3[0] * g3[1] * g3[2] * (uint64_t)B;
+    const uint64_t grid_cells = (uint64_t)g3[0] * g3[1] * g3[2];
+    if (key_cells == 0) key_cells = (int64_t)grid_cells;
+    if ((uint64_t)key_cells < grid_cells) return INSMOS_EINVAL;
+    uint64_t max_lin = (uint64_t)key_cells * (uint64_t)B;
     int end_bit = VOX_IDX_BITS + bits_for(max_lin);
     if (end_bit > 63) return INSMOS_EINVAL;
     Bump b(ws, ws_bytes);
@@ -939,7 +944,7 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
     unsigned g = cdiv(n, TPB);
     {
         ProfScope ps(KK_VOX_KEYS, s);
-        INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, win_start, B,
+        INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, win_start, B, (uint64_t)key_cells,
                       range_host[0], range_host[1], range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1],
                       g3[2], k_in, pc_voxel_id, mark, counts);
     }
@@ -963,7 +968,7 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
         INSMOS_LAUNCH(k_vox_offsets, dim3(1), dim3(64), 0, s, win_start, B, n, rank_scan, sid_scan,
                       max_voxels, woff, counts);
         INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
-                      seg_first, rank_scan, woff, B, g3[0], g3[1], g3[2], max_voxels, max_pts, feat, ld_feat, coords,
+                      seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
                       num_points, pc_voxel_id, ukeys, uperm, counts);
     }
     HIP_TRY(hipGetLastError());
@@ -975,7 +980,7 @@ extern "C" int insmos_voxelize_mean(const float* points, int64_t n, int ld_pts, 
                                     const float* vsize_host, int max_voxels, int max_pts, float* feat, int ld_feat,
                                     int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
                                     int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
-    return insmos_voxelize_mean_windows(points, n, ld_pts, n_feat, nullptr, 1, range_host, vsize_host, max_voxels, max_pts, feat,
+    return insmos_voxelize_mean_windows(points, n, ld_pts, n_feat, nullptr, 1, 0, range_host, vsize_host, max_voxels, max_pts, feat,
                                         ld_feat, coords, num_points, pc_voxel_id, ukeys, uperm, counts, ws, ws_bytes, stream);
 }
 
@@ -1109,6 +1114,7 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = 125; ps.meta[1] = 1; ps.meta[2] = 8; ps.meta[3] = n_f;
     INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
                        w125x8, bias8, out, ld_out, relu, (int64_t)0);

@@ -11,6 +11,7 @@
 // insmos_amd/engine.py carries the same graph in inspectable form and tests/test_gpu_model.py asserts that both
 // produce identical bits.  All device memory comes from a caller-provided arena (bump-allocated per window).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -314,7 +315,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         const size_t mark = A.off;
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
-        CK(insmos_voxelize_mean_windows(cur, ncur, 8, g.in_ch, cur_start_dev, B, g.range, g.vs, g.max_voxels, g.max_points, feat,
+        CK(insmos_voxelize_mean_windows(cur, ncur, 8, g.in_ch, cur_start_dev, B,
+                                        (int64_t)g.shape[1][0] * g.shape[1][1] * g.shape[1][2], g.range, g.vs, g.max_voxels, g.max_points, feat,
                                         8, coords1, num_points, pcid, ukeys, uperm, counts, ws, wsb, s));
         CK(read_counts(counts, hc, 5 + B, s));
         A.off = mark;
@@ -427,11 +429,24 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     int32_t* nbr_bev_b = B > 1 ? A.take<int32_t>((size_t)9 * nsite) : nullptr;
     NEED_ARENA();
     CK(insmos_sparse_to_bev_b(enc, 128, 128, co[5], nv[5], g.bevD, g.bevH, g.bevW, B, bev, s));
-    if (B > 1) CK(insmos_dense_nbr2d_b(g.bevH, g.bevW, B, nbr_bev_b, s));
     Table tb{B > 1 ? nbr_bev_b : const_cast<int32_t*>(g.nbr_bev), nullptr, 9, nsite};
-    CK(conv("bev0", bev, nsite, g.nbev, 0, &tb, nsite, fa, nf, 0, nullptr, 0, 0, 0, 0, 1));
+    bool tb_ready = B == 1;  // (a batch builds its stacked 9-tap table only if a layer falls back to the generic kernel)
+    // the dense 3x3 layers: LDS-tiled implicit GEMM (csrc/bev.hip) for the shapes it is built for, else the 9-tap table
+    static const bool bev_kernel = [] { const char* e = getenv("INSMOS_BEV_KERNEL"); return !(e && e[0] == '0'); }();
+    auto bev_conv = [&](const std::string& name, const float* x, int ld_in, float* o) -> int {
+        const InsmosConvW* w = Lr(name);
+        if (!w) return INSMOS_EINVAL;
+        if (bev_kernel && w->K == 9 && w->cin % 16 == 0 && (w->cout == 64 || w->cout == 128))
+            return insmos_bev_conv3x3(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, s);
+        if (!tb_ready) {
+            CK(insmos_dense_nbr2d_b(g.bevH, g.bevW, B, nbr_bev_b, s));
+            tb_ready = true;
+        }
+        return conv(name.c_str(), x, nsite, ld_in, 0, &tb, nsite, o, nf, 0, nullptr, 0, 0, 0, 0, 1);
+    };
+    CK(bev_conv("bev0", bev, g.nbev, fa));
     for (int k = 0; k < g.n_bev_layers; ++k) {
-        CK(conv(("bev" + std::to_string(k + 1)).c_str(), fa, nsite, nf, 0, &tb, nsite, fb, nf, 0, nullptr, 0, 0, 0, 0, 1));
+        CK(bev_conv("bev" + std::to_string(k + 1), fa, nf, fb));
         std::swap(fa, fb);
     }
     {

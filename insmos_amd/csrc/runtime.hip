@@ -9,7 +9,7 @@ namespace insmos {
 int g_last_hip_error = 0;
 
 static bool g_prof = false;
-struct Span { int kind; hipEvent_t e0, e1; };
+struct Span { int kind; hipEvent_t e0, e1; int64_t meta[4]; };
 static std::vector<Span> g_spans;
 static std::mutex g_mu;
 static const char* kNames[KK_COUNT] = {
@@ -29,7 +29,7 @@ ProfScope::~ProfScope() {
     if (!e0) return;
     (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_spans.push_back({kind, e0, e1});
+    g_spans.push_back({kind, e0, e1, {meta[0], meta[1], meta[2], meta[3]}});
 }
 }  // namespace insmos
 
@@ -62,6 +62,24 @@ extern "C" int insmos_prof_read(int max, int* kind_ids_host, double* total_ms_ho
     for (int k = 0; k < KK_COUNT && n < max; ++k) {
         if (!cnt[k]) continue;
         kind_ids_host[n] = k; total_ms_host[n] = tot[k]; launches_host[n] = cnt[k]; ++n;
+    }
+    return n;
+}
+
+// Per-launch durations of one kernel kind in record order, with the four integers the launch site attached (the conv
+// launcher records K, Cin, Cout and the rows computed): tools/batch_layers.py lines them up with the layer list.
+extern "C" int insmos_prof_read_spans(int kind_id, int max, double* ms_host, int64_t* meta4_host) {
+    if (!ms_host || !meta4_host || max <= 0) return INSMOS_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (auto& sp : g_spans) {
+        if (sp.kind != kind_id || n >= max) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.e0, sp.e1) != hipSuccess) continue;
+        ms_host[n] = ms;
+        for (int i = 0; i < 4; ++i) meta4_host[4 * n + i] = sp.meta[i];
+        ++n;
     }
     return n;
 }

@@ -684,6 +684,7 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     const long nblocks = split == 1 ? tiles : (tiles + (4 / split) - 1) / (4 / split);
     dim3 grid((unsigned)nblocks), block(64 * wpb);
     ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
     INSMOS_LAUNCH(kern, grid, block, 0, s, P);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
@@ -715,6 +716,7 @@ extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int 
     hipStream_t s = (hipStream_t)stream;
     const long groups = (long)((n_site + 15) / 16);
     ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = 1; ps.meta[1] = cin; ps.meta[2] = 4 * cup; ps.meta[3] = n_site;
     INSMOS_LAUNCH(k_deconv_head<16>, dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed, bd,
                   wh_packed, bh, head, ld_head, head_cout);
     HIP_TRY(hipGetLastError());

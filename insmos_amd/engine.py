@@ -12,6 +12,7 @@ Eval-mode BatchNorm is folded into the conv taps; channel concatenations (ME.cat
 UR blocks and the instance one-hots) are free: producers write into column slices of shared rows.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -116,6 +117,7 @@ class Engine:
         self.native = native      # default path of forward_window (see there)
         self.prune_dead_rows = True  # MotionNet decoder layers skip rows nothing consumes
         self.fuse_deconv_head = True  # BEV deblock + heads in one kernel (the step path can run them separately)
+        self.dense_bev_kernel = os.environ.get("INSMOS_BEV_KERNEL", "1") != "0"  # LDS-tiled 3x3 kernel for the BEV backbone
         self.keep_current_points = False  # 'eval' mode: keep current_point (Ncur, 8) of the last window (motion loss)
         self.last_current_points = None
         self._ctx_box = [None]    # native context, shared with clones
@@ -285,6 +287,19 @@ class Engine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
             self.layer_timing.append((layer.name, K, layer.cin, layer.cout, n_out, self._t0, e1))
+
+    def bev_conv(self, layer, x, ld_in, out, ld_out):
+        """One 3x3 layer of the dense BEV backbone (+ folded BN + ReLU): the LDS-tiled kernel (csrc/bev.hip) when the layer
+        has a shape it is built for, else the generic kernel over the dense 9-tap table."""
+        nsite = self.bevH * self.bevW
+        if self.dense_bev_kernel and layer.cin % 16 == 0 and layer.cout in (64, 128):
+            _lib.check(self.lib.insmos_bev_conv3x3(x.data_ptr(), 1, self.bevH, self.bevW, ld_in, layer.cin, layer.w.data_ptr(),
+                                                   layer.b.data_ptr(), out.data_ptr(), ld_out, layer.cout, 1, self._stream()),
+                       "insmos_bev_conv3x3")
+            self._conv_log.append((self.nbr_bev, nsite, layer, 0))
+            self._conv_nin.append(nsite)
+        else:
+            self.conv(layer, x, ld_in, self.nbr_bev, nsite, out, ld_out, relu_post=1)
 
     def build_nbr(self, out_coords, n_out, in_keys, in_perm, n_in, mode, shape, delta, mul=None, div=None):
         K = len(delta)
@@ -643,9 +658,9 @@ class Engine:
                                             self.bevW, bev.data_ptr(), st), "insmos_sparse_to_bev")
         nf = L["bev0"].cout
         fa, fb = E((nsite, nf)), E((nsite, nf))
-        self.conv(L["bev0"], bev, self.nbev, self.nbr_bev, nsite, fa, nf, relu_post=1)
+        self.bev_conv(L["bev0"], bev, self.nbev, fa, nf)
         for k in range(self.n_bev_layers):
-            self.conv(L[f"bev{k + 1}"], fa, nf, self.nbr_bev, nsite, fb, nf, relu_post=1)
+            self.bev_conv(L[f"bev{k + 1}"], fa, nf, fb, nf)
             fa, fb = fb, fa
         upc = self.up_ch
         ncell = 4 * nsite

@@ -60,7 +60,7 @@ class InsMOS_Model:
         if windows_in_flight is None:
             windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "2"))
         if windows_per_launch is None:
-            windows_per_launch = int(os.environ.get("INSMOS_WINDOWS_PER_LAUNCH", "4"))
+            windows_per_launch = int(os.environ.get("INSMOS_WINDOWS_PER_LAUNCH", "8"))
         self.windows_in_flight = max(1, int(windows_in_flight))         # launch sets (groups) in flight
         self.windows_per_launch = max(1, min(int(windows_per_launch), MAX_WINDOWS_PER_LAUNCH))
         self._engine = None

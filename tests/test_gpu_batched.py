@@ -67,15 +67,20 @@ def test_batched_forward_with_voxel_cap_and_order_independence(setup):
     """max_voxels is a PER-WINDOW cap (the reference voxelises each batch item on its own, models/models.py:326): windows
     that hit it and windows that do not share a batch; and a window's result does not depend on its slot in the batch."""
     from insmos_amd.engine import Engine
-    cap = 2500
-    eng = Engine(setup["cfg"], setup["sd"], native=True, max_voxels=cap)
     wins = setup["dev"][:5]
+    free = Engine(setup["cfg"], setup["sd"], native=True)
+    uncapped = []
+    for w in wins:
+        free.forward_windows([w])
+        uncapped.append(free.last_counts["unet_voxels"][0])
+    cap = sorted(uncapped)[2]            # the median: two windows exceed it, one meets it exactly, two stay below
+    eng = Engine(setup["cfg"], setup["sd"], native=True, max_voxels=cap)
     single = [eng.forward_windows([w])[0] for w in wins]
     vox = []
     for w in wins:
         eng.forward_windows([w])
         vox.append(eng.last_counts["unet_voxels"][0])
-    assert max(vox) == cap and min(vox) < cap, vox
+    assert vox == [min(v, cap) for v in uncapped] and max(uncapped) > cap > min(uncapped), (vox, uncapped)
     batched = eng.forward_windows(wins)
     assert [pw["voxels"] for pw in eng.last_counts["per_window"]] == vox
     for s, b in zip(single, batched):
@@ -141,7 +146,7 @@ def test_voxelize_windows_is_per_window_voxelisation(setup):
     cap, max_pts = 1500, 5
     hp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
 
-    def run(points, starts):
+    def run(points, starts, key_cells=0):
         n = len(points)
         B = len(starts) - 1
         d = torch.from_numpy(points).cuda()
@@ -154,21 +159,24 @@ def test_voxelize_windows_is_per_window_voxelisation(setup):
         counts = torch.zeros(8 + B, dtype=torch.int32, device="cuda")
         st = torch.tensor(starts, dtype=torch.int32, device="cuda")
         w = ws(L.insmos_voxelize_mean_ws_bytes(n))
-        _lib.check(L.insmos_voxelize_mean_windows(d.data_ptr(), n, 8, 7, st.data_ptr(), B, hp(prange), hp(vs), cap, max_pts,
+        _lib.check(L.insmos_voxelize_mean_windows(d.data_ptr(), n, 8, 7, st.data_ptr(), B, key_cells, hp(prange), hp(vs), cap, max_pts,
                                                   feat.data_ptr(), 8, coords.data_ptr(), npts.data_ptr(), pcid.data_ptr(),
                                                   uk.data_ptr(), up.data_ptr(), counts.data_ptr(), w.data_ptr(), w.numel(),
                                                   stream()), "voxelize_windows")
         torch.cuda.synchronize()
         c = counts.cpu().numpy()
-        return feat.cpu().numpy(), coords.cpu().numpy(), npts.cpu().numpy(), pcid.cpu().numpy(), c
+        return feat.cpu().numpy(), coords.cpu().numpy(), npts.cpu().numpy(), pcid.cpu().numpy(), c, uk.cpu().numpy()[:int(c[1])]
 
     starts = np.concatenate([[0], np.cumsum(sizes)]).tolist()
-    fb, cb, nb, pb, cnt = run(np.concatenate(clouds), starts)
+    KC = 41 * 1000 * 1200       # the level-1 spatial shape is one cell deeper than the 40-cell voxel grid (spconv_unet.py:114)
+    fb, cb, nb, pb, cnt, ukb = run(np.concatenate(clouds), starts, KC)
+    uk_single = []
     rows = cnt[4:4 + len(sizes) + 1]
     assert cnt[0] == rows[-1]
     hit_cap = 0
     for b, p in enumerate(clouds):
-        f1, c1, n1, p1, k1 = run(p, [0, len(p)])
+        f1, c1, n1, p1, k1, uk1 = run(p, [0, len(p)])
+        uk_single.append(uk1 + b * KC)
         v = int(k1[0])
         hit_cap += v == cap
         assert rows[b + 1] - rows[b] == v
@@ -180,6 +188,7 @@ def test_voxelize_windows_is_per_window_voxelisation(setup):
         pw = pb[starts[b]:starts[b + 1]]
         np.testing.assert_array_equal(np.where(pw >= 0, pw - rows[b], -1), p1)
     assert hit_cap >= 1
+    np.testing.assert_array_equal(ukb, np.concatenate(uk_single))   # search keys: b * key_cells + cell, ascending
 
 
 def test_sparse_to_bev_kernel_vs_reference_height_compression(golden_dir):

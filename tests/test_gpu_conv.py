@@ -114,3 +114,49 @@ def test_dense_bev_convs_match_torch():
     reft = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), stride=2)[0].permute(1, 2, 0).numpy()
     got = yt.transpose(0, 2, 1, 3, 4).reshape(2 * H, 2 * W, co)
     np.testing.assert_allclose(got, reft, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,ci,co", [(1, 13, 17, 32, 128), (2, 19, 35, 64, 64), (3, 125, 150, 128, 128), (1, 8, 16, 256, 128)])
+def test_bev_conv3x3_kernel_matches_torch_conv2d(B, H, W, ci, co):
+    """insmos_bev_conv3x3 (csrc/bev.hip: LDS-tiled implicit GEMM, base_bev_backbone.py:33-61) against torch conv2d + bias +
+    ReLU on B stacked NHWC images -- patch borders, image borders (zero padding), partial patches, both patch heights --
+    and against the generic kernel over the dense 9-tap table (same function, another summation order)."""
+    from gpu_util import dev, pack_layer, run_conv, lib, stream
+    from insmos_amd import params as P, _lib
+    rng = np.random.default_rng(B * 1000 + H)
+    x = rng.normal(size=(B, ci, H, W)).astype(np.float32)
+    w = (rng.normal(size=(co, ci, 3, 3)) * (1.0 / np.sqrt(9 * ci))).astype(np.float32)
+    bias = rng.normal(size=co).astype(np.float32)
+    layer = pack_layer(P.conv2d_weight_to_taps(w), bias, ci, co)
+    ld = ci + 16                                                      # a row pitch wider than the channel count
+    xs = torch.zeros((B * H * W, ld), device="cuda:0")
+    xs[:, :ci] = dev(np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(B * H * W, ci)))
+    ref = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(bias), padding=1))
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, co).numpy()
+    for relu in (1, 0):
+        out = torch.full((B * H * W, co + 4), 9.0, device="cuda:0")
+        _lib.check(lib().insmos_bev_conv3x3(xs.data_ptr(), B, H, W, ld, ci, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(),
+                                            co + 4, co, relu, stream()), "insmos_bev_conv3x3")
+        torch.cuda.synchronize()
+        y = out.cpu().numpy()
+        assert (y[:, co:] == 9.0).all()                                # nothing written beyond the channel count
+        if relu:
+            np.testing.assert_allclose(y[:, :co], ref, rtol=1e-4, atol=1e-4)
+        else:
+            lin = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(bias), padding=1)
+            np.testing.assert_allclose(y[:, :co], lin.permute(0, 2, 3, 1).reshape(B * H * W, co).numpy(), rtol=1e-4, atol=1e-4)
+            assert (y[:, :co] < 0).any()
+    nbr = torch.empty((9, B * H * W), dtype=torch.int32, device="cuda:0")
+    _lib.check(lib().insmos_dense_nbr2d_b(H, W, B, nbr.data_ptr(), stream()), "dense_nbr2d_b")
+    yt = run_conv(layer, xs, nbr, B * H * W, relu_post=1).cpu().numpy()
+    np.testing.assert_allclose(yt, ref, rtol=1e-4, atol=1e-4)
+    out = torch.zeros((B * H * W, co), device="cuda:0")
+    _lib.check(lib().insmos_bev_conv3x3(xs.data_ptr(), B, H, W, ld, ci, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(),
+                                        co, co, 1, stream()), "insmos_bev_conv3x3")
+    assert float((out.cpu() - torch.from_numpy(yt)).abs().max()) < 1e-4
+    # the patch a site falls into does not matter: image 0 alone == image 0 of the stack
+    if B > 1:
+        one = torch.zeros((H * W, co), device="cuda:0")
+        _lib.check(lib().insmos_bev_conv3x3(xs.data_ptr(), 1, H, W, ld, ci, layer.w.data_ptr(), layer.b.data_ptr(), one.data_ptr(),
+                                            co, co, 1, stream()), "insmos_bev_conv3x3")
+        assert torch.equal(one, out[:H * W])

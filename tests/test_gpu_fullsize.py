@@ -111,7 +111,8 @@ def test_s0_full_size_against_the_oracle():
     lab, lab_ref = R.output_stage(got)[0], R.output_stage(ref_logits)[0]
     top2 = np.sort(ref_logits[:, 1:], axis=1)
     decided = (top2[:, -1] - top2[:, -2]) > 2 * err
-    assert decided.mean() > 0.999
+    # (the 1.2 % of current points outside the voxel range carry all-zero logits: exact ties, decided by the argmax rule)
+    assert decided.mean() > 0.98 and (decided | (ref_logits == 0).all(1)).mean() > 0.999
     np.testing.assert_array_equal(lab[decided], lab_ref[decided])
     assert int((lab != lab_ref).sum()) <= 2                    # (0 in practice; undecided points are coin tosses by definition)
     pb, rb = single[1]["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"]

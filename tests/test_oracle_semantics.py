@@ -154,6 +154,88 @@ def test_voxelize_first_come_and_caps():
     np.testing.assert_allclose(R.mean_vfe(vox, num)[:, 3], [2.0, 4.0])
 
 
+def test_me_5x5x5x1_tap_order_equals_dense_conv3d_with_an_asymmetric_kernel():
+    """The first MotionNet layer (kernel [5,5,5,1], motionnet.py / minkunet.py:55-58): ME's kernel-region order is x fastest,
+    then y, z -- with a kernel that has no symmetry any other enumeration (z fastest, mirrored offsets) fails this."""
+    rng = np.random.default_rng(5)
+    xyz = np.unique(rng.integers(-7, 7, size=(700, 3)), axis=0)
+    coords = np.concatenate([xyz, np.zeros((len(xyz), 1), np.int64)], 1).astype(np.int32)
+    keys = R.key4(coords)
+    order = np.argsort(keys)
+    coords, keys = coords[order], keys[order]
+    x = rng.normal(size=(len(coords), 2)).astype(np.float32)
+    taps = rng.normal(size=(125, 2, 3)).astype(np.float32)
+    taps[0] += 5.0            # tap 0 = offset (-2, -2, -2): a strongly marked corner
+    nbr = R.me_nbr(coords, keys, R.me_kernel_offsets([5, 5, 5, 1], [1, 1, 1, 1]))
+    y = R.sparse_conv(x, nbr, taps)
+    g = coords[:, :3] + 7
+    dense = np.zeros((2, 14, 14, 14), np.float32)      # [c][z][y][x]
+    dense[:, g[:, 2], g[:, 1], g[:, 0]] = x.T
+    wd = torch.from_numpy(taps.reshape(5, 5, 5, 2, 3).transpose(4, 3, 0, 1, 2).copy())   # tap = ix + 5*iy + 25*iz -> [co][ci][kz][ky][kx]
+    yd = F.conv3d(torch.from_numpy(dense)[None], wd, padding=2)[0].numpy()
+    np.testing.assert_allclose(y, yd[:, g[:, 2], g[:, 1], g[:, 0]].T, rtol=1e-4, atol=1e-4)
+    # and the enumeration with z fastest is NOT the same function (the test has teeth)
+    wz = torch.from_numpy(taps.reshape(5, 5, 5, 2, 3).transpose(4, 3, 2, 1, 0).copy())
+    yz = F.conv3d(torch.from_numpy(dense)[None], wz, padding=2)[0].numpy()
+    assert np.abs(y - yz[:, g[:, 2], g[:, 1], g[:, 0]].T).max() > 1.0
+
+
+def test_me_4d_conv_does_not_reach_across_a_missing_time_slice():
+    """A 3^4 kernel spans t-1 .. t+1 in COORDINATE units: with the scan at t = -1 missing, the voxels at t = 0 must not see
+    the scan at t = -2 (a table built on slice RANKS instead of time coordinates would).  Dense equivalent: an empty slice."""
+    rng = np.random.default_rng(6)
+    T = 4
+    xyz = np.unique(rng.integers(-5, 5, size=(400, 3)), axis=0)
+    parts = []
+    for t in (-3, -2, 0):                                  # t = -1 is absent
+        sel = xyz[rng.random(len(xyz)) < 0.7]
+        parts.append(np.concatenate([sel, np.full((len(sel), 1), t)], 1))
+    coords = np.concatenate(parts).astype(np.int32)
+    keys = R.key4(coords)
+    order = np.argsort(keys)
+    coords, keys = coords[order], keys[order]
+    x = rng.normal(size=(len(coords), 3)).astype(np.float32)
+    taps = rng.normal(size=(81, 3, 4)).astype(np.float32)
+    nbr = R.me_nbr(coords, keys, R.me_kernel_offsets([3, 3, 3, 3], [1, 1, 1, 1]))
+    y = R.sparse_conv(x, nbr, taps)
+    g = coords.copy()
+    g[:, :3] += 5
+    g[:, 3] += T - 1
+    dense = np.zeros((T, 3, 10, 10, 10), np.float32)
+    dense[g[:, 3], :, g[:, 2], g[:, 1], g[:, 0]] = x
+    w = taps.reshape(3, 3, 3, 3, 3, 4)
+    out = np.zeros((T, 4, 10, 10, 10), np.float32)
+    for to in range(T):
+        for it in range(3):
+            ti = to + it - 1
+            if 0 <= ti < T:
+                out[to] += F.conv3d(torch.from_numpy(dense[ti])[None], torch.from_numpy(w[it].transpose(4, 3, 0, 1, 2).copy()),
+                                    padding=1)[0].numpy()
+    np.testing.assert_allclose(y, out[g[:, 3], :, g[:, 2], g[:, 1], g[:, 0]], rtol=1e-4, atol=1e-4)
+    cur = coords[:, 3] == 0
+    past_taps = nbr[:27][:, cur]                           # it = 0 <-> t - 1: nothing there for the current scan
+    assert (past_taps < 0).all() and (nbr[27:54][:, cur] >= 0).any()
+
+
+def test_voxel_cap_and_point_cap_interplay():
+    """spconv's CPU PointToVoxel walk (voxel_generate.py:19-28 -> generate_voxel_with_id): points are visited in order; a point
+    whose cell is new opens a voxel only while fewer than max_voxels exist -- afterwards the cell is dropped for good (-1) --
+    while points of cells opened EARLIER keep their voxel id even beyond max_num_points, and only the first max_num_points of
+    a voxel enter its mean."""
+    A, B, C, D = [0.05, 0.05, -2.95], [5.0, 5.0, 0.0], [-3.0, 2.0, 0.5], [7.0, -7.0, -1.0]
+    seq = [A, B, C, A, A, A, B, C, D, A]                   # cap 2 voxels, 3 points: C and D never get a voxel
+    pts = np.array([p + [float(i + 1), 0, 0, 0] for i, p in enumerate(seq)], np.float32)
+    vox, co, num, pid = R.voxelize_with_id(pts, [0.1, 0.1, 0.1], [-60, -50, -3, 60, 50, 1], 2, 3)
+    np.testing.assert_array_equal(pid, [0, 1, -1, 0, 0, 0, 1, -1, -1, 0])
+    np.testing.assert_array_equal(num, [3, 2])
+    np.testing.assert_allclose(R.mean_vfe(vox, num)[:, 3], [(1 + 4 + 5) / 3.0, (2 + 7) / 2.0])   # A's 4th and 5th point are not stored
+    # with room for three voxels C is kept, D still is not; A's id does not depend on the cap
+    _, co3, num3, pid3 = R.voxelize_with_id(pts, [0.1, 0.1, 0.1], [-60, -50, -3, 60, 50, 1], 3, 3)
+    np.testing.assert_array_equal(pid3, [0, 1, 2, 0, 0, 0, 1, 2, -1, 0])
+    np.testing.assert_array_equal(num3, [3, 2, 2])
+    np.testing.assert_array_equal(co3[:2], co)
+
+
 @pytest.fixture(scope="module")
 def s0():
     from insmos_amd.synth import make_window
