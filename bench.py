@@ -107,6 +107,57 @@ def pmc_traffic(args, wpl):
     return j
 
 
+def pin_host_threads(local_rank, local_world):
+    """N ranks on one host: give every rank its own slice of the cores and a small torch intra-op pool.  A rank drives its GPU
+    from a handful of host threads (launch-set workers, HIP queue threads); torch's default pool (one thread per core, spinning)
+    times N ranks starves exactly those threads -- the effect DESIGN.md section 5 records for a single rank."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(os.cpu_count() or 1))
+    if local_world > 1 and len(cores) >= 2 * local_world:
+        per = len(cores) // local_world
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        try:
+            os.sched_setaffinity(0, mine)
+        except (AttributeError, OSError):
+            mine = cores
+        torch.set_num_threads(max(1, min(8, len(mine) // 2)))
+    else:
+        mine = cores   # a single rank keeps the host as it is (the CPU-baseline leg uses every core)
+    return len(mine)
+
+
+def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync):
+    """The timed region of the contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync
+    on both sides, the per-rank confusion counters gathered inside the region (the path's only exchange), time = MAX over
+    ranks.  Device-agnostic (tests run it on CPU over gloo with a stub model): `sync` is torch.cuda.synchronize or a no-op."""
+    import torch.distributed as dist
+    from insmos_amd.metrics import all_gather_confusion
+    for _ in range(warmup):
+        forward(batch, "test")
+    sync()
+    if world > 1:
+        dist.barrier()
+    cm = torch.zeros((3, 3), dtype=torch.int64, device=dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, _, logits = forward(batch, "test")
+        for lg, gt in zip(logits, gts):
+            metrics.compute_confusion_matrix(lg, gt, out=cm)
+    cm_all = all_gather_confusion(cm)
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * steps * len(batch) / dt   # every rank runs the same number of windows per step (weak scaling)
+    return dt, value, cm_all
+
+
 def read_profile(lib):
     ids = (ctypes.c_int * 64)()
     ms = (ctypes.c_double * 64)()
@@ -146,6 +197,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
+    host_cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     import __graft_entry__
     if rank == 0:
@@ -167,6 +219,8 @@ def main():
     pts_list = [torch.from_numpy(w).to(dev) for w in windows]
     pts = pts_list[0]
     model = InsMOSNet(cfg, state_dict=sd).cuda(local_rank).eval()
+    if world > 1 and args.calibration:   # one cache file per rank: ranks calibrate on their own first window, concurrently
+        args.calibration = f"{args.calibration}.rank{rank}"
     calibrate_head(model, pts, args.candidates, cache=args.calibration, tag=f"rank{rank}_az{args.n_az}_c{args.candidates}",
                    load_only=args.timed_only)
     eng = model.model.engine
@@ -177,27 +231,8 @@ def main():
     gts = [torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=rank * W + i)).to(dev) for i, w in enumerate(windows)]
     metrics = ClassificationMetrics(3, [0])
 
-    for _ in range(args.warmup):
-        model.forward(batch, "test")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    cm = torch.zeros((3, 3), dtype=torch.int64, device=dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, _, logits = model.forward(batch, "test")
-        for lg, gt in zip(logits, gts):
-            metrics.compute_confusion_matrix(lg, gt, out=cm)
-    cm_all = all_gather_confusion(cm)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = world * args.steps * W / dt
+    dt, value, cm_all = timed_steps(model.forward, batch, gts, metrics, args.steps, args.warmup, world, dev,
+                                    torch.cuda.synchronize)
     iou = metrics.getIoU(cm_all).cpu().numpy()
     if args.timed_only:
         if rank == 0:
@@ -233,6 +268,7 @@ def main():
                                "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)",
                    "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
                    "n_az": args.n_az, "points_per_window": int(len(window)), "current_points": ncur,
+                   "host_cores_per_rank": host_cores, "torch_threads": torch.get_num_threads(),
                    "weights": "seeded random (He-normal, occupancy-corrected), head bias calibrated to "
                               f"~{args.candidates} candidates", "parallelism": f"dp{world} (windows sharded by rank)"},
         "ms_per_window": round(1000.0 * dt / (args.steps * W), 3),

@@ -9,8 +9,8 @@ models/models.py:269-376: three lists are returned (batch items may be in flight
   recall_dicts_list[i]  = {}           (no gt_boxes on the test path, post_process.py:68-69)
   point_logits_list[i]  = (Ncur, 3) fp32 raw MOS logits, rows in the order of the t == 0 input rows.
 Model_mode 'test' (the north-star path) and 'eval' (the validation step's forward: the same path plus the two MOS losses,
-models/models.py:347-353) are implemented; 'train' is served by the separate training pieces (insmos_amd/autograd.py,
-train_motionnet.py).  No pytorch_lightning is needed: a Lightning .ckpt is a
+models/models.py:347-353) run on the inference engine; 'train' (models/models.py:313-345) is delegated to the training twin
+(insmos_amd/train_unet.py: InsMOSTrainer) and returns the reference's four values.  No pytorch_lightning is needed: a Lightning .ckpt is a
 torch-pickled dict with "hyper_parameters" and "state_dict" (models/models.py:30,52).
 """
 import os
@@ -64,7 +64,20 @@ class InsMOS_Model:
         self.windows_in_flight = max(1, int(windows_in_flight))         # launch sets (groups) in flight
         self.windows_per_launch = max(1, min(int(windows_per_launch), MAX_WINDOWS_PER_LAUNCH))
         self._engine = None
+        self._trainer = None
         self._workers = None  # (engines, streams, executor)
+
+    @property
+    def trainer(self):
+        """The training-side twin (insmos_amd/train_unet.py), built on first use from the same checkpoint.  Its parameters
+        are torch leaf tensors a caller hands to an optimiser; `trainer.unet.export_state_dict()` / tools/train_synthetic.py
+        turn them back into a checkpoint the inference engine loads."""
+        if self._trainer is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("insmos_amd needs an MI355X (torch.cuda unavailable); there is no CPU fallback")
+            from .train_unet import InsMOSTrainer
+            self._trainer = InsMOSTrainer(self.cfg, self.state_dict_ref, self.device)
+        return self._trainer
 
     @property
     def engine(self):
@@ -94,8 +107,10 @@ class InsMOS_Model:
         """'test' (models/models.py:355-359,375-376) and 'eval' (:347-353,369-373, the validation step: the same forward
         plus MOSLoss on the point logits and on the motion features, needs batch_dict["past_labels"])."""
         if Model_mode == "train":
-            raise NotImplementedError("Model_mode == 'train': the training pieces are insmos_amd.autograd / "
-                                      "insmos_amd.train_motionnet (DESIGN.md 1f); forward() serves 'test' and 'eval'")
+            # models/models.py:313-345,365-367: the same module serves the training step.  The differentiable graph lives in
+            # InsMOSTrainer (fp32 HIP forward + backward, its own leaf tensors in `self.trainer.params`); the same four
+            # values come back: (loss, train_loss_dict, gt_mos_label_list, preb_mos_lable_list).
+            return self.trainer.forward(list_batch_dict, "train")
         if Model_mode not in ("test", "eval"):
             raise ValueError(f"unknown Model_mode {Model_mode!r}")
         keep = Model_mode == "eval"

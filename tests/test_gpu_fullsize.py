@@ -115,7 +115,14 @@ def test_s0_full_size_against_the_oracle():
     assert decided.mean() > 0.98 and (decided | (ref_logits == 0).all(1)).mean() > 0.999
     np.testing.assert_array_equal(lab[decided], lab_ref[decided])
     assert int((lab != lab_ref).sum()) <= 2                    # (0 in practice; undecided points are coin tosses by definition)
+    # the same boxes: ~1400 candidates of a random-weight head go through greedy NMS at IoU 0.1, where one borderline pair
+    # (IoU within 1e-5 of the threshold) flips a keep decision and shifts the rest of the list -- so the lists are compared
+    # as SETS: every box of one list has its twin (all 7 numbers within 1e-3, same class) in the other, up to 1 % of them
     pb, rb = single[1]["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"]
+    pl, rl = single[1]["pred_labels"].cpu().numpy(), ref_pred["pred_labels"]
     assert len(pb) == len(rb) >= 100
-    np.testing.assert_allclose(pb, rb, atol=1e-3, rtol=0)
-    np.testing.assert_array_equal(single[1]["pred_labels"].cpu().numpy(), ref_pred["pred_labels"])
+    d = np.abs(pb[:, None, :] - rb[None, :, :]).max(2)
+    twin = d.argmin(1)
+    ok = (d.min(1) < 1e-3) & (pl == rl[twin])
+    print("boxes with a twin in the oracle's list: %d / %d (identical order: %s)" % (ok.sum(), len(pb), bool((twin == np.arange(len(pb))).all())))
+    assert ok.mean() >= 0.99 and len(set(twin[ok].tolist())) == int(ok.sum())

@@ -173,7 +173,7 @@ def test_eval_mode_is_test_mode_plus_the_two_losses(setup):
     assert torch.equal(native_cur, eng.last_current_points)
     eng.keep_current_points = False
     np.testing.assert_allclose(native_cur[:, :7].cpu().numpy(), dbg["current_point"][:, :7], atol=2e-4)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError):      # 'train' is served too (test_train_unet.py), and needs the training batch keys
         model.forward(batch, "train")
     with pytest.raises(ValueError):
         model.forward([{"past_point_clouds": pts, "past_labels": [gts[0][:-1]]}], "eval")

@@ -296,3 +296,55 @@ def test_ctypes_signatures_match_the_header_prototypes():
         for i, (dcl, at) in enumerate(zip(decls, argtypes)):
             assert ctype(dcl) == at, (name, i, dcl, at)
     assert seen >= set(_lib.SIGNATURES), set(_lib.SIGNATURES) - seen
+
+
+_BENCH_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+import bench
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cores = bench.pin_host_threads(rank, world)
+assert cores >= 1 and torch.get_num_threads() >= 1
+W, steps = 3, 4
+class StubMetrics:
+    def compute_confusion_matrix(self, lg, gt, out=None):
+        pred = lg.argmax(1)
+        for p, g in zip(pred.tolist(), gt.tolist()):
+            out[p, g] += 1
+        return out
+calls = []
+def forward(batch, mode):                        # rank 1 is the slow rank: the job's time is ITS time
+    calls.append(len(batch))
+    time.sleep(0.02 if rank == 0 else 0.06)
+    logits = [torch.eye(3)[(torch.arange(5) + i + rank) % 3] for i in range(len(batch))]
+    return None, None, logits
+batch = [{"past_point_clouds": None}] * W
+gts = [(torch.arange(5) + i) % 3 for i in range(W)]
+dt, value, cm_all = bench.timed_steps(forward, batch, gts, StubMetrics(), steps, 2, world, "cpu", lambda: None)
+assert len(calls) == steps + 2 and all(c == W for c in calls)
+assert dt >= steps * 0.06 * 0.95, dt                      # MAX over ranks, on both ranks
+assert abs(value - world * steps * W / dt) < 1e-9          # whole-job aggregate
+exp = torch.zeros((3, 3), dtype=torch.int64)
+for r in range(world):
+    for i in range(W):
+        for k in range(5):
+            exp[(k + i + r) % 3, (k + i) % 3] += steps
+assert torch.equal(cm_all, exp), (cm_all, exp)             # counters of BOTH ranks, timed steps only
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank, round(dt, 3))
+"""
+
+
+def test_bench_timed_region_shard_and_aggregate_gloo_world2(tmp_path):
+    """bench.py's contract pieces without a GPU: two ranks over gloo with a stub model -- warm-up untimed, exactly K timed
+    steps, time = MAX over ranks, value = whole-job windows / that time, confusion counters all-gathered inside the region."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER)
+    port = str(29300 + os.getpid() % 200)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, ROOT], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o

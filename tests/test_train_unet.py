@@ -218,6 +218,14 @@ def test_insmos_trainer_train_mode_signature_and_descent():
         tr.sgd_step(0.2 / max(gnorm, 1e-12))  # a normalised step of length 0.2 in parameter space
     print("training losses", losses)
     assert losses[-1] < losses[0]
+    # the drop-in module serves the same mode (models/models.py:313-345): InsMOS_Model.forward(list, 'train') == the trainer's
+    model = InsMOSNet(cfg, state_dict=sd).cuda().eval()
+    loss_m, tb_m, gt_m, pred_m = model.forward(batch, "train")
+    ref = InsMOSTrainer(cfg, sd)
+    loss_r, tb_r, _, pred_r = ref.forward(batch, "train")
+    assert torch.equal(loss_m, loss_r) and tb_m == tb_r and all(torch.equal(a, b) for a, b in zip(pred_m, pred_r))
+    loss_m.backward()
+    assert all(v.grad is not None for v in model.model.trainer.params.values())
     # the trained 3D branch goes back into a checkpoint the inference model loads
     sd2 = dict(sd)
     sd2.update(tr.unet.export_state_dict())
