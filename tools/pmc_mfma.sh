@@ -11,14 +11,14 @@ import csv, glob, json, os
 f = glob.glob("$R/gpurun_out/pmc_mfma/p/**/*counter_collection.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-conv = [r for r in rows if "k_sparse_conv" in r["Kernel_Name"] or "k_deconv_head" in r["Kernel_Name"]]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sparse_conv", "k_deconv_head", "k_bev_conv", "k_resolve_taps<2, 1, 1>"))]
 tot = {}
 for r in conv:
     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 disp = len({r["Dispatch_Id"] for r in conv})
 gui = tot.get("GRBM_GUI_ACTIVE", 0.0)
 out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES -- bench.py --timed-only (one launch set)",
-       "scope": "conv launches (k_sparse_conv*, k_deconv_head) of ONE launch set of $WPL cfg-2 S0 windows (bench.py --timed-only; the profiler serialises kernels)", "windows_per_launch": $WPL,
+       "scope": "conv launches (k_sparse_conv*, k_bev_conv3x3, k_deconv_head, constant-input first layer) of ONE launch set of $WPL cfg-2 S0 windows (bench.py --timed-only; the profiler serialises kernels)", "windows_per_launch": $WPL,
        "launches": disp, "totals": tot,
        "mfma_busy_over_gpu_active": tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024 / 8) if gui else None,
        "note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_16x16x4_f32 "
