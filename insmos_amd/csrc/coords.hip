@@ -367,6 +367,61 @@ __global__ void __launch_bounds__(256) k_build_nbr(const int32_t* __restrict__ o
     }
 }
 
+// The same table for tap lists whose taps come in x-TRIPLES (kx fastest, x offsets d, d+1, d+2, no division on x: the
+// submanifold and the strided 3x3x3 maps): the three probes are consecutive integers in key space, so ONE lower-bound search
+// finds the first and the other two are the next entries of the sorted array -- a third of the searches.  grid.y = K / 3.
+__global__ void __launch_bounds__(256) k_build_nbr_x3(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                      const uint64_t* __restrict__ in_keys,
+                                                      const int32_t* __restrict__ in_perm, int64_t n_in, NbrParams P,
+                                                      int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k0 = 3 * blockIdx.y;
+    if (o >= n_out) return;
+    int4 c = *(const int4*)(out_coords + o * 4);
+    int q[4] = {c.x * P.mul[0] + P.delta[k0][0], c.y * P.mul[1] + P.delta[k0][1], c.z * P.mul[2] + P.delta[k0][2],
+                c.w * P.mul[3] + P.delta[k0][3]};
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // (x is never divided here)
+        int dv = P.dv[d];
+        if (dv > 1) {
+            if (q[d] % dv != 0) ok = false;
+            q[d] = q[d] / dv;
+        }
+    }
+    const int D = P.shape[0], H = P.shape[1], W = P.shape[2];
+    ok = ok && (unsigned)q[1] < (unsigned)D && (unsigned)q[2] < (unsigned)H && q[3] + 2 >= 0 && q[3] < W;
+    int32_t r[3] = {-1, -1, -1};
+    if (ok) {
+        const uint64_t row_key = (((uint64_t)q[0] * D + (uint64_t)q[1]) * H + (uint64_t)q[2]) * (uint64_t)W;  // key of x = 0
+        const int xs = q[3] < 0 ? 0 : q[3];
+        int64_t lo = 0, hi = n_in;  // lower_bound(row_key + xs)
+        const uint64_t want = row_key + (uint64_t)xs;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (in_keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int x = q[3] + t;
+            if (x >= xs && x < W && lo < n_in && in_keys[lo] == row_key + (uint64_t)x) {
+                r[t] = in_perm ? in_perm[lo] : (int32_t)lo;
+                ++lo;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = k0 + t;
+        nbr[(int64_t)k * n_out + o] = r[t];
+        if (mask16) {
+            const unsigned long long bal = __ballot(r[t] >= 0);
+            if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(o >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 3D hard voxelisation + mean VFE (voxel_generate.py:19-28, mean_vfe.py:47-52)
 // ---------------------------------------------------------------------------------------------------
@@ -391,8 +446,10 @@ __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, con
         uint64_t lin = ((uint64_t)(int)cz * (uint64_t)gy + (uint64_t)(int)cy) * (uint64_t)gx + (uint64_t)(int)cx;
         lin += b * key_cells;
         k = (lin << VOX_IDX_BITS) | (uint64_t)i;
-        atomicAdd(&counts[2], 1);
     }
+    // one counter update per wave (a per-point atomic on one address serialises in the L2: 170 us for a launch set)
+    const unsigned long long bal = __ballot(in);
+    if (in && (int)(threadIdx.x & 63) == __ffsll((long long)bal) - 1) atomicAdd(&counts[2], __popcll(bal));
     keys[i] = k;
     pcid[i] = -1;
     mark[i] = 0;
@@ -884,9 +941,18 @@ extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const 
     dim3 grid(cdiv(n_out, TPB), (unsigned)K);
     ProfScope ps(KK_BUILD_NBR, s);
     if (mask16) HIP_TRY(hipMemsetAsync(mask16, 0, (size_t)((n_out + 15) / 16) * 4 * sizeof(uint32_t), s));
+    // taps in x-triples (d, d+1, d+2 on x, everything else equal, x undivided): one search per triple
+    bool x3 = key_mode == 1 && K % 3 == 0 && P.dv[3] == 1 && P.mul[3] >= 1;
+    for (int k = 0; x3 && k < K; k += 3)
+        for (int t = 1; t < 3; ++t)
+            x3 = x3 && P.delta[k + t][0] == P.delta[k][0] && P.delta[k + t][1] == P.delta[k][1] &&
+                 P.delta[k + t][2] == P.delta[k][2] && P.delta[k + t][3] == P.delta[k][3] + t;
     if (key_mode == 0)
         INSMOS_LAUNCH(k_build_nbr<0>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
                            mask16);
+    else if (x3)
+        INSMOS_LAUNCH(k_build_nbr_x3, dim3(cdiv(n_out, TPB), (unsigned)(K / 3)), dim3(TPB), 0, s, out_coords, n_out, in_keys,
+                      in_perm, n_in, P, nbr, mask16);
     else
         INSMOS_LAUNCH(k_build_nbr<1>, grid, dim3(TPB), 0, s, out_coords, n_out, in_keys, in_perm, n_in, P, nbr,
                            mask16);

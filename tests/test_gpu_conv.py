@@ -160,3 +160,39 @@ def test_bev_conv3x3_kernel_matches_torch_conv2d(B, H, W, ci, co):
         _lib.check(lib().insmos_bev_conv3x3(xs.data_ptr(), 1, H, W, ld, ci, layer.w.data_ptr(), layer.b.data_ptr(), one.data_ptr(),
                                             co, co, 1, stream()), "insmos_bev_conv3x3")
         assert torch.equal(one, out[:H * W])
+
+
+@pytest.mark.parametrize("cin,cout,K", [(8, 8, 81), (16, 16, 81), (16, 8, 81), (8, 16, 27), (16, 32, 27), (32, 16, 27)])
+def test_lds_resident_weight_kernel_is_bitwise_the_unsplit_kernel(cin, cout, K):
+    """Large launches of the small-channel masked layers run on persistent workgroups with the weights in LDS (k_sparse_conv
+    WLDS, >= 16384 row groups); a launch over the tail rows only (insmos_sparse_conv_rows, few row groups) takes the one-wave
+    kernel.  Same operation order -> the SAME bits, and both agree with the oracle's conv."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(K * 100 + cin + cout)
+    n_out, n_in = 16 * 16384 + 16 * 700 + 5, 90000
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    grp = rng.uniform(size=(K, (n_out + 15) // 16)) < 0.45          # spatially coherent occupancy: whole groups without a tap
+    nbr[~(np.repeat(grp, 16, axis=1)[:, :n_out] & (rng.uniform(size=(K, n_out)) < 0.6))] = -1
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.25)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    xd, nd, md = dev(x), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+
+    def run(row0):
+        out = torch.zeros((n_out, cout), device="cuda:0")
+        _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr(), K, n_out, row0,
+                                                 layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout, None, 0,
+                                                 0, 0, 1, stream()), "insmos_sparse_conv_rows")
+        torch.cuda.synchronize()
+        return out
+
+    full = run(0)                       # 17084 row groups: LDS-resident weights
+    row0 = 16 * 16384                   # 700 row groups: the one-wave kernel
+    tail = run(row0)
+    assert torch.equal(full[row0:], tail[row0:])
+    assert float(tail[:row0].abs().sum()) == 0.0
+    sel = np.concatenate([np.arange(0, 4000), rng.integers(0, n_out, 6000), np.arange(n_out - 3000, n_out)])
+    ref = np.maximum(R.sparse_conv(x, nbr[:, sel], taps) + bias, 0.0)
+    np.testing.assert_allclose(full[torch.from_numpy(sel).cuda()].cpu().numpy(), ref, **TOL)
