@@ -533,7 +533,10 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
         }
         float norm = (float)(m < 1 ? 1 : m);
         float* fo = feat + (int64_t)vid * ld_feat;
-        for (int f = 0; f < ld_feat; ++f) fo[f] = (f < n_feat && f < 8) ? acc[f] / norm : 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)  // (compile-time indices: acc[] stays in registers)
+            if (f < ld_feat) fo[f] = f < n_feat ? acc[f] / norm : 0.f;
+        for (int f = 8; f < ld_feat; ++f) fo[f] = 0.f;
     }
     for (int j = start; j < end; ++j) {
         int p = (int)(keys_s[j] & ((1ull << VOX_IDX_BITS) - 1));

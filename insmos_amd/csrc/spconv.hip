@@ -18,11 +18,8 @@
 // B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4) + reg][j = lane&15].  The contraction index of MFMA
 // step s inside a 16-channel chunk is channel c0 + 4*(lane>>4) + s (any assignment is legal as long
 // as A and B agree), which is what makes the gather a contiguous float4 per lane.
-#include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include "common.h"
 
 namespace insmos {
@@ -90,19 +87,10 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 //    the slowest of four waves in its block;
 //  * masked layers with enough work per tile are SPLIT (above): 4x the waves, each a quarter as long.
 // DBG (probe builds only, tools/conv_probe.py): bit 0 = no weight loads, bit 1 = no gathers, bit 2 = no MFMAs
-//
-// WLDS: LDS-RESIDENT WEIGHTS (small-channel layers: Cin, Cout <= 16, where a tile does 2-4 MFMAs per tap and the 1 KiB weight
-// fragment it re-fetches per tap is the largest of its three vector-memory requests -- the layer is L1/TA bound).  A
-// persistent 16-wave workgroup copies the layer's packed weights (<= 96 KiB) into LDS once and its waves then walk the tile
-// list (16 consecutive tiles per round: spatially adjacent rows share gathered lines in the CU's L1); A fragments come from
-// LDS (ds_read_b128, a different pipe), leaving one gather and one index load per tap on the vector-memory path.  Same
-// operation order as the unsplit kernel: identical bits, so the launcher may pick either by size.
-template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0, bool WLDS = false>
-__global__ void __launch_bounds__(WLDS ? 1024 : (SPLIT == 1 ? 64 : 256)) k_sparse_conv(ConvP P) {
+template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0>
+__global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) {
     static_assert(SPLIT == 1 || (JT == 1 && (COT % SPLIT == 0 || SPLIT % COT == 0)), "split tiles are 16 rows x all channels");
     static_assert(!SPLITC || (SPLIT > 1 && CK == 0), "chunk split needs 16-channel chunks");
-    static_assert(!WLDS || (SPLIT == 1 && !IDENT && DBG == 0), "LDS-resident weights: unsplit table layers");
-    extern __shared__ __attribute__((aligned(16))) float wl_raw[];
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
     const uint32_t wib = SPLIT == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,18 +117,8 @@ __global__ void __launch_bounds__(WLDS ? 1024 : (SPLIT == 1 ? 64 : 256)) k_spars
     constexpr int CSTEP = SPLITC ? SPLIT : 1;
     const int c0 = SPLITC ? (int)ws : 0;
     const uint32_t cout = P.cout;
-    const f32x4* wl = (const f32x4*)wl_raw;
-    uint32_t wv = 0;  // wave inside a persistent workgroup
-    if constexpr (WLDS) {
-        const uint32_t total4 = (uint32_t)P.K * tap_stride / 4u;  // float4 pieces of the packed weights
-        for (uint32_t i = threadIdx.x; i < total4; i += 1024u) ((f32x4*)wl_raw)[i] = ((const f32x4*)P.w)[i];
-        __syncthreads();
-        wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    }
-    const uint32_t u_first = WLDS ? blockIdx.x * 16u + wv : blockIdx.x;
-    const uint32_t u_step = WLDS ? gridDim.x * 16u : 1u;
-    const uint32_t u_end = WLDS ? n_tiles : blockIdx.x + 1u;
-    for (uint32_t unit = u_first; unit < u_end; unit += u_step) {
+    {
+        const uint32_t unit = blockIdx.x;
         const uint32_t tile_raw = SPLIT == 1 ? unit : unit * TPB + wib / SPLIT;
         const bool live = tile_raw < n_tiles;  // only split blocks can hold a dead tile (kept for the barriers)
         const uint32_t tile = live ? tile_raw : n_tiles - 1;
@@ -257,8 +235,6 @@ __global__ void __launch_bounds__(WLDS ? 1024 : (SPLIT == 1 ? 64 : 256)) k_spars
             for (int it = 0; it < COT; ++it) {
                 if constexpr (DBG & 1) {
                     if (k == 1000) a[it] = (f32x4){1.f, 1.f, 1.f, 1.f};
-                } else if constexpr (WLDS) {
-                    a[it] = wl[(((uint32_t)k * (uint32_t)P.nblk + (uint32_t)c) * (uint32_t)P.ntile_co + cg * COT + it) * 64u + lane];
                 } else {
                     a[it] = __builtin_bit_cast(
                         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw, 0));
@@ -541,6 +517,12 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
     return INSMOS_OK;
 }
 
+namespace insmos {
+int sparse_conv_compact(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16, int K,
+                        int64_t n_out, int64_t row0, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
+                        const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, hipStream_t s);
+}
+
 namespace {
 typedef void (*ConvKernel)(ConvP);
 struct Cfg { int cot, jt; };
@@ -558,19 +540,6 @@ ConvKernel pick_kernel(int cot, int jt) {
         CASE(1, 1) CASE(1, 2) CASE(1, 4) CASE(2, 1) CASE(2, 2) CASE(2, 4)
     }
 #undef CASE
-    return nullptr;
-}
-
-// persistent workgroups with LDS-resident weights (WLDS): unsplit 16-row tiles, all (1 or 2) channel tiles per wave
-ConvKernel pick_wlds(int cot, int ck) {
-    if (ck == 8) {
-        if (cot == 1) return k_sparse_conv<1, 1, 8, false, 3, 1, false, 0, true>;
-        if (cot == 2) return k_sparse_conv<2, 1, 8, false, 3, 1, false, 0, true>;
-        return nullptr;
-    }
-    if (ck) return nullptr;
-    if (cot == 1) return k_sparse_conv<1, 1, 0, false, 3, 1, false, 0, true>;
-    if (cot == 2) return k_sparse_conv<2, 1, 0, false, 3, 1, false, 0, true>;
     return nullptr;
 }
 
@@ -630,6 +599,12 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         ((uintptr_t)in & 15) || n_out * (int64_t)K * 4 >= (1ll << 31) || n_in * (int64_t)ld_in * 4 >= (1ll << 31))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    // the wide masked layers (Cout 64 / 128): row-compacted 64-row tiles (spconv_cmp.hip); chosen by layer shape only
+    if (!g_force_cot && !g_dbg) {
+        const int rc = sparse_conv_compact(in, n_in, ld_in, cin, nbr, mask16, K, n_out, row0, wpacked, bias, out, ld_out, cout, res,
+                                           ld_res, res_mode, relu_pre, relu_post, s);
+        if (rc != 0) return rc < 0 ? rc : INSMOS_OK;
+    }
     ConvP P;
     P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
     P.n_out = (uint32_t)n_out;
@@ -714,40 +689,6 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         if (pk) kern = pk;
     }
     if (!kern) return INSMOS_EINVAL;
-
-    // ---- LDS-resident weights for the small-channel table layers of a large launch (same bits as the unsplit kernel)
-    static int wlds_min_tiles = -1, n_cu = 0;
-    if (wlds_min_tiles < 0) {
-        wlds_min_tiles = env_int("INSMOS_WLDS_MIN_TILES", 16384);
-        hipDeviceProp_t prop;
-        int dev = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
-    const size_t w_bytes = (size_t)K * (size_t)P.nblk * (size_t)P.ntile_co * 1024u;
-    if (wlds_min_tiles > 0 && split == 1 && !ident && mask16 && !g_force_cot && !g_dbg && K >= 16 && best.jt == 1 &&
-        best.cot == P.ntile_co && w_bytes <= (96u << 10) && (long)P.n_otiles >= (long)wlds_min_tiles) {
-        ConvKernel wk = pick_wlds(best.cot, ck);
-        if (wk) {
-            static std::map<ConvKernel, size_t> lds_set;   // (one thread at a time per kernel is enough: the value only grows)
-            static std::mutex mu;
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                size_t& cur = lds_set[wk];
-                if (cur < w_bytes) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96u << 10)));
-                    cur = 96u << 10;
-                }
-            }
-            const int per_cu = w_bytes <= (48u << 10) ? 2 : 1;   // 16-wave workgroups a CU's LDS holds
-            const long want = ((long)P.n_otiles + 15) / 16;
-            const long nblk = std::min<long>(want, (long)n_cu * per_cu);
-            ProfScope ps(KK_SPARSE_CONV, s);
-            ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
-            INSMOS_LAUNCH(wk, dim3((unsigned)nblk), dim3(1024), w_bytes, s, P);
-            HIP_TRY(hipGetLastError());
-            return INSMOS_OK;
-        }
-    }
 
     // ---- launch shape: one ONE-WAVE block per tile (split: one 4-wave block per tile)
     const long tiles = (long)P.n_otiles * (P.ntile_co / best.cot);

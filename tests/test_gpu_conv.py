@@ -162,37 +162,51 @@ def test_bev_conv3x3_kernel_matches_torch_conv2d(B, H, W, ci, co):
         assert torch.equal(one, out[:H * W])
 
 
-@pytest.mark.parametrize("cin,cout,K", [(8, 8, 81), (16, 16, 81), (16, 8, 81), (8, 16, 27), (16, 32, 27), (32, 16, 27)])
-def test_lds_resident_weight_kernel_is_bitwise_the_unsplit_kernel(cin, cout, K):
-    """Large launches of the small-channel masked layers run on persistent workgroups with the weights in LDS (k_sparse_conv
-    WLDS, >= 16384 row groups); a launch over the tail rows only (insmos_sparse_conv_rows, few row groups) takes the one-wave
-    kernel.  Same operation order -> the SAME bits, and both agree with the oracle's conv."""
+@pytest.mark.parametrize("cin,cout,K,res_mode", [(128, 128, 27, 0), (64, 64, 27, 1), (256, 128, 27, 2), (64, 128, 27, 0), (128, 64, 81, 1)])
+def test_row_compaction_kernel_vs_oracle_and_layout_independence(cin, cout, K, res_mode):
+    """The wide masked layers run on row-compacted tiles (csrc/spconv_cmp.hip): against the oracle's conv with every epilogue,
+    and -- the property batching rests on -- a row's bits depend neither on the rows sharing its tile, nor on the tile size the
+    launch picks (64 / 32 / 16 rows by launch size), nor on where in the row list it sits."""
     from gpu_util import dev, lib, pack_layer, stream, tap_masks
     from insmos_amd import _lib
-    rng = np.random.default_rng(K * 100 + cin + cout)
-    n_out, n_in = 16 * 16384 + 16 * 700 + 5, 90000
+    rng = np.random.default_rng(K * 1000 + cin + cout)
+    n_out, n_in = 33000, 9000
     nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
-    grp = rng.uniform(size=(K, (n_out + 15) // 16)) < 0.45          # spatially coherent occupancy: whole groups without a tap
-    nbr[~(np.repeat(grp, 16, axis=1)[:, :n_out] & (rng.uniform(size=(K, n_out)) < 0.6))] = -1
+    grp = rng.uniform(size=(K, (n_out + 15) // 16)) < 0.6            # spatially coherent occupancy, ~70 % fill inside a group
+    nbr[~(np.repeat(grp, 16, axis=1)[:, :n_out] & (rng.uniform(size=(K, n_out)) < 0.7))] = -1
+    nbr[:, 5000:5100] = -1                                            # rows without any neighbour: bias only
     x = rng.normal(size=(n_in, cin)).astype(np.float32)
-    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.25)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.4)).astype(np.float32)
     bias = rng.normal(size=cout).astype(np.float32)
     layer = pack_layer(taps, bias, cin, cout)
-    xd, nd, md = dev(x), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = rng.normal(size=(n_out, ld_res)).astype(np.float32) if res_mode else None
+    xd, resd = dev(x), (dev(res) if res_mode else None)
 
-    def run(row0):
-        out = torch.zeros((n_out, cout), device="cuda:0")
-        _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr(), K, n_out, row0,
-                                                 layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout, None, 0,
-                                                 0, 0, 1, stream()), "insmos_sparse_conv_rows")
+    def run(table, row0=0, res_t=resd):
+        n = table.shape[1]
+        nd, md = dev(table), dev(tap_masks(table).view(np.int32))
+        out = torch.zeros((n, cout), device="cuda:0")
+        _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr(), K, n, row0,
+                                                 layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout,
+                                                 res_t.data_ptr() if res_t is not None else None, ld_res if res_mode else 0, res_mode,
+                                                 1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
         torch.cuda.synchronize()
         return out
 
-    full = run(0)                       # 17084 row groups: LDS-resident weights
-    row0 = 16 * 16384                   # 700 row groups: the one-wave kernel
-    tail = run(row0)
-    assert torch.equal(full[row0:], tail[row0:])
-    assert float(tail[:row0].abs().sum()) == 0.0
-    sel = np.concatenate([np.arange(0, 4000), rng.integers(0, n_out, 6000), np.arange(n_out - 3000, n_out)])
-    ref = np.maximum(R.sparse_conv(x, nbr[:, sel], taps) + bias, 0.0)
-    np.testing.assert_allclose(full[torch.from_numpy(sel).cuda()].cpu().numpy(), ref, **TOL)
+    full = run(nbr)                                                   # 33000 rows: 64-row tiles
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res[:, 0::2] + res[:, 1::2]      # relu_pre, then the channel-pair residual
+    elif res_mode == 1:
+        ref = ref + res
+    ref = np.maximum(ref, 0.0)
+    np.testing.assert_allclose(full.cpu().numpy(), ref, **TOL)
+    tail32 = run(nbr, row0=16 * 1000)                                 # 17000 rows left: 32-row tiles
+    tail16 = run(nbr, row0=16 * 1900)                                 # 2600 rows left: 16-row tiles
+    assert torch.equal(full[16000:], tail32[16000:]) and torch.equal(full[30400:], tail16[30400:])
+    # the same rows, 16 places further down a longer list (other tile mates, other tile boundaries)
+    shifted = np.concatenate([nbr[:, 777:793], nbr], axis=1)
+    res_s = dev(np.concatenate([res[777:793], res])) if res_mode else None
+    out_s = run(shifted, res_t=res_s)
+    assert torch.equal(out_s[16:], full)
