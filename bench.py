@@ -21,7 +21,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per window in flight (see insmos_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # a hardware queue per launch set in flight (see insmos_amd/__init__.py)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -517,12 +517,6 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
     return INSMOS_OK;
 }
 
-namespace insmos {
-int sparse_conv_compact(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr, const uint32_t* mask16, int K,
-                        int64_t n_out, int64_t row0, const float* wpacked, const float* bias, float* out, int ld_out, int cout,
-                        const float* res, int ld_res, int res_mode, int relu_pre, int relu_post, hipStream_t s);
-}
-
 namespace {
 typedef void (*ConvKernel)(ConvP);
 struct Cfg { int cot, jt; };
@@ -599,12 +593,6 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         ((uintptr_t)in & 15) || n_out * (int64_t)K * 4 >= (1ll << 31) || n_in * (int64_t)ld_in * 4 >= (1ll << 31))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // the wide masked layers (Cout 64 / 128): row-compacted 64-row tiles (spconv_cmp.hip); chosen by layer shape only
-    if (!g_force_cot && !g_dbg) {
-        const int rc = sparse_conv_compact(in, n_in, ld_in, cin, nbr, mask16, K, n_out, row0, wpacked, bias, out, ld_out, cout, res,
-                                           ld_res, res_mode, relu_pre, relu_post, s);
-        if (rc != 0) return rc < 0 ? rc : INSMOS_OK;
-    }
     ConvP P;
     P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
     P.n_out = (uint32_t)n_out;

@@ -163,10 +163,10 @@ def test_bev_conv3x3_kernel_matches_torch_conv2d(B, H, W, ci, co):
 
 
 @pytest.mark.parametrize("cin,cout,K,res_mode", [(128, 128, 27, 0), (64, 64, 27, 1), (256, 128, 27, 2), (64, 128, 27, 0), (128, 64, 81, 1)])
-def test_row_compaction_kernel_vs_oracle_and_layout_independence(cin, cout, K, res_mode):
-    """The wide masked layers run on row-compacted tiles (csrc/spconv_cmp.hip): against the oracle's conv with every epilogue,
-    and -- the property batching rests on -- a row's bits depend neither on the rows sharing its tile, nor on the tile size the
-    launch picks (64 / 32 / 16 rows by launch size), nor on where in the row list it sits."""
+def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_mode):
+    """The wide masked layers (split tiles: four waves share a 16-row group) against the oracle's conv with every epilogue,
+    and -- the property batching rests on -- a row's bits depend neither on the rows sharing its tile (taps are handed to the
+    waves by tap index, not by rank in the tile's active set), nor on the launch size, nor on where in the row list it sits."""
     from gpu_util import dev, lib, pack_layer, stream, tap_masks
     from insmos_amd import _lib
     rng = np.random.default_rng(K * 1000 + cin + cout)
@@ -194,7 +194,7 @@ def test_row_compaction_kernel_vs_oracle_and_layout_independence(cin, cout, K, r
         torch.cuda.synchronize()
         return out
 
-    full = run(nbr)                                                   # 33000 rows: 64-row tiles
+    full = run(nbr)
     ref = R.sparse_conv(x, nbr, taps) + bias
     if res_mode == 2:
         ref = np.maximum(ref, 0.0) + res[:, 0::2] + res[:, 1::2]      # relu_pre, then the channel-pair residual
@@ -202,11 +202,11 @@ def test_row_compaction_kernel_vs_oracle_and_layout_independence(cin, cout, K, r
         ref = ref + res
     ref = np.maximum(ref, 0.0)
     np.testing.assert_allclose(full.cpu().numpy(), ref, **TOL)
-    tail32 = run(nbr, row0=16 * 1000)                                 # 17000 rows left: 32-row tiles
-    tail16 = run(nbr, row0=16 * 1900)                                 # 2600 rows left: 16-row tiles
-    assert torch.equal(full[16000:], tail32[16000:]) and torch.equal(full[30400:], tail16[30400:])
-    # the same rows, 16 places further down a longer list (other tile mates, other tile boundaries)
-    shifted = np.concatenate([nbr[:, 777:793], nbr], axis=1)
-    res_s = dev(np.concatenate([res[777:793], res])) if res_mode else None
+    tail_a = run(nbr, row0=16 * 1000)                                 # a row suffix: 17000 rows, then 2600
+    tail_b = run(nbr, row0=16 * 1900)
+    assert torch.equal(full[16000:], tail_a[16000:]) and torch.equal(full[30400:], tail_b[30400:])
+    # the same rows, 5 places further down a longer list: every row gets other tile mates and other active-tap sets
+    shifted = np.concatenate([nbr[:, 777:782], nbr], axis=1)
+    res_s = dev(np.concatenate([res[777:782], res])) if res_mode else None
     out_s = run(shifted, res_t=res_s)
-    assert torch.equal(out_s[16:], full)
+    assert torch.equal(out_s[5:], full)

@@ -126,3 +126,40 @@ def test_s0_full_size_against_the_oracle():
     ok = (d.min(1) < 1e-3) & (pl == rl[twin])
     print("boxes with a twin in the oracle's list: %d / %d (identical order: %s)" % (ok.sum(), len(pb), bool((twin == np.arange(len(pb))).all())))
     assert ok.mean() >= 0.99 and len(set(twin[ok].tolist())) == int(ok.sum())
+
+
+def test_cfg4_dense_stress_full_size_properties():
+    """BASELINE.json configs[3] at FULL size: 300k points/scan (n_az 4710), voxel 0.05 m, N = 10 -> 3.0 M points, grid
+    [81, 2000, 2400], BEV 250 x 300 x 640 (random weights: the 0.05 m grid is not weight-compatible with the 0.1 m
+    checkpoints).  The oracle needs minutes at this size (it is compared at reduced size in
+    test_dense_stress_config_voxel_005), so: the coordinate-set sizes (the 100 000-voxel cap of models.py:287 IS hit),
+    native runner == step path bit for bit, determinism, zero logits for the points the cap drops, and the window as one half
+    of a launch set == the window alone."""
+    import copy
+    from insmos_amd import params as P
+    from insmos_amd.engine import Engine
+    from insmos_amd.synth import make_window
+    cfg = copy.deepcopy(P.default_cfg())
+    cfg["DATA"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    cfg["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"] = 640
+    cfg["MODEL"]["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    eng = Engine(cfg, P.random_state_dict(cfg, 4), native=True)
+    assert eng.shape[1] == [81, 2000, 2400] and eng.shape[5] == [5, 250, 300]
+    w = make_window(0, 10, 4710)
+    assert len(w) == 2995748
+    pts = torch.from_numpy(w).cuda()
+    logits, pred = eng.forward_window(pts)
+    c = dict(eng.last_counts)
+    assert c["me_voxels"] == [1300911, 608512, 246875, 93347]
+    assert c["unet_voxels"] == [100000, 117408, 51585, 19108, 15097]      # level 1 capped; the strided levels grow again
+    assert logits.shape == (c["n_cur"], 3) and bool(torch.isfinite(logits).all())
+    logits_s, pred_s = eng.forward_window(pts, native=False)                # the inspectable step path: same bits
+    assert torch.equal(logits, logits_s) and torch.equal(pred["pred_boxes"], pred_s["pred_boxes"])
+    dropped = eng._un_tables["pcid"] < 0
+    assert int(dropped.sum()) > 10000 and float(logits[dropped].abs().sum()) == 0.0
+    logits2, _ = eng.forward_window(pts)
+    assert torch.equal(logits, logits2)
+    small = torch.from_numpy(make_window(5, 4, 300)).cuda()
+    pair = eng.forward_windows([small, pts])
+    assert torch.equal(pair[1][0], logits) and torch.equal(pair[1][1]["pred_boxes"], pred["pred_boxes"])
+    assert [pw["voxels"] for pw in eng.last_counts["per_window"]][1] == 100000
