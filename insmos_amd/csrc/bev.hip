@@ -8,8 +8,8 @@
 //   * the patch's input halo ((TH+2) x 18 sites) is staged in LDS one 16-channel chunk at a time (double buffered: the next
 //     chunk's global loads are in flight during the current chunk's MFMAs), so every input element is read from global
 //     memory once per workgroup instead of nine times per output-channel group;
-//   * the four waves split the patch 2 (row halves) x 2 (output-channel halves): a wave keeps TH/2 row groups x COT channel
-//     tiles of accumulators, so each 1 KiB weight fragment it loads feeds TH/2 row groups (4x fewer weight bytes per
+//   * the waves split the patch 2 (row halves) x NCG (output-channel groups): a wave keeps TH/2 row groups x COT channel
+//     tiles of accumulators, so each 1 KiB weight fragment it loads feeds TH/2 row groups (4-5x fewer weight bytes per
 //     flop than a 16-row tile) and each B fragment it reads from LDS feeds COT channel tiles;
 //   * B fragments are `ds_read_b128` at a 96-byte site pitch: with lane (g, j) reading the 16 bytes of channel group g
 //     of site j, a 6-slot pitch puts the 16 lanes of every hardware lane group of ds_read_b128 on 16 distinct 16-byte bank
@@ -28,13 +28,17 @@ constexpr int BEV_TW = 16;           // sites per row group (x extent of a patch
 constexpr int BEV_HW = BEV_TW + 2;   // halo width
 constexpr int BEV_PITCH = 24;        // floats per halo site in LDS: 16 channels + 8 pad = 96 bytes (conflict-free, see above)
 
-template <int TH, int COT>
-__global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16,
+// YM: the 16-site row groups run along y (and the TH extent along x) instead of along x -- picked per launch so that the
+// patches pad the image as little as possible (150 x 125: 16-wide strips along x waste 6 % of the last strip, along y 2 %)
+// NCG: output-channel groups (waves = 2 row halves x NCG; a wave owns COT = Cout / 16 / NCG channel tiles)
+template <int TH, int COT, int NCG, bool YM>
+__global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty) {
     constexpr int JT = TH / 2;                          // row groups per wave
     constexpr int NSITE = (TH + 2) * BEV_HW;            // halo sites
-    constexpr int NQ = (NSITE * 4 + 255) / 256;         // float4 pieces per thread per chunk
+    constexpr int NTHR = 128 * NCG;
+    constexpr int NQ = (NSITE * 4 + NTHR - 1) / NTHR;   // float4 pieces per thread per chunk
     __shared__ __attribute__((aligned(16))) float halo[2][NSITE * BEV_PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,8 +46,10 @@ __global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x
     const int g = lane >> 4, j = lane & 15;
     const int bid = blockIdx.x;
     const int tx = bid % n_tx, ty = (bid / n_tx) % n_ty, img = bid / (n_tx * n_ty);
-    const int x0 = tx * BEV_TW, y0 = ty * TH;
-    const int ntile = 2 * COT;
+    // patch origin: (u, v) = (fast axis, slow axis) of the patch; u is x (v is y) unless YM
+    const int u0 = tx * BEV_TW, v0 = ty * TH;
+    const int U = YM ? H : W, V = YM ? W : H;
+    const int ntile = NCG * COT;
 
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_img * H * W * ld_x * 4), 0x00020000);
@@ -55,11 +61,12 @@ __global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x
     uint32_t src[NQ], dst[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int i = tid + 256 * q;
+        const int i = tid + NTHR * q;
         const int s = i >> 2, quarter = i & 3;
-        const int hy = s / BEV_HW, hx = s % BEV_HW;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = i < NSITE * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int hv = s / BEV_HW, hu = s % BEV_HW;
+        const int gu = u0 - 1 + hu, gv = v0 - 1 + hv;
+        const bool ok = i < NSITE * 4 && gu >= 0 && gu < U && gv >= 0 && gv < V;
+        const int gy = YM ? gu : gv, gx = YM ? gv : gu;
         src[q] = ok ? (uint32_t)((((size_t)img * H + gy) * W + gx) * (size_t)ld_x * 4u + quarter * 16u) : 0xFFFFFFF0u;
         dst[q] = i < NSITE * 4 ? (uint32_t)(s * BEV_PITCH + quarter * 4) : 0xFFFFFFFFu;
     }
@@ -113,9 +120,10 @@ __global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x
             // their own operands only), in flight during the rest of this chunk's MFMAs
             if (k == 1 && c + 1 < n16) fetch(c + 1);
             const int ky = k / 3, kx = k % 3;
+            const int ku = YM ? ky : kx, kv = YM ? kx : ky;   // tap offset along the patch's fast / slow axis
             f32x4 b[JT];
 #pragma unroll
-            for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (ky * BEV_HW + kx) * BEV_PITCH);
+            for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -127,12 +135,13 @@ __global__ void __launch_bounds__(256) k_bev_conv3x3(const float* __restrict__ x
         __syncthreads();
     }
 
-    // ---- epilogue: lane (g, j) holds channels co0..co0+3 of site (y, x0 + j)
-    const int gx = x0 + j;
+    // ---- epilogue: lane (g, j) holds channels co0..co0+3 of site (u0 + j, v0 + rh*JT + r)
+    const int gu = u0 + j;
 #pragma unroll
     for (int r = 0; r < JT; ++r) {
-        const int gy = y0 + rh * JT + r;
-        if (gy >= H || gx >= W) continue;
+        const int gv = v0 + rh * JT + r;
+        if (gv >= V || gu >= U) continue;
+        const int gy = YM ? gu : gv, gx = YM ? gv : gu;
         float* op = out + (((size_t)img * H + gy) * W + gx) * (size_t)ld_out;
 #pragma unroll
         for (int it = 0; it < COT; ++it) {
@@ -163,18 +172,37 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int n16 = cin / 16;
-    const int n_tx = (W + BEV_TW - 1) / BEV_TW;
-    // 8-row patches when that still gives every CU a workgroup, else 4-row patches (a single image)
-    const bool tall = (int64_t)B * ((H + 7) / 8) * n_tx >= 256;
-    const int th = tall ? 8 : 4;
-    const int n_ty = (H + th - 1) / th;
+    // patch shape: 16 sites along one axis x TH in {10, 8, 4} along the other.  Every site's value is the same expression
+    // whatever patch it falls into, so the choice is free: least padded work, at least one workgroup per CU, tallest wins ties
+    // (a taller patch re-uses each weight fragment for more row groups).
+    int best_th = 0, best_ym = 0;
+    double best_cost = 1e30;
+    for (int ym = 0; ym < 2; ++ym)
+        for (int th : {10, 8, 4}) {
+            const int U = ym ? H : W, V = ym ? W : H;
+            const int64_t nblk = (int64_t)B * ((U + 15) / 16) * ((V + th - 1) / th);
+            double cost = (double)nblk * 16.0 * th;                    // padded sites
+            if (nblk < 256) cost *= 256.0 / (double)nblk;             // idle CUs
+            cost *= 1.0 + 0.04 * (10 - th) / 6.0;                      // weight traffic of the flatter patches
+            // whole rounds of resident workgroups (2 per CU for the tall patches, more for TH = 4)
+            const int64_t slots = 256 * (th == 4 ? 4 : 2);
+            cost *= (double)(((nblk + slots - 1) / slots) * slots) / (double)nblk > 1.35 ? 1.1 : 1.0;
+            if (cost < best_cost) { best_cost = cost; best_th = th; best_ym = ym; }
+        }
+    const int U = best_ym ? H : W, V = best_ym ? W : H;
+    const int n_tx = (U + BEV_TW - 1) / BEV_TW, n_ty = (V + best_th - 1) / best_th;
     const unsigned grid = (unsigned)((int64_t)B * n_ty * n_tx);
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 9; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = (int64_t)B * H * W;
-#define BEV_GO(TH_, COT_) \
-    INSMOS_LAUNCH((k_bev_conv3x3<TH_, COT_>), dim3(grid), dim3(256), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, out, ld_out, relu, n_tx, n_ty)
-    if (cout == 128) { if (tall) BEV_GO(8, 4); else BEV_GO(4, 4); }
-    else             { if (tall) BEV_GO(8, 2); else BEV_GO(4, 2); }
+    // Cout = 128: 2 x 4 waves of 2 channel tiles (10-row patches: the accumulators of 4 tiles x 5 row groups would leave one
+    // wave per SIMD); Cout = 64: 2 x 2 waves of 2 tiles
+#define BEV_GO(TH_, NCG_, YM_) \
+    INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, out, ld_out, relu, n_tx, n_ty)
+#define BEV_TH(NCG_, YM_) \
+    do { if (best_th == 10) BEV_GO(10, NCG_, YM_); else if (best_th == 8) BEV_GO(8, NCG_, YM_); else BEV_GO(4, NCG_, YM_); } while (0)
+    if (cout == 128) { if (best_ym) BEV_TH(4, true); else BEV_TH(4, false); }
+    else             { if (best_ym) BEV_TH(2, true); else BEV_TH(2, false); }
+#undef BEV_TH
 #undef BEV_GO
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
