@@ -30,7 +30,7 @@ enum KernelKind : int {
     KK_QUANT_KEYS = 0, KK_SORT, KK_SCAN, KK_QUANT_SCATTER, KK_LEVEL_DOWN, KK_BUILD_NBR, KK_VOX_KEYS,
     KK_VOX_SEGMENTS, KK_VOX_MEAN, KK_DOWN_CAND, KK_DOWN_UNIQUE, KK_SPARSE_CONV, KK_DENSE_NBR, KK_TO_BEV,
     KK_DECODE, KK_SELECT, KK_NMS_MASK, KK_NMS_REDUCE, KK_IOU, KK_GATHER_PREDS, KK_ONEHOT, KK_GATHER_ROWS,
-    KK_CUR_POINTS, KK_FILL, KK_CONFUSION, KK_MEMSET, KK_COUNT
+    KK_CUR_POINTS, KK_FILL, KK_CONFUSION, KK_MEMSET, KK_BATCHNORM, KK_COUNT
 };
 struct ProfScope {
     int kind;

@@ -447,9 +447,8 @@ __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, con
         lin += b * key_cells;
         k = (lin << VOX_IDX_BITS) | (uint64_t)i;
     }
-    // one counter update per wave (a per-point atomic on one address serialises in the L2: 170 us for a launch set)
-    const unsigned long long bal = __ballot(in);
-    if (in && (int)(threadIdx.x & 63) == __ffsll((long long)bal) - 1) atomicAdd(&counts[2], __popcll(bal));
+    // (the number of in-range points is NOT counted here: 15 000 waves adding to one address serialise in the L2, 170 us
+    //  for a launch set; k_vox_heads reads it off the sorted keys instead)
     keys[i] = k;
     pcid[i] = -1;
     mark[i] = 0;
@@ -457,9 +456,11 @@ __global__ void k_vox_keys(const float* __restrict__ pts, int64_t n, int ld, con
 
 __global__ void k_vox_heads(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ flag,
                             const int32_t* __restrict__ scan, int64_t n, int32_t* __restrict__ seg_start,
-                            int32_t* __restrict__ seg_first, int32_t* __restrict__ mark) {
+                            int32_t* __restrict__ seg_first, int32_t* __restrict__ mark, int32_t* __restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // in-range points = the sorted keys before the first invalid one (counts[2] was zeroed: stays 0 when there is none)
+    if (keys_s[i] != INSMOS_INVALID_KEY && (i == n - 1 || keys_s[i + 1] == INSMOS_INVALID_KEY)) counts[2] = (int32_t)(i + 1);
     if (flag[i]) {
         int sid = scan[i] - 1;
         int p = (int)(keys_s[i] & ((1ull << VOX_IDX_BITS) - 1));
@@ -538,10 +539,16 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
             if (f < ld_feat) fo[f] = f < n_feat ? acc[f] / norm : 0.f;
         for (int f = 8; f < ld_feat; ++f) fo[f] = 0.f;
     }
-    for (int j = start; j < end; ++j) {
-        int p = (int)(keys_s[j] & ((1ull << VOX_IDX_BITS) - 1));
-        pcid[p] = kept ? (int64_t)vid : (int64_t)-1;
-    }
+}
+
+// pc_voxel_id: one thread per sorted point (the voxel of a point = uperm of its segment; no per-voxel loops over 1..50 points)
+__global__ void k_vox_pcid(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ sid_scan, int64_t n,
+                           const int32_t* __restrict__ uperm, int64_t* __restrict__ pcid) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t k = keys_s[j];
+    if (k == INSMOS_INVALID_KEY) return;  // (pcid was preset to -1)
+    pcid[(int64_t)(k & ((1ull << VOX_IDX_BITS) - 1))] = (int64_t)uperm[sid_scan[j] - 1];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1028,7 +1035,7 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_SEGMENTS, s);
-        INSMOS_LAUNCH(k_vox_heads, dim3(g), dim3(TPB), 0, s, k_s, flag, sid_scan, n, seg_start, seg_first, mark);
+        INSMOS_LAUNCH(k_vox_heads, dim3(g), dim3(TPB), 0, s, k_s, flag, sid_scan, n, seg_start, seg_first, mark, counts);
     }
     rc = inclusive_scan_i32(tmp, sc, mark, rank_scan, N, s);
     if (rc) return rc;
@@ -1039,6 +1046,7 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
         INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
                       seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
                       num_points, pc_voxel_id, ukeys, uperm, counts);
+        INSMOS_LAUNCH(k_vox_pcid, dim3(g), dim3(TPB), 0, s, k_s, sid_scan, n, uperm, pc_voxel_id);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;

@@ -16,7 +16,7 @@ static const char* kNames[KK_COUNT] = {
     "quant_keys", "radix_sort", "scan", "quant_scatter", "level_down", "build_nbr", "vox_keys", "vox_segments",
     "vox_mean", "down_candidates", "down_unique", "sparse_conv_mfma", "dense_nbr2d", "sparse_to_bev", "center_decode",
     "select_topk", "nms_mask", "nms_reduce", "iou_bev", "gather_preds", "boxes_to_onehot", "gather_rows",
-    "current_points", "fill_cols", "confusion", "memset"};
+    "current_points", "fill_cols", "confusion", "memset", "batchnorm"};
 
 bool prof_on() { return g_prof; }
 

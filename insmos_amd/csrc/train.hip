@@ -407,7 +407,7 @@ extern "C" int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, i
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)((n + 1023) / 1024);
     float *mean = stats, *invstd = stats + c;
-    ProfScope ps(KK_FILL, s);
+    ProfScope ps(KK_BATCHNORM, s);
     INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, (const float*)nullptr, c, n, 0, ws);
     INSMOS_LAUNCH(k_bn_finish_stats, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, nb, c, n, mean, 0, eps);
     INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, mean, c, n, 1, ws);
@@ -425,7 +425,7 @@ extern "C" int insmos_batchnorm_train_backward(const float* dy, int ld_dy, const
     if (!dy || !xhat || !gamma || !stats || !dx || !dgamma || !dbeta || !g_ws || !ws || (relu && !y)) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)((n + 1023) / 1024);
-    ProfScope ps(KK_FILL, s);
+    ProfScope ps(KK_BATCHNORM, s);
     const float* g = dy;
     int ld_g = ld_dy;
     if (relu || ld_dy != c) {
