@@ -30,6 +30,7 @@ extern "C" {
 #define INSMOS_EINVAL (-1)    /* bad argument */
 #define INSMOS_EHIP (-2)      /* a HIP runtime call failed; see insmos_last_hip_error() */
 #define INSMOS_EWORKSPACE (-3) /* workspace too small */
+#define INSMOS_EBATCH (-4)     /* launch set too large for 32-bit table offsets: run it as smaller sets */
 
 int insmos_version(void);
 int insmos_last_hip_error(void);
@@ -509,7 +510,9 @@ int insmos_ctx_destroy(void* ctx);
 int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts, void* arena, size_t arena_bytes,
                           void* stream, InsmosForwardOut* out);
 /* The whole batch list of InsMOS_Model.forward in one launch set: points_host[b] (n_points_host[b], ld_pts) device arrays,
- * outs[b] as above for window b (offsets into the shared arena).  B = 1 is insmos_forward_window. */
+ * outs[b] as above for window b (offsets into the shared arena).  B = 1 is insmos_forward_window.  INSMOS_EBATCH: the
+ * batch's finest 81-tap table would pass 2 GiB (kernels address tables with 32-bit byte offsets) -- split the list. */
+int insmos_debug_table_limit(int64_t bytes); /* tests only: lower the table size at which a batch is refused (0 = default) */
 int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
                            void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs);
 

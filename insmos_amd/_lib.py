@@ -61,6 +61,7 @@ SIGNATURES = {
     "insmos_boxes_to_onehot_scratch_ints_b": (c_sz, [c_int, c_int, c_i64]),
     "insmos_boxes_to_onehot_b": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
                                          c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_debug_table_limit": (c_int, [c_i64]),
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
@@ -162,7 +163,8 @@ def load():
     return _lib
 
 
-_ERR = {-1: "INSMOS_EINVAL (bad argument)", -2: "INSMOS_EHIP (HIP runtime error)", -3: "INSMOS_EWORKSPACE"}
+_ERR = {-1: "INSMOS_EINVAL (bad argument)", -2: "INSMOS_EHIP (HIP runtime error)", -3: "INSMOS_EWORKSPACE",
+        -4: "INSMOS_EBATCH (launch set too large)"}
 
 
 def check(rc, what):

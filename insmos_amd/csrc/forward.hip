@@ -57,6 +57,7 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 }
 
 struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
+int64_t g_table_limit = 1ll << 31;  // bytes a neighbour table may span (32-bit offsets); lowered by tests (insmos_debug_table_limit)
 
 #define CK(expr)                                  \
     do {                                          \
@@ -224,6 +225,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     }
     auto row_from = [&](int l, int d) -> int64_t { return d < 16 ? starts[l][d] : 0; };
 
+    // kernels address a table with 32-bit byte offsets: a batch whose finest 81-tap table would pass 2 GiB is refused
+    // (the caller runs it as two smaller launch sets); a single window of that size is simply too large
+    if ((int64_t)81 * n[0] * 4 >= g_table_limit) return B > 1 ? INSMOS_EBATCH : INSMOS_EINVAL;
     // only the coarsest level is searched; every finer table is derived through the Morton hierarchy
     Table nbr81[4];
     nbr81[3] = table(81, n[3]);
@@ -566,4 +570,9 @@ extern "C" int insmos_forward_windows(void* ctx, const float* const* points_host
 extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int ld, void* arena, size_t arena_bytes,
                                      void* stream, InsmosForwardOut* out) {
     return forward_windows_impl(ctx, &pts, &N, 1, ld, arena, arena_bytes, stream, out);
+}
+
+extern "C" int insmos_debug_table_limit(int64_t bytes) {
+    g_table_limit = (bytes > 0 && bytes < (1ll << 31)) ? bytes : (1ll << 31);
+    return INSMOS_OK;
 }

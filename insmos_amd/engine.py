@@ -829,6 +829,9 @@ class Engine:
                 break
             self._arena = None
             self._arena = torch.empty(max(int(outs[0].arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
+        if rc == -4:  # INSMOS_EBATCH: the set's finest table would pass 2 GiB -> two smaller launch sets, same bits per window
+            h = B // 2
+            return self.forward_windows(pts_list[:h]) + self.forward_windows(pts_list[h:])
         if rc == -1 and outs[0].n_out_of_window:
             raise ValueError(f"{int(outs[0].n_out_of_window)} points fall outside the +-32768-voxel key window")
         if rc == -1 and outs[0].me_voxels[0] > 0 and any(int(o.n_cur) == 0 for o in outs):

@@ -149,7 +149,8 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
     done = 0
     writer = OutputWriter(device)
     mine = [jobs[idx] for idx in shard_indices(len(jobs), rank, world)]
-    group = max(1, int(getattr(model.model, "windows_in_flight", 1)))  # batch items the model keeps in flight
+    # batch items per forward(): the launch sets the model keeps in flight (windows_in_flight sets of windows_per_launch)
+    group = max(1, int(getattr(model.model, "windows_in_flight", 1)) * int(getattr(model.model, "windows_per_launch", 1)))
     for g0 in range(0, len(mine), group):
         batch, metas = [], []
         for n_past, j in mine[g0 + group:g0 + 2 * group]:  # read-ahead for the next group while this one computes

@@ -128,6 +128,29 @@ def test_model_groups_of_launch_sets_match_the_sequential_walk(setup):
         model.model.engine.forward_windows([setup["dev"][1], w[w[:, 4] < 0].contiguous()])
 
 
+def test_oversized_launch_set_is_split_not_refused(setup):
+    """Kernels address a neighbour table with 32-bit byte offsets: insmos_forward_windows refuses a batch whose finest 81-tap
+    table would pass 2 GiB (INSMOS_EBATCH) and Engine.forward_windows runs it as two smaller sets -- same bits per window.
+    (The limit is lowered for the test; 16 full S0 windows would reach the real one.)"""
+    from insmos_amd.engine import Engine
+    eng = Engine(setup["cfg"], setup["sd"], native=True)
+    wins = setup["dev"][:6]
+    ref = eng.forward_windows(wins)
+    n0 = eng.last_counts["me_voxels"][0]
+    L = lib()
+    try:
+        L.insmos_debug_table_limit(81 * 4 * (n0 // 2 + n0 // 8))       # the six together are too large, halves fit
+        got = eng.forward_windows(wins)
+        assert eng.last_counts["batch"] == 3
+        for a, b in zip(ref, got):
+            assert _same(a, b)
+        L.insmos_debug_table_limit(81 * 4 * 100)                        # nothing fits: a single window is an error, not a loop
+        with pytest.raises(_lib.InsmosHipError):
+            eng.forward_windows(wins[:2])
+    finally:
+        L.insmos_debug_table_limit(0)
+
+
 def test_voxelize_windows_is_per_window_voxelisation(setup):
     """insmos_voxelize_mean_windows == insmos_voxelize_mean per window (first-seen order, per-window cap), rows window-major."""
     L = lib()

@@ -2,7 +2,7 @@
 """tools/batch_sweep.py -- windows/s of InsMOS_Model.forward over the launch-set shape: windows per launch set x launch
 sets in flight, same 16 S0 windows, inputs resident (the bench.py step without the bookkeeping).
 
-    python tools/batch_sweep.py [W=16] [steps=6]          # prints one line per (windows_per_launch, in_flight)
+    python tools/batch_sweep.py [W=16] [steps=6] [grid="1x1,1x4,..."]     # one line per (windows_per_launch x in_flight)
 """
 import os
 import sys
@@ -19,6 +19,8 @@ def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     grid = [(1, 1), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 3), (8, 1), (8, 2)]
+    if len(sys.argv) > 3:
+        grid = [tuple(int(v) for v in g.split("x")) for g in sys.argv[3].split(",")]
     cfg = P.default_cfg()
     model = InsMOSNet(cfg, state_dict=P.random_state_dict(cfg, seed=0)).cuda().eval()
     wins = [torch.from_numpy(w).cuda() for w in bench.load_windows(list(range(W)), 1886)]
