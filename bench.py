@@ -183,7 +183,7 @@ def main():
                          "warm-up and the timed steps and nothing else -- every kernel launch in the trace belongs to a step")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
-    ap.add_argument("--windows-per-step", type=int, default=16, help="batch items of one forward() = one step")
+    ap.add_argument("--windows-per-step", type=int, default=24, help="batch items of one forward() = one step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

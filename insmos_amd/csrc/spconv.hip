@@ -108,7 +108,11 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
                                           IDENT ? 4 : (int)((uint32_t)P.K * n_out * 4u), 0x00020000);
     constexpr uint32_t LW = CK == 4 ? 4u : CK == 8 ? 8u : 16u;  // bytes per lane per gather
     const uint32_t goff = (uint32_t)g * LW;
-    const uint32_t blk_stride = (uint32_t)P.ntile_co * 256u;   // floats between chunk blocks of one tap
+    // A fragments: 4 floats per lane per 16-channel chunk; the single-chunk layers (Cin = 8 / 4) pack 2 / 1 floats per lane
+    // (their other MFMA steps would multiply packed zeros: half / three quarters of the weight bytes these L2-bound layers fetch)
+    constexpr uint32_t LWF = CK == 4 ? 1u : CK == 8 ? 2u : 4u;  // floats per lane per fragment
+    constexpr uint32_t FR = 64u * LWF;                          // floats per fragment
+    const uint32_t blk_stride = (uint32_t)P.ntile_co * FR;      // floats between chunk blocks of one tap
     const uint32_t tap_stride = (uint32_t)P.nblk * blk_stride;  // floats between taps
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)P.w, 0, (int)((uint32_t)P.K * tap_stride * 4u), 0x00020000);
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
 #pragma unroll
         for (int it = 0; it < COT; ++it) {
             const uint32_t co = (cg * COT + it) * 16u + (uint32_t)(lane & 15);
-            woffv[it] = co < cout ? ((cg * COT + it) * 256u + lane * 4u) * 4u : 0x7FFFFFF0u;
+            woffv[it] = co < cout ? ((cg * COT + it) * FR + lane * LWF) * 4u : 0x7FFFFFF0u;
         }
 
         // raw neighbour indices of tap k (one dword per 16-row group and lane)
@@ -235,6 +239,11 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
             for (int it = 0; it < COT; ++it) {
                 if constexpr (DBG & 1) {
                     if (k == 1000) a[it] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                } else if constexpr (CK == 4) {
+                    a[it] = (f32x4){__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woffv[it], sw, 0)), 0.f, 0.f, 0.f};
+                } else if constexpr (CK == 8) {
+                    f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, woffv[it], sw, 0));
+                    a[it] = (f32x4){t[0], t[1], 0.f, 0.f};
                 } else {
                     a[it] = __builtin_bit_cast(
                         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw, 0));
@@ -482,11 +491,14 @@ static void chunking(int cin, int& n16, int& has8, int& has4) {
     has4 = (rem & 4) ? 1 : 0;
 }
 
+// floats per lane of an A fragment: 4 per 16-channel chunk; the single-chunk layers Cin = 8 / 4 pack 2 / 1 (see k_sparse_conv)
+static int frag_lane_floats(int cin) { return cin == 8 ? 2 : cin == 4 ? 1 : 4; }
+
 extern "C" size_t insmos_packed_weight_floats(int K, int cin, int cout) {
     int n16, h8, h4;
     chunking(cin, n16, h8, h4);
     int ntile = (cout + 15) / 16;
-    return (size_t)K * (size_t)(n16 + h8 + h4) * (size_t)ntile * 256;
+    return (size_t)K * (size_t)(n16 + h8 + h4) * (size_t)ntile * 64 * (size_t)frag_lane_floats(cin);
 }
 
 extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, int cout_real, int cin, int cout,
@@ -495,6 +507,7 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
     int n16, h8, h4;
     chunking(cin, n16, h8, h4);
     const int nblk = n16 + h8 + h4, ntile = (cout + 15) / 16;
+    const int lf = frag_lane_floats(cin);  // floats stored per lane (4; 2 / 1 for the single-chunk layers Cin = 8 / 4)
     auto W = [&](int k, int ci, int co) -> float {
         return (ci < cin_real && co < cout_real) ? taps[((size_t)k * cin_real + ci) * cout_real + co] : 0.f;
     };
@@ -504,8 +517,8 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
             for (int t = 0; t < ntile; ++t)
                 for (int l = 0; l < 64; ++l) {
                     int g = l >> 4, i = l & 15;
-                    float* dst = packed + ((((size_t)k * nblk + blk) * ntile + t) * 64 + l) * 4;
-                    for (int s = 0; s < 4; ++s) dst[s] = (s < width) ? W(k, c0 + width * g + s, t * 16 + i) : 0.f;
+                    float* dst = packed + ((((size_t)k * nblk + blk) * ntile + t) * 64 + l) * lf;
+                    for (int s = 0; s < lf; ++s) dst[s] = (s < width) ? W(k, c0 + width * g + s, t * 16 + i) : 0.f;
                 }
             ++blk;
         };

@@ -33,6 +33,9 @@ __global__ void k_pack_weights(const float* __restrict__ taps, int K, int cin_re
     if (blk < n16) { c0 = blk * 16; width = 4; }
     else if (has8 && blk == n16) { c0 = n16 * 16; width = 2; }
     else { c0 = n16 * 16 + (has8 ? 8 : 0); width = 1; }
+    // single-chunk layers (Cin = 8 / 4) store `width` floats per lane, everything else 4 (insmos_pack_weights_host)
+    const int lf = (nblk == 1 && n16 == 0) ? width : 4;
+    if (s >= lf) return;
     float v = 0.f;
     if (s < width) {
         const int ci = c0 + width * g + s, co = tile * 16 + i;  // channel in / out of the PACKED layer
@@ -44,7 +47,7 @@ __global__ void k_pack_weights(const float* __restrict__ taps, int K, int cin_re
             v = taps[((int64_t)ks * cin_real + co) * cout_real + ci];
         }
     }
-    packed[t] = v;
+    packed[(t >> 2) * lf + s] = v;
 }
 
 // ---- dW: block = 256 threads = 16 x 16 (ci, co) pairs of a 16 x 16 channel tile, one tap, one chunk of rows ----

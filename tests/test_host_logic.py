@@ -34,7 +34,8 @@ def test_header_symbols_all_exported(lib):
 
 def _emulate_conv(packed, K, cin, cout, x, nbr):
     """Numpy emulation of k_sparse_conv's contraction straight from the PACKED weights: one MFMA step s of a
-    block contracts, for lane group g, input channel c0 + width*g + s with A = packed[k][blk][tile][lane][s]."""
+    block contracts, for lane group g, input channel c0 + width*g + s with A = packed[k][blk][tile][lane][s]
+    (4 floats per lane; Cin = 8 / 4 layers -- one chunk of width 2 / 1 -- store just those 2 / 1)."""
     n16, rem = cin // 16, cin % 16
     blocks = [(c * 16, 4) for c in range(n16)]
     c0 = n16 * 16
@@ -43,7 +44,8 @@ def _emulate_conv(packed, K, cin, cout, x, nbr):
     if rem & 4:
         blocks.append((c0, 1))
     ntile = (cout + 15) // 16
-    pk = packed.reshape(K, len(blocks), ntile, 64, 4)
+    lf = 2 if cin == 8 else 1 if cin == 4 else 4   # floats per lane: the single-chunk layers (Cin = 8 / 4) are stored compactly
+    pk = packed.reshape(K, len(blocks), ntile, 64, lf)
     n_out = nbr.shape[1]
     out = np.zeros((n_out, ntile * 16), np.float64)
     for k in range(K):
