@@ -669,9 +669,13 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
                         if (live) nbr[(int64_t)k * n_f + o] = r;
                         if (hit && live) mw[k >> 5] |= 1u << (k & 31);
                     } else {
-                        const float sel = hit ? 1.0f : 0.0f;
+                        // a tap none of the wave's 64 (Morton-consecutive) voxels has is skipped wave-uniformly: its
+                        // products are exact zeros, the sums do not change (LiDAR shells are thin: most |dz| = 2 taps)
+                        if (__ballot(hit) != 0ull) {
+                            const float sel = hit ? 1.0f : 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(sel, w[k * 8 + i], acc[i]);
+                            for (int i = 0; i < 8; ++i) acc[i] = fmaf(sel, w[k * 8 + i], acc[i]);
+                        }
                     }
                 }
     static_assert(W1 * W1 * W1 * NDT <= 128, "tap count");

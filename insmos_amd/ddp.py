@@ -6,17 +6,29 @@ per-collective latency: InsMOS has ~6.5 M parameters (26 MB fp32) in ~250 tensor
 collectives if reduced tensor by tensor.  Gradients are therefore packed into a few flat fp32 buckets (default 8 MB:
 large enough to run at link bandwidth, small enough that the first bucket can start while later gradients are still
 being produced) and each bucket is all-reduced once; `reduce()` returns after the last bucket is unpacked.
+
+overlap=True (round 2): the exchange starts DURING backward.  Buckets are laid out in reverse parameter order (gradients
+arrive roughly last layer first); a post-accumulate hook on every parameter copies its gradient into its bucket, and a bucket
+is all-reduced (async) as soon as it is complete AND every earlier bucket has been launched -- the launch order is the bucket
+order on every rank, whatever order the gradients arrive in and whether or not a rank produced all of them (a gradient that
+never arrives counts as zero and its bucket goes out in `reduce()`), so ranks can never pair up different collectives.
 """
+
 import torch
 import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None):
-        """params: dict name -> tensor (requires_grad) or list of tensors; the bucket layout is fixed at construction
-        (same order on every rank: sorted names / list order)."""
-        self.items = sorted(params.items()) if isinstance(params, dict) else list(enumerate(params))
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, overlap=False):
+        """params: dict name -> tensor (requires_grad) or list of tensors; the bucket layout is fixed at construction and the
+        same on every rank: sorted names / list order, or -- overlap=True -- the reverse of the dict / list order (pass the
+        parameters in forward order)."""
+        if overlap:
+            self.items = (list(params.items()) if isinstance(params, dict) else list(enumerate(params)))[::-1]
+        else:
+            self.items = sorted(params.items()) if isinstance(params, dict) else list(enumerate(params))
         self.group = group
+        self.overlap = bool(overlap)
         self.buckets = []  # list of (flat buffer, [(tensor, offset, numel)])
         cur, off, cap = [], 0, max(1, bucket_bytes // 4)
         for _, p in self.items:
@@ -28,24 +40,51 @@ class BucketedGradReducer:
             off += n
         if cur:
             self._close(cur, off)
+        self._works, self._launched, self._seen = [], 0, [set() for _ in self.buckets]
+        self.launched_in_backward = 0   # collectives of the last step that went out before reduce() was called
+        if self.overlap:
+            for bi, (_, members) in enumerate(self.buckets):
+                for mi, (p, _, _) in enumerate(members):
+                    p.register_post_accumulate_grad_hook(lambda t, bi=bi, mi=mi: self._on_grad(bi, mi))
 
     def _close(self, cur, total):
         dev = cur[0][0].device
         self.buckets.append((torch.zeros(total, dtype=torch.float32, device=dev), cur))
 
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _launch(self, bi):
+        """Pack bucket bi (gradients the hooks did not see count as zero) and start its all-reduce."""
+        flat, members = self.buckets[bi]
+        for mi, (p, off, n) in enumerate(members):
+            if mi in self._seen[bi]:
+                continue                      # copied by its hook
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+        if self._world() > 1:
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, bi, mi):
+        flat, members = self.buckets[bi]
+        p, off, n = members[mi]
+        flat[off:off + n].copy_(p.grad.reshape(-1))
+        self._seen[bi].add(mi)
+        while self._launched < len(self.buckets) and len(self._seen[self._launched]) == len(self.buckets[self._launched][1]):
+            self._launch(self._launched)      # strictly in bucket order
+            self._launched += 1
+
     def reduce(self, average=True):
-        """All-reduce every parameter's .grad (missing grads count as zero) in place; returns the number of collectives."""
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        works = []
-        for flat, members in self.buckets:
-            for p, off, n in members:
-                if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
-            if world > 1:
-                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
+        """All-reduce every parameter's .grad (missing grads count as zero) in place; returns the number of collectives.
+        With overlap=True most of them are already in flight (or done) when this is called after backward()."""
+        world = self._world()
+        self.launched_in_backward = self._launched
+        while self._launched < len(self.buckets):
+            self._launch(self._launched)
+            self._launched += 1
+        for w in self._works:
             w.wait()
         for flat, members in self.buckets:
             if average and world > 1:
@@ -56,4 +95,5 @@ class BucketedGradReducer:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
+        self._works, self._launched, self._seen = [], 0, [set() for _ in self.buckets]
         return len(self.buckets)

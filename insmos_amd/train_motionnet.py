@@ -103,10 +103,12 @@ class MotionNetTrainer:
         """loss_motion_encoder of models/models.py:324."""
         return mos_loss(self.forward(pts), gt_labels_cur)
 
-    def make_reducer(self, bucket_bytes=8 << 20):
+    def make_reducer(self, bucket_bytes=8 << 20, overlap=True):
         """Data-parallel gradient exchange (insmos_amd/ddp.py): call .reduce() between backward() and the update."""
         from .ddp import BucketedGradReducer
-        return BucketedGradReducer(self.params, bucket_bytes)
+        # overlap: buckets are all-reduced while backward is still producing the earlier layers' gradients (the parameter
+        # dict is in forward order: MotionNet first, the 3D branch's decoder last -- the reverse is the arrival order)
+        return BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
 
     def sgd_step(self, lr):
         with torch.no_grad():

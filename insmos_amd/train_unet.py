@@ -268,9 +268,11 @@ class InsMOSTrainer:
             pred_list.append(out["point_logits"])
         return loss / len(list_batch_dict), train_loss_dict, gt_list, pred_list
 
-    def make_reducer(self, bucket_bytes=8 << 20):
+    def make_reducer(self, bucket_bytes=8 << 20, overlap=True):
         from .ddp import BucketedGradReducer
-        return BucketedGradReducer(self.params, bucket_bytes)
+        # overlap: buckets are all-reduced while backward is still producing the earlier layers' gradients (the parameter
+        # dict is in forward order: MotionNet first, the 3D branch's decoder last -- the reverse is the arrival order)
+        return BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
 
     def sgd_step(self, lr):
         with torch.no_grad():

@@ -198,6 +198,62 @@ def test_bucketed_grad_reducer_gloo_world2(tmp_path):
         assert p.returncode == 0 and "OK" in o, o
 
 
+_DDP_OVERLAP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from insmos_amd.ddp import BucketedGradReducer
+rank, world = int(sys.argv[1]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+shapes = [(40, 8), (8,), (30, 16), (16,), (20, 4), (4,), (9, 3)]          # forward order: layer 0 first
+params = {"p%d" % i: torch.nn.Parameter(torch.randn(s)) for i, s in enumerate(shapes)}
+red = BucketedGradReducer(params, bucket_bytes=1500, overlap=True)       # several buckets, laid out last layer first
+assert len(red.buckets) >= 3 and red.buckets[0][1][0][0] is params["p6"]
+def loss_fn(r, step):
+    x = torch.full((5, 40), 0.1 * (r + 1) + step)
+    h = torch.tanh(x @ params["p0"] + params["p1"])
+    h = torch.tanh(h @ params["p2"][:8] + params["p3"])
+    h = h @ params["p4"][:16] + params["p5"]
+    out = h.sum()
+    if r == 0:                       # rank 1 never touches p6: its gradient counts as zero there
+        out = out + (params["p6"] ** 2).sum()
+    return out
+for step in range(2):                # the reducer is reusable step after step
+    for p in params.values():
+        p.grad = None
+    loss_fn(rank, step).backward()
+    if rank == 0:
+        assert red._launched >= 1    # a bucket went out DURING backward
+    n = red.reduce(average=True)
+    assert n == len(red.buckets)
+    # reference: both ranks' gradients computed locally, averaged
+    exp = {k: torch.zeros_like(v) for k, v in params.items()}
+    saved = {k: v.grad.clone() for k, v in params.items()}
+    for r in range(world):           # (autograd.grad: no accumulation into .grad, so the reducer's hooks stay out of it)
+        gs = torch.autograd.grad(loss_fn(r, step), list(params.values()), allow_unused=True)
+        for k, g in zip(params, gs):
+            if g is not None:
+                exp[k] += g / world
+    for k in params:
+        assert torch.allclose(saved[k], exp[k], atol=1e-6), (step, k)
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_overlapped_grad_reducer_gloo_world2(tmp_path):
+    """overlap=True: buckets go out during backward, in bucket order on every rank, a rank's missing gradient counts as zero."""
+    script = tmp_path / "ddp_overlap_worker.py"
+    script.write_text(_DDP_OVERLAP_WORKER)
+    port = str(29100 + os.getpid() % 150)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, ROOT], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o
+
+
 def test_unet_trainer_layouts_round_trip_and_deconv_table():
     """Host side of insmos_amd/train_unet.py (no GPU): checkpoint layout -> tap layout -> export is the identity, and the
     4-tap table that stands for ConvTranspose2d(2, 2) reproduces torch's conv_transpose2d."""
