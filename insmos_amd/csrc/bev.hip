@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rh = wave & 1, ch = wave >> 1;            // row half, output-channel half
     const int g = lane >> 4, j = lane & 15;
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);  // neighbouring patches (shared halos) behind one L2
+    const int bid = blockIdx.x;
     const int tx = bid % n_tx, ty = (bid / n_tx) % n_ty, img = bid / (n_tx * n_ty);
     // patch origin: (u, v) = (fast axis, slow axis) of the patch; u is x (v is y) unless YM
     const int u0 = tx * BEV_TW, v0 = ty * TH;

@@ -153,13 +153,6 @@ __device__ __forceinline__ int64_t find_key(const uint64_t* __restrict__ keys, i
     return (lo < n && keys[lo] == key) ? lo : -1;
 }
 
-// Workgroup b of a launch lands on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md): handing each XCD a CONTIGUOUS run of
-// tiles keeps spatially adjacent tiles -- which gather overlapping rows -- behind the same 4 MiB L2.  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
-    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
-}
-
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace insmos

@@ -40,7 +40,6 @@ struct ConvP {
     uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
     int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
     int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
-    int xcd_remap;  // 1: workgroup -> tile through xcd_contiguous() (adjacent tiles on one XCD's L2)
     int tap_mod;  // tap-split tiles: 1 = wave ws owns the taps k with k % SPLIT == ws (a row's sum does not depend on which
                   // rows share its tile), 0 = every SPLIT-th ACTIVE tap of the tile (evenest load, tile-dependent order)
 };
@@ -123,7 +122,10 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
     const int c0 = SPLITC ? (int)ws : 0;
     const uint32_t cout = P.cout;
     {
-        const uint32_t unit = P.xcd_remap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+        // (workgroup b runs on XCD b % 8: consecutive tiles are dealt round-robin over the eight L2s.  Handing each XCD a
+        //  contiguous run of tiles instead was measured: +4...29 % per layer -- the work per tile varies smoothly along the
+        //  row order, so contiguous runs unbalance the XCDs; round-robin is also the better load balancer)
+        const uint32_t unit = blockIdx.x;
         const uint32_t tile_raw = SPLIT == 1 ? unit : unit * TPB + wib / SPLIT;
         const bool live = tile_raw < n_tiles;  // only split blocks can hold a dead tile (kept for the barriers)
         const uint32_t tile = live ? tile_raw : n_tiles - 1;
@@ -655,8 +657,6 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     static int split_work = -1, tap_mod = -1;
     if (split_work < 0) { split_work = env_int("INSMOS_CONV_SPLIT_WORK", 100); tap_mod = env_int("INSMOS_SPLIT_TAP_MOD", 1); }
     P.tap_mod = tap_mod;
-    static const int xcd_remap = env_int("INSMOS_XCD_REMAP", 1);
-    P.xcd_remap = xcd_remap;
     const bool co_ok = P.ntile_co == 1 || P.ntile_co == 2 || P.ntile_co == 4 || P.ntile_co == 8;
     const bool wide = P.ntile_co >= 4;
     const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
