@@ -175,18 +175,19 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
     // patch shape: 16 sites along one axis x TH in {10, 8, 4} along the other.  Every site's value is the same expression
     // whatever patch it falls into, so the choice is free: least padded work, at least one workgroup per CU, tallest wins ties
     // (a taller patch re-uses each weight fragment for more row groups).
+    constexpr int kCUs = 256;  // MI355X
     int best_th = 0, best_ym = 0;
     double best_cost = 1e30;
     for (int ym = 0; ym < 2; ++ym)
         for (int th : {10, 8, 4}) {
             const int U = ym ? H : W, V = ym ? W : H;
             const int64_t nblk = (int64_t)B * ((U + 15) / 16) * ((V + th - 1) / th);
-            double cost = (double)nblk * 16.0 * th;                    // padded sites
-            if (nblk < 256) cost *= 256.0 / (double)nblk;             // idle CUs
-            cost *= 1.0 + 0.04 * (10 - th) / 6.0;                      // weight traffic of the flatter patches
-            // whole rounds of resident workgroups (2 per CU for the tall patches, more for TH = 4)
-            const int64_t slots = 256 * (th == 4 ? 4 : 2);
-            cost *= (double)(((nblk + slots - 1) / slots) * slots) / (double)nblk > 1.35 ? 1.1 : 1.0;
+            double cost = (double)nblk * 16.0 * th;                        // padded sites
+            if (nblk < kCUs) cost *= (double)kCUs / (double)nblk;          // idle CUs
+            cost *= 1.0 + 0.04 * (10 - th) / 6.0;                           // weight traffic of the flatter patches
+            const int64_t slots = (int64_t)kCUs * (th == 4 ? 4 : 2);       // resident workgroups per round
+            const double last_round = (double)nblk / (double)(((nblk + slots - 1) / slots) * slots);
+            cost /= 0.5 + 0.5 * last_round;                                 // a part-empty last round of workgroups
             if (cost < best_cost) { best_cost = cost; best_th = th; best_ym = ym; }
         }
     const int U = best_ym ? H : W, V = best_ym ? W : H;

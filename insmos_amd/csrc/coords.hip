@@ -498,7 +498,7 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
                                const int32_t* __restrict__ woff, int B, uint64_t key_cells, int gx, int gy, int max_voxels,
                                int max_pts,
                                float* __restrict__ feat, int ld_feat, int32_t* __restrict__ coords,
-                               int32_t* __restrict__ num_points, int64_t* __restrict__ pcid, uint64_t* __restrict__ ukeys,
+                               int32_t* __restrict__ num_points, uint64_t* __restrict__ ukeys,
                                int32_t* __restrict__ uperm, const int32_t* __restrict__ counts) {
     int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int S = sid_scan[n - 1];
@@ -1049,7 +1049,7 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
                       max_voxels, woff, counts);
         INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
                       seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
-                      num_points, pc_voxel_id, ukeys, uperm, counts);
+                      num_points, ukeys, uperm, counts);
         INSMOS_LAUNCH(k_vox_pcid, dim3(g), dim3(TPB), 0, s, k_s, sid_scan, n, uperm, pc_voxel_id);
     }
     HIP_TRY(hipGetLastError());
