@@ -15,7 +15,8 @@ from insmos_amd import _lib, params as P  # noqa: E402
 from insmos_amd.engine import NbrTable  # noqa: E402
 from insmos_amd.models import InsMOSNet  # noqa: E402
 
-LAYERS = sys.argv[1].split(",") if len(sys.argv) > 1 else [
+REP = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # replicate the window's tables REP times (launch-set size)
+LAYERS = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] else [
     "block1.0.conv1", "block8.0.conv1", "block8.0.conv2", "block7.0.conv1", "block6.0.conv1", "block3.0.conv2",
     "conv2.1.0", "conv3.1.0", "conv4.1.0", "conv_up_m4.0", "bev1", "bev0"]
 DBGS = [0, 1, 2, 3, 4, 7]
@@ -38,6 +39,15 @@ for name in LAYERS:
     tab = nbr.nbr if isinstance(nbr, NbrTable) else nbr
     mask = nbr.mask16 if isinstance(nbr, NbrTable) else None
     n_in = int(tab.max().item()) + 1
+    if REP > 1:  # REP copies of the window back to back, each on a 16-row boundary (tap masks stay valid)
+        n_o16 = (n_out + 15) // 16 * 16
+        big = torch.full((tab.shape[0], n_o16 * REP), -1, dtype=torch.int32, device="cuda")
+        for b in range(REP):
+            big[:, b * n_o16:b * n_o16 + n_out] = torch.where(tab >= 0, tab + b * n_in, tab)
+        tab = big
+        if mask is not None:
+            mask = mask.view(torch.int32).reshape(-1, 4).repeat(REP, 1).contiguous()
+        n_out, n_in = n_o16 * REP, n_in * REP
     x = torch.randn((n_in, layer.cin), device="cuda")
     out = torch.empty((n_out, layer.cout), device="cuda")
     res = []
