@@ -60,7 +60,7 @@ timed(D.SequenceWindows, "window", "window() incl. waiting for the reader")
 timed(D.SequenceWindows, "_load", "reader thread: file -> pinned -> H2D issue")
 timed(PM, "output_stage", "output_stage")
 timed(PM.OutputWriter, "submit", "writer.submit")
-timed(type(model), "forward", "model.forward (4 windows in flight)")
+timed(type(model), "forward", "model.forward (launch sets)")
 
 
 def run(tag):
