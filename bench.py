@@ -184,19 +184,24 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
     ap.add_argument("--windows-per-step", type=int, default=24, help="batch items of one forward() = one step")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for a multi-rank "
+                                                               "dry run of this script on a one-GPU box)")
+    ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; the dry run puts "
+                                                                    "every rank on GPU 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
+    gpu = local_rank if args.device_index is None else args.device_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
+    dev = f"cuda:{gpu}"
+    torch.cuda.set_device(gpu)
     host_cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     import __graft_entry__
@@ -218,7 +223,7 @@ def main():
     window = windows[0]
     pts_list = [torch.from_numpy(w).to(dev) for w in windows]
     pts = pts_list[0]
-    model = InsMOSNet(cfg, state_dict=sd).cuda(local_rank).eval()
+    model = InsMOSNet(cfg, state_dict=sd).cuda(gpu).eval()
     if world > 1 and args.calibration:   # one cache file per rank: ranks calibrate on their own first window, concurrently
         args.calibration = f"{args.calibration}.rank{rank}"
     calibrate_head(model, pts, args.candidates, cache=args.calibration, tag=f"rank{rank}_az{args.n_az}_c{args.candidates}",
