@@ -36,3 +36,18 @@ c = eng.last_counts
 print("4D voxels", c["me_voxels"], "current points", c["n_cur"], "3D voxels", c["unet_voxels"], "boxes", c["n_boxes"])
 print(f"{dt * 1e3:.2f} ms per window ({1 / dt:.1f} windows/s), arena {eng._arena.numel() / 2**30:.2f} GiB, "
       f"logits finite: {bool(torch.isfinite(logits).all())}", flush=True)
+# the same window as a launch set of B copies (the level-0 table of more than two such windows passes 2 GiB: the engine
+# then splits the set by itself)
+for B in (2, 4):
+    wins = [pts] * B
+    for _ in range(2):
+        eng.forward_windows(wins)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        res = eng.forward_windows(wins)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (3 * B)
+    same = all(torch.equal(r[0], logits) for r in res)
+    print(f"launch set of {B}: {dt * 1e3:.2f} ms per window ({1 / dt:.1f} windows/s), sets of {eng.last_counts['batch']}, "
+          f"bits as the single window: {same}", flush=True)
