@@ -89,11 +89,7 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 // DBG (probe builds only, tools/conv_probe.py): bit 0 = no weight loads, bit 1 = no gathers, bit 2 = no MFMAs
 template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0>
 __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) {
-    static_assert(SPLIT == 1 || ((JT == 1 || JT == 2) && (COT % SPLIT == 0 || SPLIT % COT == 0)),
-                  "split tiles are 16 (or 32) rows x all channels");
-    // GSKIP (split tiles of two row groups): a tap that only ONE of the two groups has is still walked (its weight fragments
-    // are shared), but the other group's MFMAs -- products of absent rows -- are skipped wave-uniformly
-    constexpr bool GSKIP = SPLIT > 1 && JT > 1;
+    static_assert(SPLIT == 1 || (JT == 1 && (COT % SPLIT == 0 || SPLIT % COT == 0)), "split tiles are 16 rows x all channels");
     static_assert(!SPLITC || (SPLIT > 1 && CK == 0), "chunk split needs 16-channel chunks");
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave id (hence every tile-level quantity) is wave-uniform
@@ -145,9 +141,6 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
 
         // ---- active-tap set of the tile = union over its 16-row groups (SGPRs)
         uint64_t tlo = 0, thi = 0;
-        uint64_t glo[JT], ghi[JT];  // per-group sets (GSKIP)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) glo[jt] = ghi[jt] = 0;
         if constexpr (IDENT) {
             tlo = 1;
         } else {
@@ -161,10 +154,8 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
                     uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
                     uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
                     if (grp < ngrp) {
-                        glo[jt] = ((uint64_t)w1 << 32) | w0;
-                        ghi[jt] = ((uint64_t)w3 << 32) | w2;
-                        tlo |= glo[jt];
-                        thi |= ghi[jt];
+                        tlo |= ((uint64_t)w1 << 32) | w0;
+                        thi |= ((uint64_t)w3 << 32) | w2;
                     }
                 }
             } else {
@@ -187,19 +178,17 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         } else if constexpr (SPLIT > 1) {
             nt = live ? nt : 0;
         }
-        uint64_t clo = tlo, chi = thi;  // the same tap list for the consumer side (GSKIP: which tap an item belongs to)
         // next tap of THIS wave (a tap-split wave skips the taps owned by the other waves of the tile)
-        auto pop_tap = [&](uint64_t& lo, uint64_t& hi, int keep) {
-            const int k = pop_or_keep(lo, hi, keep);
+        auto next_tap = [&](int keep) {
+            const int k = pop_or_keep(tlo, thi, keep);
             if constexpr (SPLIT > 1 && !SPLITC) {
                 if (!P.tap_mod) {
 #pragma unroll
-                    for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(lo, hi, 0);
+                    for (int q = 1; q < SPLIT; ++q) (void)pop_or_keep(tlo, thi, 0);
                 }
             }
             return k;
         };
-        auto next_tap = [&](int keep) { return pop_tap(tlo, thi, keep); };
 
         f32x4 acc[COT][JT];
 #pragma unroll
@@ -264,27 +253,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
                 }
             }
         };
-        int kC = 0, cC = c0;  // consumer cursor (GSKIP)
         auto mma = [&](const f32x4 (&a)[COT], const f32x4 (&b)[JT]) {
-            if constexpr (GSKIP) {
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    const uint64_t wd = kC < 64 ? glo[jt] >> kC : ghi[jt] >> (kC - 64);
-                    if (wd & 1ull) {
-#pragma unroll
-                        for (int s = 0; s < NS; ++s)
-#pragma unroll
-                            for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA(a[it][s], b[jt][s], acc[it][jt]);
-                    }
-                }
-                if (cC + CSTEP < nchunk) {
-                    cC += CSTEP;
-                } else {
-                    cC = c0;
-                    kC = pop_tap(clo, chi, kC);
-                }
-                return;
-            }
             if constexpr (DBG & 4) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) asm volatile("" ::"v"(b[jt]));
@@ -305,7 +274,6 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
             // offN = those of the next one (already scaled), idxNN = raw indices of the tap after that, in flight.
             // (The ring holds SCALED offsets on purpose: rotating raw loaded indices between variables made hipcc
             // copy the just-issued load at the loop back-edge, i.e. wait vmcnt(0) every iteration.)
-            if constexpr (GSKIP) kC = pop_tap(clo, chi, 0);
             int kL = next_tap(0);
             int kN = next_tap(kL);
             int kNN = next_tap(kN);
@@ -409,22 +377,18 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         } else {
             __shared__ f32x4 red[4][COT][64];  // [wave in block][channel tile][lane]
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {  // one row group at a time through the same 4 x COT KiB
-                if (jt > 0) __syncthreads();   // the previous group's partial sums have been read
+            for (int it = 0; it < COT; ++it) red[wib][it][lane] = acc[it][0];
+            __syncthreads();
+            if (live && (COT >= SPLIT || ws < (uint32_t)COT)) {  // (fewer channel tiles than waves: the first COT waves finish)
+                const uint32_t w0 = wib - ws;  // first wave of this tile inside the block
+                constexpr int PER = COT >= SPLIT ? COT / SPLIT : 1;
 #pragma unroll
-                for (int it = 0; it < COT; ++it) red[wib][it][lane] = acc[it][jt];
-                __syncthreads();
-                if (live && (COT >= SPLIT || ws < (uint32_t)COT)) {  // (fewer channel tiles than waves: the first COT waves finish)
-                    const uint32_t w0 = wib - ws;  // first wave of this tile inside the block
-                    constexpr int PER = COT >= SPLIT ? COT / SPLIT : 1;
+                for (int q = 0; q < PER; ++q) {
+                    const int it = (int)ws * PER + q;
+                    f32x4 v = red[w0][it][lane];
 #pragma unroll
-                    for (int q = 0; q < PER; ++q) {
-                        const int it = (int)ws * PER + q;
-                        f32x4 v = red[w0][it][lane];
-#pragma unroll
-                        for (int p = 1; p < SPLIT; ++p) v += red[w0 + p][it][lane];  // fixed order -> deterministic
-                        finish(it, jt, v);
-                    }
+                    for (int p = 1; p < SPLIT; ++p) v += red[w0 + p][it][lane];  // fixed order -> deterministic
+                    finish(it, 0, v);
                 }
             }
         }
@@ -603,17 +567,6 @@ ConvKernel pick_split(int cot, int ck, bool by_chunk) {
     return nullptr;
 }
 
-// the same with TWO row groups per tile: the tap's weight fragments are fetched once for 32 rows (the wide layers are bound
-// by those fetches, not by the MFMAs); same per-row operation order as the 16-row split tiles -> identical bits, so the
-// launcher picks by launch size
-ConvKernel pick_split2(int cot, int ck, bool by_chunk) {
-    if (ck) return nullptr;
-#define CASE(C, RR) if (cot == C) return by_chunk ? k_sparse_conv<C, 2, 0, false, RR, 4, true> : k_sparse_conv<C, 2, 0, false, RR, 4, false>;
-    CASE(8, 2) CASE(4, 2) CASE(2, 2)
-#undef CASE
-    return nullptr;
-}
-
 // tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
 // probe variants of the kernel configurations the heavy S0 layers use (ring >= 16 selects dbg = ring / 16)
@@ -716,13 +669,6 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
             best = {P.ntile_co, 1};
             P.n_otiles = (int)groups;
             kern = sk;
-            static const int split2_groups = env_int("INSMOS_SPLIT2_MIN_GROUPS", 4096);
-            ConvKernel sk2 = (split2_groups > 0 && groups >= split2_groups) ? pick_split2(P.ntile_co, ck, by_chunk) : nullptr;
-            if (sk2) {  // 32-row split tiles: only when the launch still has >= 2048 of them
-                best.jt = 2;
-                P.n_otiles = (int)((groups + 1) / 2);
-                kern = sk2;
-            }
         }
     }
     if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
