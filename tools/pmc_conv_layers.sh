@@ -1,6 +1,8 @@
 #!/bin/bash
 # SQ / TA counters of single conv layers at launch-set size: where do the waves' cycles go?  One rocprofv3 pass per counter
-# group (--kernel-trace only).  usage: bash tools/pmc_conv_layers.sh "conv4.1.0,block1.0.conv1,..." [B=8] [tag]
+# group (--kernel-trace only).  Averages are per kernel VARIANT over every launch of the process, i.e. they include the one
+# single-window forward that builds the tables -- qualitative (wait_any = parked on s_waitcnt / barrier, wait_inst = issue
+# stall: MFMA pipe / RAW or a full vector-memory queue, active = issuing).  usage: bash tools/pmc_conv_layers.sh "conv4.1.0,block1.0.conv1,..." [B=8] [tag]
 R=$(pwd); L=${1:-conv4.1.0,block1.0.conv1,block7.0.conv2,conv2.1.0,conv3.1.0,bev1}; B=${2:-8}; TAG=${3:-r02}
 export TMPDIR=/tmp
 O=$R/gpurun_out/pmc_conv; mkdir -p $O
@@ -30,9 +32,9 @@ json.dump(res, open("$R/gpurun_out/${TAG}_pmc_conv_layers.json", "w"), indent=1)
 for k, d in res.items():
     wc = d.get("SQ_WAVE_CYCLES", 0) or 1
     print(k)
-    print("   wave-cycles split: wait_any %.2f  wait_inst %.2f  active %.2f | inst mix (of wave cycles): vmem %.3f lds %.3f valu %.3f salu %.3f | mfma busy/SQ busy %.2f" % (
+    print("   wave-cycles split: wait_any %.2f  wait_inst %.2f  active %.2f | inst mix (of wave cycles): vmem %.3f lds %.3f valu %.3f salu %.3f " % (
         d.get("SQ_WAIT_ANY", 0) / wc, d.get("SQ_WAIT_INST_ANY", 0) / wc, d.get("SQ_ACTIVE_INST_ANY", 0) / wc,
         d.get("SQ_ACTIVE_INST_VMEM", 0) / wc, d.get("SQ_ACTIVE_INST_LDS", 0) / wc, d.get("SQ_ACTIVE_INST_VALU", 0) / wc,
-        d.get("SQ_ACTIVE_INST_SCA", 0) / wc, d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(d.get("SQ_BUSY_CYCLES", 0) * 4, 1)))
+        d.get("SQ_ACTIVE_INST_SCA", 0) / wc))
     print("   " + "  ".join("%s=%.3g" % (c, v) for c, v in d.items() if c.startswith(("TA_", "TCP_", "TCC_", "GRBM", "SQ_INSTS", "SQ_WAVES"))))
 PY
