@@ -210,3 +210,26 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
     res_s = dev(np.concatenate([res[777:782], res])) if res_mode else None
     out_s = run(shifted, res_t=res_s)
     assert torch.equal(out_s[5:], full)
+
+
+@pytest.mark.parametrize("n_site", [1000, 16 * 4096 + 37])
+def test_fused_deconv_head_is_bitwise_the_two_launches(n_site):
+    """insmos_deconv_head (ConvTranspose2d(2,2)+BN+ReLU and the 1x1 heads in one kernel, base_bev_backbone.py:104-115,
+    center_head.py:65-72) == the deconv as a 1x1 layer followed by the head layer, bit for bit -- with one row group per wave
+    (a single image) and with two (a launch set: >= 4096 groups)."""
+    from gpu_util import dev, lib, pack_layer, run_conv, stream
+    from insmos_amd import _lib
+    rng = np.random.default_rng(n_site)
+    cin, cup, hc = 128, 256, 12
+    x = dev(rng.normal(size=(n_site, cin)).astype(np.float32))
+    wd = (rng.normal(size=(1, cin, 4 * cup)) / np.sqrt(cin)).astype(np.float32)
+    wh = (rng.normal(size=(1, cup, hc)) / np.sqrt(cup)).astype(np.float32)
+    ld = pack_layer(wd, rng.normal(size=4 * cup).astype(np.float32), cin, 4 * cup)
+    lh = pack_layer(wh, rng.normal(size=hc).astype(np.float32), cup, hc)
+    up = run_conv(ld, x, None, n_site, relu_post=1)                                  # (n_site, 4*cup) == (4*n_site, cup) sub-site rows
+    ref = run_conv(lh, up.view(4 * n_site, cup), None, 4 * n_site)
+    head = torch.full((4 * n_site, hc), 5.0, device="cuda:0")
+    _lib.check(lib().insmos_deconv_head(x.data_ptr(), n_site, cin, cin, ld.w.data_ptr(), ld.b.data_ptr(), cup, lh.w.data_ptr(),
+                                        lh.b.data_ptr(), hc, head.data_ptr(), hc, stream()), "insmos_deconv_head")
+    torch.cuda.synchronize()
+    assert torch.equal(head, ref)
