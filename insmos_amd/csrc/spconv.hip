@@ -403,83 +403,61 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
 // accumulators, applies bias + ReLU, and -- because lane (g, j) of a D fragment holds channels 4g..4g+3 of row j, exactly
 // the B-fragment layout of a contraction over those channels -- feeds them straight into the head's MFMAs.
 // Same operation order as the two separate launches (chunks ascending, 4 steps each): identical bits.
-// JT row groups per wave (32 sites for JT = 2): every 1 KiB weight fragment of the deconv feeds JT groups -- with one group the
-// kernel is bound by those fetches (16 fragments per 64 MFMAs), with two by the MFMAs.  Per-site arithmetic is unchanged.
-template <int NT, int JT>  // NT: channel tiles of the deconv output per sub-site (CUP / 16)
-__global__ void __launch_bounds__(64, 2) k_deconv_head(const float* __restrict__ x, uint32_t n_site, int ld_x, int n16_in,
+template <int NT>  // channel tiles of the deconv output per sub-site (CUP / 16)
+__global__ void __launch_bounds__(64) k_deconv_head(const float* __restrict__ x, uint32_t n_site, int ld_x, int n16_in,
                                                      const float* __restrict__ wd, const float* __restrict__ bd,
                                                      const float* __restrict__ wh, const float* __restrict__ bh,
                                                      float* __restrict__ head, int ld_head, int head_cout) {
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const uint32_t sub = blockIdx.x & 3u, rg = blockIdx.x >> 2;
+    const uint32_t row = rg * 16u + (uint32_t)j;
+    const uint32_t rowc = row < n_site ? row : n_site - 1;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_site * ld_x * 4), 0x00020000);
     const uint32_t ntile_d = 4u * NT;  // channel tiles of the packed deconv layer
     const __amdgpu_buffer_rsrc_t rs_wd =
         __builtin_amdgcn_make_buffer_rsrc((void*)wd, 0, (int)((size_t)n16_in * ntile_d * 1024u), 0x00020000);
-    f32x4 acc[NT][JT];
-    uint32_t row[JT], xoff[JT];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int r = 0; r < JT; ++r) {
-        row[r] = (rg * JT + r) * 16u + (uint32_t)j;
-        const uint32_t rowc = row[r] < n_site ? row[r] : n_site - 1;
-        xoff[r] = rowc * (uint32_t)ld_x * 4u + (uint32_t)g * 16u;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t xoff = rowc * (uint32_t)ld_x * 4u + (uint32_t)g * 16u;
     const uint32_t woff = (sub * NT * 256u + (uint32_t)lane * 4u) * 4u;
     for (int c = 0; c < n16_in; ++c) {
-        f32x4 b[JT];
-#pragma unroll
-        for (int r = 0; r < JT; ++r)
-            b[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[r], (uint32_t)c * 64u, 0));
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (uint32_t)c * 64u, 0));
         const uint32_t sw = (uint32_t)c * ntile_d * 1024u;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wd, woff + (uint32_t)t * 1024u, sw, 0));
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int r = 0; r < JT; ++r) acc[t][r] = MFMA(a[s2], b[r][s2], acc[t][r]);
+            for (int s2 = 0; s2 < 4; ++s2) acc[t] = MFMA(a[s2], b[s2], acc[t]);
         }
     }
     // deconv epilogue (folded BN shift, ReLU) in registers
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const f32x4 bv = *(const f32x4*)(bd + (sub * NT + t) * 16u + 4u * g);
+        acc[t] += bv;
 #pragma unroll
-        for (int r = 0; r < JT; ++r) {
-            acc[t][r] += bv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[t][r][q] = fmaxf(acc[t][r][q], 0.f);
-        }
+        for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
     }
     // heads: contraction over the NT*16 channels just computed; wh packed [chunk = NT][tile = 1][lane][4]
-    f32x4 o[JT];
-#pragma unroll
-    for (int r = 0; r < JT; ++r) o[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const f32x4 a2 = *(const f32x4*)(wh + ((size_t)t * 64 + lane) * 4);
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-            for (int r = 0; r < JT; ++r) o[r] = MFMA(a2[s2], acc[t][r][s2], o[r]);
+        for (int s2 = 0; s2 < 4; ++s2) o = MFMA(a2[s2], acc[t][s2], o);
     }
+    if (row >= n_site) return;
     const uint32_t co0 = 4u * g;
     if ((int)co0 >= head_cout) return;
-    const f32x4 hb = *(const f32x4*)(bh + co0);
+    o += *(const f32x4*)(bh + co0);
+    float* op = head + ((size_t)row * 4 + sub) * ld_head + co0;
+    if ((int)co0 + 3 < head_cout && (ld_head & 3) == 0) {
+        *(f32x4*)op = o;
+    } else {
 #pragma unroll
-    for (int r = 0; r < JT; ++r) {
-        if (row[r] >= n_site) continue;
-        const f32x4 v = o[r] + hb;
-        float* op = head + ((size_t)row[r] * 4 + sub) * ld_head + co0;
-        if ((int)co0 + 3 < head_cout && (ld_head & 3) == 0) {
-            *(f32x4*)op = v;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((int)co0 + q < head_cout) op[q] = v[q];
-        }
+        for (int r = 0; r < 4; ++r)
+            if ((int)co0 + r < head_cout) op[r] = o[r];
     }
 }
 
@@ -755,13 +733,8 @@ extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int 
     const long groups = (long)((n_site + 15) / 16);
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 1; ps.meta[1] = cin; ps.meta[2] = 4 * cup; ps.meta[3] = n_site;
-    // two row groups per wave when the launch has groups to spare (a launch set), one for a single image
-    if (groups >= 4096)
-        INSMOS_LAUNCH((k_deconv_head<16, 2>), dim3((unsigned)(((groups + 1) / 2) * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16,
-                      wd_packed, bd, wh_packed, bh, head, ld_head, head_cout);
-    else
-        INSMOS_LAUNCH((k_deconv_head<16, 1>), dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed,
-                      bd, wh_packed, bh, head, ld_head, head_cout);
+    INSMOS_LAUNCH(k_deconv_head<16>, dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed, bd,
+                  wh_packed, bh, head, ld_head, head_cout);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

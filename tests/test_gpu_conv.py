@@ -212,11 +212,10 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
     assert torch.equal(out_s[5:], full)
 
 
-@pytest.mark.parametrize("n_site", [1000, 16 * 4096 + 37])
+@pytest.mark.parametrize("n_site", [1000, 18750 * 2 + 5])
 def test_fused_deconv_head_is_bitwise_the_two_launches(n_site):
     """insmos_deconv_head (ConvTranspose2d(2,2)+BN+ReLU and the 1x1 heads in one kernel, base_bev_backbone.py:104-115,
-    center_head.py:65-72) == the deconv as a 1x1 layer followed by the head layer, bit for bit -- with one row group per wave
-    (a single image) and with two (a launch set: >= 4096 groups)."""
+    center_head.py:65-72) == the deconv as a 1x1 layer followed by the head layer, bit for bit."""
     from gpu_util import dev, lib, pack_layer, run_conv, stream
     from insmos_amd import _lib
     rng = np.random.default_rng(n_site)
