@@ -556,20 +556,29 @@ __global__ void k_vox_pcid(const uint64_t* __restrict__ keys_s, const int32_t* _
 // ---------------------------------------------------------------------------------------------------
 struct DownParams { int ks[3], st[3], pd[3], oshape[3]; };   // (cells of a batch: window b owns bits [b*cells, (b+1)*cells))
 
-// mark every output cell some tap of some active input reaches, in an occupancy bitmap of the output grid
-__global__ void k_down_mark(const int32_t* __restrict__ in_coords, int64_t n_in, int K, DownParams P,
-                            uint32_t* __restrict__ bitmap) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_in * K) return;
-    int64_t i = t / K;
-    int k = (int)(t % K);
-    int kx = k % P.ks[2], ky = (k / P.ks[2]) % P.ks[1], kz = k / (P.ks[2] * P.ks[1]);
+// mark every output cell some tap of some active input reaches, in an occupancy bitmap of the output grid.  One thread per
+// INPUT voxel: along each axis the outputs o with 0 <= i + pad - o*stride < ksize form a short interval (1-2 cells for the
+// 3/2/1 maps), so the voxel walks its <= 8 reachable cells instead of testing all 27 taps
+__global__ void k_down_mark(const int32_t* __restrict__ in_coords, int64_t n_in, DownParams P, uint32_t* __restrict__ bitmap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
     int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
-    int nz = c.y + P.pd[0] - kz, ny = c.z + P.pd[1] - ky, nx = c.w + P.pd[2] - kx;
-    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % P.st[0] == 0 && ny % P.st[1] == 0 && nx % P.st[2] == 0) {
-        uint64_t key = key3b_encode(c.x, nz / P.st[0], ny / P.st[1], nx / P.st[2], P.oshape[0], P.oshape[1], P.oshape[2]);
-        if (key != INSMOS_INVALID_KEY) atomicOr(&bitmap[key >> 5], 1u << (unsigned)(key & 31));
+    const int in[3] = {c.y, c.z, c.w};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int top = in[d] + P.pd[d];                     // o*st <= top
+        const int bot = top - P.ks[d] + 1;                   // o*st >= bot
+        hi[d] = top >= 0 ? top / P.st[d] : -1;
+        lo[d] = bot > 0 ? (bot + P.st[d] - 1) / P.st[d] : 0;
+        if (hi[d] > P.oshape[d] - 1) hi[d] = P.oshape[d] - 1;
     }
+    for (int oz = lo[0]; oz <= hi[0]; ++oz)
+        for (int oy = lo[1]; oy <= hi[1]; ++oy)
+            for (int ox = lo[2]; ox <= hi[2]; ++ox) {
+                const uint64_t key = key3b_encode(c.x, oz, oy, ox, P.oshape[0], P.oshape[1], P.oshape[2]);
+                atomicOr(&bitmap[key >> 5], 1u << (unsigned)(key & 31));
+            }
 }
 __global__ void k_word_popc(const uint32_t* __restrict__ bitmap, int64_t nwords, int32_t* __restrict__ cnt) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1102,7 +1111,7 @@ extern "C" int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, co
     {
         ProfScope ps(KK_DOWN_CAND, s);
         HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, s));
-        INSMOS_LAUNCH(k_down_mark, dim3(cdiv(N, TPB)), dim3(TPB), 0, s, in_coords, n_in, K, P, bitmap);
+        INSMOS_LAUNCH(k_down_mark, dim3(cdiv(n_in, TPB)), dim3(TPB), 0, s, in_coords, n_in, P, bitmap);
         INSMOS_LAUNCH(k_word_popc, dim3(cdiv(nwords, TPB)), dim3(TPB), 0, s, bitmap, nwords, cnt);
     }
     int rc = inclusive_scan_i32(tmp, sc, cnt, scan, (size_t)nwords, s);

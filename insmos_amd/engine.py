@@ -843,15 +843,21 @@ class Engine:
             nb = count * torch.empty((), dtype=dtype).element_size()
             return a[off:off + nb].view(dtype).reshape(shape).clone()  # the arena is rewritten by the next batch
 
-        results = []
-        for out in outs:
+        # the arena is rewritten by the next launch set: ONE copy per output array and set (the windows' slices of it are
+        # views), not four per window
+        pm = self.post_max
+        n_all = sum(int(o.n_cur) for o in outs)
+        logits_all = view(outs[0].logits_off, n_all * 3, torch.float32, (n_all, 3))
+        boxes_all = view(outs[0].boxes_off, B * pm * 7, torch.float32, (B, pm, 7))
+        scores_all = view(outs[0].scores_off, B * pm, torch.float32, (B, pm))
+        labels_all = view(outs[0].labels_off, B * pm, torch.int64, (B, pm))
+        cur_all = view(outs[0].cur_points_off, n_all * 8, torch.float32, (n_all, 8)) if self.keep_current_points else None
+        results, c0 = [], 0
+        for b, out in enumerate(outs):
             ncur, K = int(out.n_cur), int(out.n_boxes)
-            logits = view(out.logits_off, ncur * 3, torch.float32, (ncur, 3))
-            pred = {"pred_boxes": view(out.boxes_off, K * 7, torch.float32, (K, 7)),
-                    "pred_scores": view(out.scores_off, K, torch.float32, (K,)),
-                    "pred_labels": view(out.labels_off, K, torch.int64, (K,))}
-            cur = view(out.cur_points_off, ncur * 8, torch.float32, (ncur, 8)) if self.keep_current_points else None
-            results.append((logits, pred, cur))
+            pred = {"pred_boxes": boxes_all[b, :K], "pred_scores": scores_all[b, :K], "pred_labels": labels_all[b, :K]}
+            results.append((logits_all[c0:c0 + ncur], pred, cur_all[c0:c0 + ncur] if cur_all is not None else None))
+            c0 += ncur
         o0 = outs[0]
         self.last_counts = {"me_voxels": [int(v) for v in o0.me_voxels], "n_cur": int(o0.n_cur),
                             "unet_voxels": [int(v) for v in o0.unet_voxels], "n_boxes": int(o0.n_boxes),
