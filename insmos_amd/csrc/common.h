@@ -115,7 +115,7 @@ __host__ __device__ __forceinline__ uint64_t key3b_encode(int b, int z, int y, i
     return k == INSMOS_INVALID_KEY ? k : k + (uint64_t)b * ((uint64_t)D * (uint64_t)H * (uint64_t)W);
 }
 
-// ---- several windows in one launch set (docs/round2_batching_plan.md) ----------------------------------------------
+// ---- several windows in one launch set ----------------------------------------------
 // The point clouds of the B windows of a batch stay where the caller has them: kernels that read points take this table
 // by value (kernel-argument memory: every access below is a wave-uniform scalar load) and locate a global point index
 // i in [0, start[B]) with a short select chain.

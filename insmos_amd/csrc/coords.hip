@@ -102,7 +102,7 @@ __global__ void k_quant_keys(const float* __restrict__ pts, int64_t n, int ld, f
     tflag[i] = (ft == 0.0f) ? 1 : 0;
 }
 
-// ---- several windows in ONE coordinate set (docs/round2_batching_plan.md): the window index b is folded into the time
+// ---- several windows in ONE coordinate set: the window index b is folded into the time
 // coordinate, t' = floor(t / dt) * B + b.  Time has no bounds and no striding and every table kernel treats time taps
 // symbolically, so with the searched (coarsest) table built on time offsets scaled by B nothing else has to know about
 // windows: rows stay time-major (the newest scans of ALL windows are one suffix), windows never share a neighbour.

@@ -321,7 +321,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     def motionnet(self, pts, win_sizes=None):
         """pts (N, ld>=5) fp32 device [x,y,z,r,t] -> current_point (Ncur, 8) [x,y,z,r,m0,m1,m2,0].
-        win_sizes (docs/round2_batching_plan.md): pts holds B = len(win_sizes) windows back to back; the window index is
+        win_sizes: pts holds B = len(win_sizes) windows back to back; the window index is
         folded into the time coordinate (t' = t * B + b), the searched table is built on time offsets scaled by B,
         everything else runs unchanged on B x the rows -> current points of all windows in input order (window-major).
         (The product path for batches is the native runner, insmos_forward_windows; this is its inspectable 4D half.)"""
@@ -512,7 +512,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------
     def motionnet_windows(self, pts_list):
-        """EXPERIMENTAL (docs/round2_batching_plan.md, step 1): MotionNet of several windows in ONE set of launches ->
+        """The 4D half of a launch set on the step path: MotionNet of several windows in ONE set of launches ->
         list of current_point tensors, each bit-identical to motionnet() of that window alone."""
         B = len(pts_list)
         if B == 1:

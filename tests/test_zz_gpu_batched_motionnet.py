@@ -1,4 +1,4 @@
-"""-m gpu: MotionNet of several windows in one set of launches (Engine.motionnet_windows; docs/round2_batching_plan.md
+"""-m gpu: MotionNet of several windows in one set of launches (Engine.motionnet_windows; DESIGN.md section 2
 step 1) must give every window the bits it gets alone."""
 
 import numpy as np

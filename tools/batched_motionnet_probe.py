@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/batched_motionnet_probe.py -- first measurement for docs/round2_batching_plan.md: MotionNet of B S0 windows in one
+"""tools/batched_motionnet_probe.py -- first measurement for DESIGN.md section 2: MotionNet of B S0 windows in one
 set of launches (Engine.motionnet_windows) against the same windows one after the other, step path, one stream.
 
     python tools/batched_motionnet_probe.py [B=4] [n_az=1886]
