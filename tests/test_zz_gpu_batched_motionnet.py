@@ -22,13 +22,10 @@ def test_batched_motionnet_matches_single_windows(B):
         batched = eng.motionnet_windows(wins)
         assert len(batched) == B
         for a, b in zip(single, batched):
-            # per-row arithmetic is the same; the conv kernel's tile / split variant is picked per launch, and a split
-            # variant sums its partial results in a different (still fixed) order, so equality is to fp32 round-off
-            # unless every layer happens to pick the same variant at both sizes
+            # a row's value does not depend on the rows sharing its tile (tap-split tiles hand taps to waves by tap index):
+            # the same bits whatever the batch
             assert a.shape == b.shape
-            assert torch.equal(a[:, :4], b[:, :4])
-            assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())
-            print("B", B, "prune", prune, "bitwise", bool(torch.equal(a, b)))
+            assert torch.equal(a, b), float((a - b).abs().max())
     # the batched coordinate set is the union of the windows' sets, window index folded into t
     n_single = []
     for w in wins:
