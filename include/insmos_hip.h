@@ -275,6 +275,9 @@ int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, c
 int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd, int cup,
                        const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head, void* stream);
 int insmos_debug_conv_force(int cot, int jt, int ring);
+/* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
+ * both produce the same bits (tests/test_gpu_conv.py). */
+int insmos_debug_conv_quad(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * insmos_dense_nbr2d -- full-grid 3x3 (pad 1) neighbour table for an H x W NHWC map, so that the

@@ -395,6 +395,200 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-chunk layers (Cin = 8, or 16: one chunk per tap; 16 rows x COT channel tiles per wave) with QUAD INDEX LOADS.
+// These layers are bound by the texture-address unit: ~16 cycles per wave-wide vector memory instruction whatever it
+// fetches, and k_sparse_conv issues three per tap here (neighbour indices, gather, weight fragment).  The index load is
+// the wasteful one: 64 lanes fetch 16 distinct dwords (the four lane groups g read the same 16 rows).  This kernel
+// fetches the indices of FOUR taps with one instruction -- lane (g, j) reads row j under the g-th tap of a quad -- and
+// hands each tap's 16 indices to all four lane groups with a ds_bpermute (LDS crossbar, no memory traffic): 2.25 vector
+// memory instructions per tap instead of 3.
+//
+// Pipeline (per wave, item = tap): operand ring of 4 slots requested 3 taps ahead; the bpermute of tap n+4 is issued at
+// step n and consumed at step n+1; the index quad Q+2 is requested at the first step of quad Q and rotated into place
+// after its last (a load issued four steps earlier).  Taps past the end of the tile's list re-request the last tap (clamp,
+// no guard).  Per output row the operation order is that of k_sparse_conv<COT, 1, CK, false, *, 1, false>: same bits.
+template <int COT, int CK>
+__global__ void __launch_bounds__(64) k_sparse_conv_q(ConvP P) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const uint32_t n_out = P.n_out;
+    const uint32_t ld4 = (uint32_t)P.ld_in * 4u;
+    const uint32_t n4 = n_out * 4u;  // bytes per tap row of the neighbour table
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, 0, (int)P.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_nb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.nbr, 0, (int)((uint32_t)P.K * n4), 0x00020000);
+    constexpr uint32_t LW = CK == 8 ? 8u : 16u;  // bytes per lane per gather
+    constexpr uint32_t LWF = CK == 8 ? 2u : 4u;  // floats per lane per weight fragment
+    constexpr uint32_t FR = 64u * LWF;
+    const uint32_t goff = (uint32_t)g * LW;
+    const uint32_t tap_stride = (uint32_t)P.ntile_co * FR;  // one chunk block per tap
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((uint32_t)P.K * tap_stride * 4u), 0x00020000);
+    constexpr int NS = CK ? CK / 4 : 4;
+    const uint32_t cout = P.cout;
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t cg = tile / P.n_otiles;
+    const uint32_t ot = tile % P.n_otiles;
+    const uint32_t orow = P.row0 + ot * 16 + j;
+    const uint32_t rowoff = (orow < n_out ? orow : n_out - 1) * 4u;
+
+    uint64_t tlo, thi;
+    if (P.mask16) {
+        const uint32_t* mp = P.mask16 + (size_t)((P.row0 >> 4) + ot) * 4;
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(mp[0]), w1 = __builtin_amdgcn_readfirstlane(mp[1]);
+        const uint32_t w2 = __builtin_amdgcn_readfirstlane(mp[2]), w3 = __builtin_amdgcn_readfirstlane(mp[3]);
+        tlo = ((uint64_t)w1 << 32) | w0;
+        thi = ((uint64_t)w3 << 32) | w2;
+    } else {
+        const int K = P.K;
+        tlo = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+        thi = K > 64 ? (K >= 128 ? ~0ull : ((1ull << (K - 64)) - 1ull)) : 0ull;
+    }
+    const int nt = __builtin_popcountll(tlo) + __builtin_popcountll(thi);
+
+    f32x4 acc[COT];
+#pragma unroll
+    for (int it = 0; it < COT; ++it) acc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t woffv[COT];  // lanes whose output channel lies beyond Cout read zeros from past the end of the buffer
+#pragma unroll
+    for (int it = 0; it < COT; ++it) {
+        const uint32_t co = (cg * COT + it) * 16u + (uint32_t)(lane & 15);
+        woffv[it] = co < cout ? ((cg * COT + it) * FR + lane * LWF) * 4u : 0x7FFFFFF0u;
+    }
+
+    const uint32_t gm[4] = {g == 0 ? ~0u : 0u, g == 1 ? ~0u : 0u, g == 2 ? ~0u : 0u, g == 3 ? ~0u : 0u};
+    auto pop4 = [&](int (&k)[4], int keep) {
+        k[0] = pop_or_keep(tlo, thi, keep);
+        k[1] = pop_or_keep(tlo, thi, k[0]);
+        k[2] = pop_or_keep(tlo, thi, k[1]);
+        k[3] = pop_or_keep(tlo, thi, k[2]);
+    };
+    // lane (g, j): neighbour index of row j under the g-th tap of the quad
+    auto load_quad = [&](const int (&k)[4]) -> uint32_t {
+        // (bitwise select on lane masks: a ?: chain over k[] made hipcc spill the tap ids to a scratch array indexed by g)
+        const uint32_t ksel = ((uint32_t)k[0] & gm[0]) | ((uint32_t)k[1] & gm[1]) | ((uint32_t)k[2] & gm[2]) | ((uint32_t)k[3] & gm[3]);
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff + ksel * n4, 0, 0);
+    };
+    const int bp = j * 4;  // ds_bpermute byte address of lane (0, j)
+    auto quad_tap = [&](uint32_t iq, int p) -> uint32_t {  // the 16 indices of the quad's p-th tap, to every lane group
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(bp + 64 * p, (int)iq);
+    };
+    auto load_ab = [&](int k, uint32_t idx, f32x4 (&a)[COT], f32x4& b) {
+        const uint32_t off = idx * ld4 + goff;  // index -1 wraps past the end of the buffer -> the load returns 0
+        if constexpr (CK == 8) {
+            f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, 0, 0));
+            b = (f32x4){t[0], t[1], 0.f, 0.f};
+        } else {
+            b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+        }
+        const uint32_t sw = (uint32_t)k * tap_stride * 4u;
+#pragma unroll
+        for (int it = 0; it < COT; ++it) {
+            if constexpr (CK == 8) {
+                f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, woffv[it], sw, 0));
+                a[it] = (f32x4){t[0], t[1], 0.f, 0.f};
+            } else {
+                a[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw, 0));
+            }
+        }
+    };
+    auto mma = [&](const f32x4 (&a)[COT], const f32x4& b) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int it = 0; it < COT; ++it) acc[it] = MFMA(a[it][s], b[s], acc[it]);
+    };
+
+    if (nt > 0) {
+        int kqA[4], kqB[4], kqC[4];  // tap ids of the current quad and the next two (SGPRs)
+        pop4(kqA, 0);
+        pop4(kqB, kqA[3]);
+        pop4(kqC, kqB[3]);
+        uint32_t iqB, iqC, pidx;
+        f32x4 as[4][COT], bs[4];
+        {
+            const uint32_t iqA = load_quad(kqA);
+            iqB = load_quad(kqB);
+            const uint32_t p0 = quad_tap(iqA, 0), p1 = quad_tap(iqA, 1), p2 = quad_tap(iqA, 2);
+            pidx = quad_tap(iqA, 3);
+            load_ab(kqA[0], p0, as[0], bs[0]);
+            load_ab(kqA[1], p1, as[1], bs[1]);
+            load_ab(kqA[2], p2, as[2], bs[2]);
+        }
+        // one quad of steps: bpermutes read `src` (quad Q+1), the load of quad Q+2 lands in `dst`.  The two index registers
+        // swap roles every quad (no copy of a just-loaded register: that would wait for the load at the loop back-edge)
+        auto quad = [&](const uint32_t& src, uint32_t& dst) {
+            dst = load_quad(kqC);  // (tap ids popped one quad earlier: no scalar chain in front of the load)
+            __builtin_amdgcn_sched_barrier(0);
+            int kqD[4];
+            pop4(kqD, kqC[3]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                load_ab(s == 0 ? kqA[3] : kqB[s - 1], pidx, as[(s + 3) & 3], bs[(s + 3) & 3]);  // tap i + s + 3
+                pidx = quad_tap(src, s);                                                          // tap i + s + 4
+                mma(as[s], bs[s]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { kqA[q] = kqB[q]; kqB[q] = kqC[q]; kqC[q] = kqD[q]; }
+        };
+        int i = 0;
+        for (; i + 8 <= nt; i += 8) {
+            quad(iqB, iqC);
+            quad(iqC, iqB);
+        }
+        if (i + 4 <= nt) {
+            quad(iqB, iqC);
+            i += 4;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (i + s < nt) mma(as[s], bs[s]);  // wave-uniform tail, at most 3 taps (operands already in flight)
+        }
+    }
+
+    // ---- epilogue: lane (g, j) holds channels co0..co0+3 of row orow (same as k_sparse_conv's)
+#pragma unroll
+    for (int it = 0; it < COT; ++it) {
+        const uint32_t co0 = (cg * COT + it) * 16 + 4 * g;
+        if (orow >= n_out || co0 >= cout) continue;
+        f32x4 v = acc[it];
+        v += *(const f32x4*)(P.bias + co0);
+        if (P.relu_pre) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (P.res_mode == 1) {
+            const float* rp = P.res + (size_t)orow * P.ld_res + co0;
+            if (P.vec_store && co0 + 3 < cout) {
+                v += *(const f32x4*)rp;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < cout) v[r] += rp[r];
+            }
+        } else if (P.res_mode == 2) {
+            const float* rp = P.res + (size_t)orow * P.ld_res + 2 * co0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < cout) v[r] += rp[2 * r] + rp[2 * r + 1];
+        }
+        if (P.relu_post) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        float* op = P.out + (size_t)orow * P.ld_out + co0;
+        if (P.vec_store && co0 + 3 < cout) {
+            *(f32x4*)op = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < cout) op[r] = v[r];
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused ConvTranspose2d(k=2,s=2)+BN+ReLU and the 1x1 heads (base_bev_backbone.py:104-115 deblocks, center_head.py:65-72).
@@ -569,6 +763,7 @@ ConvKernel pick_split(int cot, int ck, bool by_chunk) {
 
 // tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
+int g_quad = -1;  // quad-index kernel for single-chunk layers: -1 = read INSMOS_CONV_QUAD (default on)
 // probe variants of the kernel configurations the heavy S0 layers use (ring >= 16 selects dbg = ring / 16)
 template <int DBG>
 ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
@@ -671,6 +866,14 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
             kern = sk;
         }
     }
+    // single-chunk unsplit layers: quad index loads (same bits, fewer vector memory instructions per tap)
+    if (g_quad < 0) g_quad = env_int("INSMOS_CONV_QUAD", 1);
+    // (measured per layer on a launch set of 8 S0 windows: -7...-13 % on the 27- and 81-tap layers and on the 8-tap 16-channel
+    //  ones, +3...5 % on the 8-tap Cin = 8 layers, whose whole tap list is two quads: those stay on the generic kernel)
+    if (g_quad && !ident && split == 1 && best.jt == 1 && best.cot <= 2 && ((ck == 8 && K >= 16) || (ck == 0 && P.n16 == 1))) {
+        if (ck == 8) kern = best.cot == 1 ? k_sparse_conv_q<1, 8> : k_sparse_conv_q<2, 8>;
+        else kern = best.cot == 1 ? k_sparse_conv_q<1, 0> : k_sparse_conv_q<2, 0>;
+    }
     if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
         ConvKernel fk = pick_forced(g_force_cot, g_force_jt, g_force_ring);
         if (fk) {
@@ -742,6 +945,11 @@ extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int 
 extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {
     g_dbg = ring / 16;
     g_force_cot = cot; g_force_jt = jt; g_force_ring = ring % 16;
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_debug_conv_quad(int on) {
+    g_quad = on ? 1 : 0;
     return INSMOS_OK;
 }
 

@@ -22,7 +22,7 @@ def _rand_nbr(rng, K, n_out, n_in, density):
     (48, 32, 81, 260, 0.3), (32, 32, 8, 4000, 0.13), (7, 16, 27, 2000, 0.3), (131, 128, 27, 500, 0.4),
     (67, 64, 27, 300, 0.4), (35, 32, 27, 300, 0.4), (19, 16, 27, 129, 0.4), (256, 128, 27, 200, 0.5),
     (128, 128, 3, 64, 0.7), (16, 3, 1, 1000, 1.0), (8, 3, 1, 70, 1.0), (64, 64, 27, 70000, 0.25),
-    # >= 2048 row groups, one or two channel tiles: the weights-in-LDS variant
+    # >= 2048 row groups, one or two channel tiles
     (8, 8, 81, 40000, 0.2), (16, 8, 81, 36000, 0.2), (16, 16, 27, 40000, 0.3), (8, 16, 27, 33000, 0.3),
     (32, 16, 27, 34000, 0.3), (16, 32, 27, 35011, 0.3), (8, 8, 8, 33000, 0.13)])
 def test_sparse_conv_matches_oracle(cin, cout, K, n_out, density):
@@ -210,6 +210,59 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
     res_s = dev(np.concatenate([res[777:782], res])) if res_mode else None
     out_s = run(shifted, res_t=res_s)
     assert torch.equal(out_s[5:], full)
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
+    (8, 8, 81, 40003, 1), (8, 16, 81, 5000, 0), (16, 16, 81, 33333, 1), (16, 8, 81, 2049, 0), (16, 16, 27, 40000, 2),
+    (8, 16, 27, 777, 0), (16, 32, 27, 3000, 1), (8, 8, 8, 33000, 0), (16, 16, 8, 1000, 0), (16, 16, 3, 17, 0), (8, 32, 27, 4100, 0)])
+def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_mode):
+    """Single-chunk layers run on k_sparse_conv_q (index loads of four taps at a time, ds_bpermute to the lane groups): the
+    same bits as the generic kernel with and without active-tap masks, for every epilogue, for a row suffix, and for tap lists
+    of every length modulo 8 (the quad pipeline's tails)."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(K * 100 + cin + cout)
+    n_in = max(n_out // 2, 40)
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    ngrp = (n_out + 15) // 16
+    n_act = rng.integers(0, K + 1, size=ngrp)                         # active taps per 16-row group: every count 0..K
+    grp = np.zeros((K, ngrp), bool)
+    for gi in range(ngrp):
+        grp[rng.permutation(K)[:n_act[gi]], gi] = True
+    nbr[~(np.repeat(grp, 16, axis=1)[:, :n_out] & (rng.uniform(size=(K, n_out)) < 0.7))] = -1
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.3)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    xd, nd, md = dev(x), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+
+    def run(quad, masked, row0=0):
+        lib().insmos_debug_conv_quad(quad)
+        try:
+            out = torch.full((n_out, cout), -7.0, device="cuda:0")
+            _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr() if masked else None,
+                                                     K, n_out, row0, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout,
+                                                     layer.cout, res.data_ptr() if res is not None else None, ld_res if res_mode else 0,
+                                                     res_mode, 1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib().insmos_debug_conv_quad(1)
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    for masked in (True, False):
+        a, b = run(1, masked), run(0, masked)
+        assert torch.equal(a, b)
+        np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    r0 = 16 * (n_out // 48)
+    assert torch.equal(run(1, True, r0)[r0:], run(0, True, r0)[r0:])
 
 
 @pytest.mark.parametrize("n_site", [1000, 18750 * 2 + 5])
