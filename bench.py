@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
     ap.add_argument("--windows-per-step", type=int, default=24, help="batch items of one forward() = one step")
+    ap.add_argument("--conv-precision", type=int, default=0, choices=[0, 3],
+                    help="EXPERIMENT ONLY (the line is then labelled as such and is not the benchmark): 3 = split-bf16 x 3 "
+                         "convolutions (include/insmos_hip.h: insmos_conv_precision); 0 = exact fp32, the product path")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for a multi-rank "
                                                                "dry run of this script on a one-GPU box)")
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; the dry run puts "
@@ -229,6 +232,8 @@ def main():
     calibrate_head(model, pts, args.candidates, cache=args.calibration, tag=f"rank{rank}_az{args.n_az}_c{args.candidates}",
                    load_only=args.timed_only)
     eng = model.model.engine
+    if args.conv_precision:
+        eng.set_conv_precision(args.conv_precision)
     wpl = min(W, model.model.windows_per_launch)
     in_flight = min((W + wpl - 1) // wpl, model.model.windows_in_flight)
     batch = [{"past_point_clouds": p} for p in pts_list]
@@ -268,7 +273,9 @@ def main():
     out = {
         "metric": "scans_per_sec", "value": round(value, 3), "unit": "scans/s (windows of N=10 scans, ~120k pts/scan)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if not args.conv_precision else "EXPERIMENT split-bf16x3 (NOT the product path, NOT a benchmark line)",
+        "data": "synthetic",
         "config": {"workload": "cfg-2: synthetic S0 windows, N=10 scans, voxel 0.1 m, full InsMOS forward "
                                "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)",
                    "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,

@@ -274,6 +274,20 @@ int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, c
  * insmos_sparse_conv(deconv, relu) followed by insmos_sparse_conv(head). */
 int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd, int cup,
                        const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Reduced-precision convolution modes -- opt-in, process-wide, NEVER the default.  The inference path of this library is
+ * exact fp32 (v_mfma_f32_16x16x4_f32) and every parity claim and benchmark line is made in mode 0.
+ *   mode 0: exact fp32.
+ *   mode 1: operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x16_bf16) on the layers whose Cin is a multiple of
+ *           16 and that have a neighbour table -- the opt-in for the TRAINING convolutions (no reference counterpart: the
+ *           reference trains in fp32; config/config.yaml has no precision switch).
+ *   mode 3: the split-bf16 x 3 experiment (x = hi + lo, three bf16 MFMAs per chunk; ~2^-16 relative error per product) on
+ *           the layers whose split weights were registered; all others stay fp32.
+ * insmos_split_weights_bf16: out (n_floats * 4 bytes) = the packed fp32 weights with every lane's 4 floats replaced by
+ * (hi4 | lo4) bf16; insmos_register_split_weights(wpacked, wsplit): table entry (wsplit = NULL removes it). */
+int insmos_conv_precision(int mode);
+int insmos_split_weights_bf16(const float* wpacked, int64_t n_floats, void* out, void* stream);
+int insmos_register_split_weights(const float* wpacked, const void* wsplit);
 int insmos_debug_conv_force(int cot, int jt, int ring);
 /* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
  * both produce the same bits (tests/test_gpu_conv.py). */

@@ -68,6 +68,9 @@ SIGNATURES = {
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
+    "insmos_conv_precision": (c_int, [c_int]),
+    "insmos_split_weights_bf16": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "insmos_register_split_weights": (c_int, [c_vp, c_vp]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),
     "insmos_sparse_to_bev": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "insmos_center_decode_select_ws_bytes": (c_sz, [c_i64]),

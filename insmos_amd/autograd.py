@@ -36,11 +36,33 @@ def _packed(lib, taps, cin_pad, cout_store, transpose, mirror, st):
     return packed
 
 
+# Precision of the TRAINING convolutions (forward and d/dx; d/dW and every other kernel stay fp32).  0 = exact fp32 (default);
+# 1 = operands rounded to bf16, fp32 accumulate (include/insmos_hip.h: insmos_conv_precision) -- opt-in through
+# set_train_conv_precision(1) / InsMOSTrainer(bf16_convs=True) / INSMOS_TRAIN_BF16=1.  The library mode is process-wide: it is
+# switched around each training conv launch and back to exact fp32 right after, so inference calls made between training
+# steps are untouched (do not run inference on another host thread while a training step is in progress).
+_TRAIN_CONV_PRECISION = 0
+
+
+def set_train_conv_precision(mode):
+    global _TRAIN_CONV_PRECISION
+    if mode not in (0, 1):
+        raise ValueError("training conv precision: 0 (fp32) or 1 (bf16 operands, fp32 accumulate)")
+    _TRAIN_CONV_PRECISION = int(mode)
+
+
 def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
-                                      None, K, n_out, packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
-                                      0, 0, 0, 0, st), "insmos_sparse_conv")
+    mode = _TRAIN_CONV_PRECISION
+    if mode:
+        _lib.check(lib.insmos_conv_precision(mode), "insmos_conv_precision")
+    try:
+        _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
+                                          None, K, n_out, packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
+                                          0, 0, 0, 0, st), "insmos_sparse_conv")
+    finally:
+        if mode:
+            lib.insmos_conv_precision(0)
     return out
 
 

@@ -18,6 +18,7 @@
 // every output site a function of its own 3x3 neighbourhood only.  Weights are the same pre-packed A fragments
 // k_sparse_conv uses ([tap][chunk][channel tile][lane][4]); fragment roles as there: i = output channel, j = site.
 #include "common.h"
+#include "prec.h"
 
 namespace insmos {
 
@@ -31,7 +32,9 @@ constexpr int BEV_PITCH = 24;        // floats per halo site in LDS: 16 channels
 // YM: the 16-site row groups run along y (and the TH extent along x) instead of along x -- picked per launch so that the
 // patches pad the image as little as possible (150 x 125: 16-wide strips along x waste 6 % of the last strip, along y 2 %)
 // NCG: output-channel groups (waves = 2 row halves x NCG; a wave owns COT = Cout / 16 / NCG channel tiles)
-template <int TH, int COT, int NCG, bool YM>
+// PREC = 3: the split-bf16 x 3 experiment (prec.h; never the default): the halo is split into (hi4 | lo4) bf16 when it is
+// staged into LDS -- once per element, same 16 bytes per lane and the same bank pattern --, the weights arrive pre-split
+template <int TH, int COT, int NCG, bool YM, int PREC = 0>
 __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty) {
@@ -79,7 +82,15 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     auto stage = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (dst[q] != 0xFFFFFFFFu) *(f32x4*)(&halo[buf][dst[q]]) = pf[q];
+            if (dst[q] != 0xFFFFFFFFu) {
+                if constexpr (PREC == 3) {
+                    s16x4 hi, lo;
+                    split_bf16(pf[q], hi, lo);
+                    *(f32x4*)(&halo[buf][dst[q]]) = pack_split(hi, lo);
+                } else {
+                    *(f32x4*)(&halo[buf][dst[q]]) = pf[q];
+                }
+            }
     };
 
     f32x4 acc[COT][JT];
@@ -124,12 +135,29 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
             f32x4 b[JT];
 #pragma unroll
             for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
+            if constexpr (PREC == 3) {
+                s16x4 ah[COT], al[COT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int it = 0; it < COT; ++it) unpack_split(a[k % 3][it], ah[it], al[it]);
 #pragma unroll
-                for (int r = 0; r < JT; ++r)
+                for (int r = 0; r < JT; ++r) {
+                    s16x4 bh, bl;
+                    unpack_split(b[r], bh, bl);
 #pragma unroll
-                    for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
+                    for (int it = 0; it < COT; ++it) {
+                        acc[it][r] = MFMA_BF16(al[it], bh, acc[it][r]);  // small terms first
+                        acc[it][r] = MFMA_BF16(ah[it], bl, acc[it][r]);
+                        acc[it][r] = MFMA_BF16(ah[it], bh, acc[it][r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int r = 0; r < JT; ++r)
+#pragma unroll
+                        for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
+            }
         }
         if (c + 1 < n16) stage(buf ^ 1);  // (that buffer was last read in chunk c-1; every wave is past that barrier)
         __syncthreads();
@@ -197,8 +225,17 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
     ps.meta[0] = 9; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = (int64_t)B * H * W;
     // Cout = 128: 2 x 4 waves of 2 channel tiles (10-row patches: the accumulators of 4 tiles x 5 row groups would leave one
     // wave per SIMD); Cout = 64: 2 x 2 waves of 2 tiles
-#define BEV_GO(TH_, NCG_, YM_) \
-    INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, out, ld_out, relu, n_tx, n_ty)
+    // (experiment, never the default: split-bf16 x 3 when the mode is set and this layer's split weights are registered)
+    const float* wsplit = conv_precision() == 3 ? (const float*)split_weights_of(wpacked) : nullptr;
+#define BEV_GO(TH_, NCG_, YM_)                                                                                                  \
+    do {                                                                                                                        \
+        if (wsplit)                                                                                                             \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 3>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wsplit, \
+                          bias, out, ld_out, relu, n_tx, n_ty);                                                                 \
+        else                                                                                                                    \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, \
+                          bias, out, ld_out, relu, n_tx, n_ty);                                                                 \
+    } while (0)
 #define BEV_TH(NCG_, YM_) \
     do { if (best_th == 10) BEV_GO(10, NCG_, YM_); else if (best_th == 8) BEV_GO(8, NCG_, YM_); else BEV_GO(4, NCG_, YM_); } while (0)
     if (cout == 128) { if (best_ym) BEV_TH(4, true); else BEV_TH(4, false); }

@@ -20,7 +20,10 @@
 // as A and B agree), which is what makes the gather a contiguous float4 per lane.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
+#include "prec.h"
 
 namespace insmos {
 
@@ -45,6 +48,7 @@ struct ConvP {
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
 
 // next active tap of the 128-bit set, or `keep` when the set is exhausted (branch-free scalar code)
 __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep) {
@@ -87,8 +91,9 @@ __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep)
 //    the slowest of four waves in its block;
 //  * masked layers with enough work per tile are SPLIT (above): 4x the waves, each a quarter as long.
 // DBG (probe builds only, tools/conv_probe.py): bit 0 = no weight loads, bit 1 = no gathers, bit 2 = no MFMAs
-template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0>
+template <int COT, int JT, int CK, bool IDENT, int R, int SPLIT, bool SPLITC, int DBG = 0, int PREC = 0>
 __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) {
+    static_assert(PREC == 0 || (CK == 0 && DBG == 0), "reduced-precision variants exist for 16-channel chunks only");
     static_assert(SPLIT == 1 || (JT == 1 && (COT % SPLIT == 0 || SPLIT % COT == 0)), "split tiles are 16 rows x all channels");
     static_assert(!SPLITC || (SPLIT > 1 && CK == 0), "chunk split needs 16-channel chunks");
     const int lane = threadIdx.x & 63;
@@ -259,6 +264,30 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
                 for (int jt = 0; jt < JT; ++jt) asm volatile("" ::"v"(b[jt]));
 #pragma unroll
                 for (int it = 0; it < COT; ++it) asm volatile("" ::"v"(a[it]));
+                return;
+            }
+            if constexpr (PREC == 1) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const s16x4 bh = round_bf16(b[jt]);
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) acc[it][jt] = MFMA_BF16(round_bf16(a[it]), bh, acc[it][jt]);
+                }
+                return;
+            } else if constexpr (PREC == 3) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    s16x4 bh, bl;
+                    split_bf16(b[jt], bh, bl);
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) {
+                        s16x4 ah, al;
+                        unpack_split(a[it], ah, al);
+                        acc[it][jt] = MFMA_BF16(al, bh, acc[it][jt]);  // small terms first
+                        acc[it][jt] = MFMA_BF16(ah, bl, acc[it][jt]);
+                        acc[it][jt] = MFMA_BF16(ah, bh, acc[it][jt]);
+                    }
+                }
                 return;
             }
 #pragma unroll
@@ -761,6 +790,27 @@ ConvKernel pick_split(int cot, int ck, bool by_chunk) {
     return nullptr;
 }
 
+// reduced-precision variants (insmos_conv_precision) of the kernels the 16-channel-chunk layers run on: split tiles and the
+// unsplit 16-row tile
+template <int PREC>
+ConvKernel pick_prec(int cot, int split, bool by_chunk) {
+    if (split == 4) {
+#define CASE(C, RR)                                                                                         \
+    if (cot == C)                                                                                           \
+        return by_chunk ? k_sparse_conv<C, 1, 0, false, RR, 4, true, 0, PREC> : k_sparse_conv<C, 1, 0, false, RR, 4, false, 0, PREC>;
+        CASE(8, 2) CASE(4, 2) CASE(2, 3) CASE(1, 3)
+#undef CASE
+        return nullptr;
+    }
+    if (cot == 1) return k_sparse_conv<1, 1, 0, false, 3, 1, false, 0, PREC>;
+    if (cot == 2) return k_sparse_conv<2, 1, 0, false, 3, 1, false, 0, PREC>;
+    if (cot == 4) return k_sparse_conv<4, 1, 0, false, 2, 1, false, 0, PREC>;
+    return nullptr;
+}
+int g_prec = 0;  // 0 = exact fp32 (the product default), 1 = bf16 operands, 3 = split-bf16 x 3 (see insmos_conv_precision)
+std::unordered_map<const float*, const void*> g_split_weights;  // packed fp32 weights -> their (hi | lo) bf16 split
+std::mutex g_split_mu;
+
 // tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
 int g_quad = -1;  // quad-index kernel for single-chunk layers: -1 = read INSMOS_CONV_QUAD (default on)
@@ -790,6 +840,15 @@ int env_int(const char* name, int dflt) {
 }
 
 }  // namespace
+
+namespace insmos {
+int conv_precision() { return g_prec; }
+const void* split_weights_of(const float* wpacked) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_weights.find(wpacked);
+    return it == g_split_weights.end() ? nullptr : it->second;
+}
+}  // namespace insmos
 
 static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, const int32_t* nbr,
                             const uint32_t* mask16, int K, int64_t n_out, int64_t row0, const float* wpacked,
@@ -874,6 +933,19 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         if (ck == 8) kern = best.cot == 1 ? k_sparse_conv_q<1, 8> : k_sparse_conv_q<2, 8>;
         else kern = best.cot == 1 ? k_sparse_conv_q<1, 0> : k_sparse_conv_q<2, 0>;
     }
+    // reduced precision (opt-in, never the default): 16-channel-chunk layers with a neighbour table
+    // (single-chunk layers stay fp32: they are vector-memory bound, measured 0.91x under the experiment)
+    if (g_prec && !ck && P.n16 >= 2 && !ident && best.jt == 1) {
+        int prec = g_prec;
+        if (prec == 3) {
+            const void* ws = split_weights_of(wpacked);
+            if (!ws) prec = 0;  // no split weights registered for this layer: exact fp32
+            else P.w = (const float*)ws;
+        }
+        ConvKernel pk = prec == 1 ? pick_prec<1>(best.cot, split, by_chunk) : prec == 3 ? pick_prec<3>(best.cot, split, by_chunk) : nullptr;
+        if (pk) kern = pk;
+        else P.w = wpacked;
+    }
     if (g_force_cot && !ck && !ident && P.ntile_co % g_force_cot == 0) {
         ConvKernel fk = pick_forced(g_force_cot, g_force_jt, g_force_ring);
         if (fk) {
@@ -945,6 +1017,39 @@ extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int 
 extern "C" int insmos_debug_conv_force(int cot, int jt, int ring) {
     g_dbg = ring / 16;
     g_force_cot = cot; g_force_jt = jt; g_force_ring = ring % 16;
+    return INSMOS_OK;
+}
+
+// fp32 packed weights -> (hi4 | lo4) bf16 per 16-byte lane slot; same indexing as the fp32 buffer
+__global__ void k_split_weights_bf16(const f32x4* __restrict__ w, int64_t n4, u32x2* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    s16x4 hi, lo;
+    insmos::split_bf16(w[i], hi, lo);
+    out[2 * i] = __builtin_bit_cast(u32x2, hi);
+    out[2 * i + 1] = __builtin_bit_cast(u32x2, lo);
+}
+
+extern "C" int insmos_split_weights_bf16(const float* wpacked, int64_t n_floats, void* out, void* stream) {
+    if (!wpacked || !out || n_floats <= 0 || n_floats % 4 != 0) return INSMOS_EINVAL;
+    const int64_t n4 = n_floats / 4;
+    INSMOS_LAUNCH(k_split_weights_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                  (const insmos::f32x4*)wpacked, n4, (insmos::u32x2*)out);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_register_split_weights(const float* wpacked, const void* wsplit) {
+    if (!wpacked) return INSMOS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    if (wsplit) g_split_weights[wpacked] = wsplit;
+    else g_split_weights.erase(wpacked);
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_conv_precision(int mode) {
+    if (mode != 0 && mode != 1 && mode != 3) return INSMOS_EINVAL;
+    g_prec = mode;
     return INSMOS_OK;
 }
 

@@ -288,6 +288,24 @@ class Engine:
             e1.record(torch.cuda.current_stream(self.device))
             self.layer_timing.append((layer.name, K, layer.cin, layer.cout, n_out, self._t0, e1))
 
+    def set_conv_precision(self, mode):
+        """EXPERIMENT / training opt-in, process-wide, never the default (include/insmos_hip.h: insmos_conv_precision).
+        0 = exact fp32; 1 = bf16 operands, fp32 accumulate; 3 = split-bf16 x 3 on every layer with Cin % 16 == 0 and a
+        neighbour table (their weights are split once, here, and registered)."""
+        mode = int(mode)
+        if mode == 3 and not getattr(self, "_split_w", None):
+            self._split_w = {}
+            for name, l in self.L.items():
+                if l.cin % 16 == 0 and l.K > 1:
+                    buf = torch.empty_like(l.w)
+                    _lib.check(self.lib.insmos_split_weights_bf16(l.w.data_ptr(), l.w.numel(), buf.data_ptr(), self._stream()),
+                               "insmos_split_weights_bf16")
+                    _lib.check(self.lib.insmos_register_split_weights(l.w.data_ptr(), buf.data_ptr()), "insmos_register_split_weights")
+                    self._split_w[name] = buf
+            torch.cuda.synchronize(self.device)
+        _lib.check(self.lib.insmos_conv_precision(mode), "insmos_conv_precision")
+        self.conv_precision = mode
+
     def bev_conv(self, layer, x, ld_in, out, ld_out):
         """One 3x3 layer of the dense BEV backbone (+ folded BN + ReLU): the LDS-tiled kernel (csrc/bev.hip) when the layer
         has a shape it is built for, else the generic kernel over the dense 9-tap table."""

@@ -15,6 +15,8 @@ in the kernels' tap layout (K, Cin, Cout); export_state_dict() converts back to 
 `bn_training=False` runs the same graph with running statistics: it must reproduce the inference path's logits
 (tests/test_train_unet.py), which pins the wiring to the oracle-checked forward.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -232,8 +234,16 @@ class InsMOSTrainer:
     """InsMOS_Model.forward(list, 'train') (models/models.py:297-345, 365-367): MotionNet and the 3D branch in train mode,
     loss = mean over the batch items of loss_rpn + loss_mos (+ loss_motion_encoder when MODEL.USE_MOTION_LOSS)."""
 
-    def __init__(self, cfg, state_dict, device="cuda:0"):
+    def __init__(self, cfg, state_dict, device="cuda:0", bf16_convs=None):
+        """bf16_convs (default: INSMOS_TRAIN_BF16=1 in the environment, else off): the training convolutions' forward and d/dx
+        round their operands to bf16 and accumulate in fp32 (autograd.set_train_conv_precision); everything else, and the
+        inference path always, stays fp32.  The reference trains in fp32 only (config/config.yaml has no precision key)."""
         from .train_motionnet import MotionNetTrainer
+        from . import autograd
+        if bf16_convs is None:
+            bf16_convs = os.environ.get("INSMOS_TRAIN_BF16", "0") == "1"
+        self.bf16_convs = bool(bf16_convs)
+        autograd.set_train_conv_precision(1 if self.bf16_convs else 0)
         self.cfg, self.device = cfg, torch.device(device)
         self.use_motion_loss = bool(cfg["MODEL"].get("USE_MOTION_LOSS", False))
         self.motion = MotionNetTrainer(cfg, state_dict, device)

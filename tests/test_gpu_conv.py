@@ -265,6 +265,122 @@ def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_m
     assert torch.equal(run(1, True, r0)[r0:], run(0, True, r0)[r0:])
 
 
+def _with_precision(mode, layers, fn):
+    """Run fn() in conv precision `mode` (3: with the layers' split weights registered); always back to exact fp32."""
+    from gpu_util import lib, stream
+    from insmos_amd import _lib
+    bufs = []
+    try:
+        if mode == 3:
+            for l in layers:
+                buf = torch.empty_like(l.w)
+                _lib.check(lib().insmos_split_weights_bf16(l.w.data_ptr(), l.w.numel(), buf.data_ptr(), stream()), "split")
+                _lib.check(lib().insmos_register_split_weights(l.w.data_ptr(), buf.data_ptr()), "register")
+                bufs.append(buf)
+            torch.cuda.synchronize()
+        _lib.check(lib().insmos_conv_precision(mode), "insmos_conv_precision")
+        return fn()
+    finally:
+        lib().insmos_conv_precision(0)
+        for l in layers:
+            lib().insmos_register_split_weights(l.w.data_ptr(), None)
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out", [(128, 128, 27, 20000), (64, 64, 27, 9000), (256, 128, 27, 3000), (32, 32, 81, 5000),
+                                              (48, 32, 81, 4000), (32, 64, 27, 4000), (32, 16, 27, 900), (64, 128, 27, 700)])
+def test_reduced_precision_modes_are_opt_in_and_accurate(cin, cout, K, n_out):
+    """insmos_conv_precision: mode 3 (split-bf16 x 3, the experiment) stays within ~1e-4 of the exact fp32 kernel relative to
+    the output scale, mode 1 (bf16 operands, training opt-in) within bf16's 2^-8 per product; a mode-3 layer WITHOUT registered
+    split weights, and everything after the mode is reset, is bit-identical fp32."""
+    from gpu_util import dev, pack_layer, run_conv, tap_masks, lib
+    rng = np.random.default_rng(cin * 7 + cout + K)
+    n_in = max(n_out // 2, 100)
+    nbr = _rand_nbr(rng, K, n_out, n_in, 0.35)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.35)).astype(np.float32)
+    layer = pack_layer(taps, rng.normal(size=cout).astype(np.float32), cin, cout)
+    xd, nd, md = dev(x), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+    run = lambda: run_conv(layer, xd, nd, n_out, mask=md)
+    exact = run()
+    scale = float(exact.abs().mean())
+    y3 = _with_precision(3, [layer], run)
+    assert not torch.equal(y3, exact)                                  # the variant really ran
+    assert float((y3 - exact).abs().max()) < 2e-4 * scale
+    y1 = _with_precision(1, [layer], run)
+    e1 = float((y1 - exact).abs().max())
+    assert 2e-4 * scale < e1 < 5e-2 * scale
+    assert torch.equal(_with_precision(3, [], run), exact)             # mode 3 without split weights: the fp32 kernel
+    assert torch.equal(run(), exact) and lib().insmos_conv_precision(2) != 0   # back to the default; unknown modes are refused
+
+
+def test_single_chunk_layers_ignore_the_precision_modes():
+    """Cin = 8 / 16 layers are vector-memory bound: they stay on the exact fp32 kernels in every mode."""
+    from gpu_util import dev, pack_layer, run_conv, tap_masks
+    rng = np.random.default_rng(3)
+    for cin, cout in ((16, 16), (8, 16)):
+        nbr = _rand_nbr(rng, 27, 3000, 1500, 0.4)
+        layer = pack_layer((rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32), np.zeros(cout, np.float32), cin, cout)
+        xd, nd, md = dev(rng.normal(size=(1500, cin)).astype(np.float32)), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+        run = lambda: run_conv(layer, xd, nd, 3000, mask=md)
+        exact = run()
+        assert torch.equal(_with_precision(3, [layer], run), exact) and torch.equal(_with_precision(1, [layer], run), exact)
+
+
+def test_training_convs_bf16_opt_in():
+    """autograd.set_train_conv_precision(1): forward and d/dx of the training conv round their operands to bf16 (fp32
+    accumulate), d/dW stays fp32; the library is back in exact fp32 after every launch."""
+    from gpu_util import dev, run_conv, pack_layer, lib
+    from insmos_amd import autograd as A
+    rng = np.random.default_rng(9)
+    K, cin, cout, n = 27, 64, 32, 3000
+    nbr = dev(_rand_nbr(rng, K, n, n, 0.4))
+    x0 = dev(rng.normal(size=(n, cin)).astype(np.float32))
+    t0 = dev((rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.4)).astype(np.float32))
+    dy = dev(rng.normal(size=(n, cout)).astype(np.float32))
+    res = {}
+    for mode in (0, 1):
+        A.set_train_conv_precision(mode)
+        try:
+            x, t = x0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+            y = A.sparse_conv(x, t, None, nbr)
+            y.backward(dy)
+            res[mode] = (y.detach(), x.grad.clone(), t.grad.clone())
+        finally:
+            A.set_train_conv_precision(0)
+    for a, b, lo, hi in zip(res[0][:2], res[1][:2], (2e-4, 2e-4), (5e-2, 5e-2)):
+        e = float((a - b).abs().max()) / float(a.abs().mean())
+        assert lo < e < hi, e
+    assert torch.equal(res[0][2], res[1][2])                           # d/dW: fp32 kernel on the saved fp32 input and dy
+    # and the library is in exact fp32 again
+    layer = pack_layer(t0.cpu().numpy(), np.zeros(cout, np.float32), cin, cout)
+    a = run_conv(layer, x0, nbr, n)
+    assert torch.equal(a, run_conv(layer, x0, nbr, n)) and float((a - res[0][0]).abs().max()) < 1e-4
+
+
+def test_bev_kernel_split_bf16x3_experiment():
+    from gpu_util import dev, pack_layer, lib, stream
+    from insmos_amd import params as P, _lib
+    rng = np.random.default_rng(5)
+    B, H, W, ci, co = 2, 47, 61, 128, 128
+    x = rng.normal(size=(B * H * W, ci)).astype(np.float32)
+    w = (rng.normal(size=(co, ci, 3, 3)) * (1.0 / np.sqrt(9 * ci))).astype(np.float32)
+    layer = pack_layer(P.conv2d_weight_to_taps(w), rng.normal(size=co).astype(np.float32), ci, co)
+    xd = dev(x)
+
+    def run():
+        out = torch.zeros((B * H * W, co), device="cuda:0")
+        _lib.check(lib().insmos_bev_conv3x3(xd.data_ptr(), B, H, W, ci, ci, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(),
+                                            co, co, 1, stream()), "insmos_bev_conv3x3")
+        torch.cuda.synchronize()
+        return out
+
+    exact = run()
+    y3 = _with_precision(3, [layer], run)
+    assert not torch.equal(y3, exact)
+    assert float((y3 - exact).abs().max()) < 2e-4 * float(exact.abs().mean() + 1.0)
+    assert torch.equal(run(), exact)
+
+
 @pytest.mark.parametrize("n_site", [1000, 18750 * 2 + 5])
 def test_fused_deconv_head_is_bitwise_the_two_launches(n_site):
     """insmos_deconv_head (ConvTranspose2d(2,2)+BN+ReLU and the 1x1 heads in one kernel, base_bev_backbone.py:104-115,

@@ -50,6 +50,8 @@ def main():
     wins = [torch.from_numpy(w).cuda() for w in bench.load_windows(list(range(B)), 1886)]
     bench.calibrate_head(model, wins[0], 1500, cache="/tmp/insmos_bench_calibration.json", tag="rank0_az1886_c1500")
     eng = model.model.engine
+    if os.environ.get("INSMOS_CONV_PRECISION"):   # per-layer times of the split-bf16 x 3 EXPERIMENT (tools/bf16x3_experiment.py)
+        eng.set_conv_precision(int(os.environ["INSMOS_CONV_PRECISION"]))
     lib = eng.lib
     per_win = []
     for w in wins:

@@ -4,6 +4,7 @@ four losses, backward, Adam) on the S0 window, with the per-kernel-class breakdo
 
     python tools/train_step_bench.py [n_az]                 # default 1886 (S0, 1.2 M points)
     INSMOS_DW_MFMA=1 python tools/train_step_bench.py       # the MFMA dW kernel instead of the LDS one
+    INSMOS_TRAIN_BF16=1 python tools/train_step_bench.py    # conv forward / d/dx with bf16 operands, fp32 accumulate (opt-in)
 """
 import ctypes
 import os
@@ -54,7 +55,7 @@ dt = (time.perf_counter() - t0) / steps
 prof = bench.read_profile(lib)
 lib.insmos_prof_enable(0)
 print(f"full training step, {len(w)} points: {dt * 1e3:.1f} ms (loss {float(loss.detach()):.4f}, {tb[0]}); "
-      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; INSMOS_DW_MFMA={os.environ.get('INSMOS_DW_MFMA', '0')}",
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; INSMOS_DW_MFMA={os.environ.get('INSMOS_DW_MFMA', '0')} bf16_convs={tr.bf16_convs}",
       flush=True)
 for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]:
     print(f"    {k:24s} {ms / steps:9.3f} ms/step  {cnt // steps:6d} launches/step")
