@@ -292,6 +292,10 @@ int insmos_debug_conv_force(int cot, int jt, int ring);
 /* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
  * both produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_quad(int on);
+/* test / tuning hook: the d/dW kernel of insmos_sparse_conv_backward_weight -- 2 = row-compacting MFMA kernel (default),
+ * 1 = first MFMA design (also INSMOS_DW_MFMA=1), 0 = LDS slabs.  All three are deterministic; they differ in summation order.
+ * insmos_sparse_conv_backward_weight_ws_floats follows the mode: size the workspace after switching. */
+int insmos_debug_dw_kernel(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * insmos_dense_nbr2d -- full-grid 3x3 (pad 1) neighbour table for an H x W NHWC map, so that the

@@ -5,9 +5,10 @@
 //   d/dx      dx[i] = sum_k dy[nbrT[k][i]] @ W[k]^T   -- the SAME kernel on the transposed table with transposed taps
 //                     (for a submanifold layer nbrT[k] = nbr[K-1-k]; for strided layers the engine already builds the
 //                     transposed table: down <-> inverse, dn <-> up), packed on the device by insmos_pack_weights_device
-//   d/dW      dW[k] = sum_o x[nbr[k][o]]^T (x) dy[o]  -- k_conv_dw below: per (row chunk, tap, channel tile) partial sums
-//                     in LDS-staged 64-row slabs, then a fixed-order reduction over the chunks (deterministic, no atomics:
-//                     the reference's libraries scatter-add with atomics)
+//   d/dW      dW[k] = sum_o x[nbr[k][o]]^T (x) dy[o]  -- k_conv_dw_rows below (default): per (row chunk, tap, channel block)
+//                     partial sums on the matrix cores over the rows that have the tap, then a fixed-order reduction over the
+//                     chunks (deterministic, no atomics: the reference's libraries scatter-add with atomics); k_conv_dw (LDS
+//                     slabs) and k_conv_dw_mfma (first MFMA design) remain selectable as cross-checks
 //   d/db      db    = sum_o dy[o]                     -- k_col_sum (two stages, fixed order)
 //   loss      MOSLoss.compute_loss (models/loss.py:20-34): ignored classes -> -inf, softmax, log(clamp(., 1e-8)),
 //             class-weighted NLL; k_mos_loss writes the per-point terms and d loss / d logits, reduced in fixed order.
@@ -90,8 +91,8 @@ __global__ void __launch_bounds__(256) k_conv_dw(const float* __restrict__ x, in
     if (gci < cin && gco < cout) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + gco] = acc;
 }
 
-// ---- dW on the matrix cores (selected with INSMOS_DW_MFMA=1: it passes the conv-autograd tests of
-// tests/test_train_slice.py, but it has not been timed against k_conv_dw yet, so it is not the default) ----
+// ---- dW on the matrix cores, first design (INSMOS_DW_KERNEL=1 / INSMOS_DW_MFMA=1; tools/dw_bench.py: slower than the LDS
+// kernel on the wide layers, 5-15x slower than k_conv_dw_rows) ----
 // D[i = ci][j = co] += sum_r A[i][r] * B[r][j] with the contraction over ROWS, 4 rows per v_mfma_f32_16x16x4_f32:
 //   A[i = lane & 15][r = lane >> 4] = x[nbr[k][o_r]][ci0 + i]   (0 where the row has no neighbour under tap k)
 //   B[r = lane >> 4][j = lane & 15] = dy[o_r][co0 + j]
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(256) k_conv_dw(const float* __restrict__ x, in
 // k_conv_dw_reduce, so the result is deterministic (it differs from k_conv_dw's only in summation order).
 #define DW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT>
 __global__ void __launch_bounds__(64) k_conv_dw_mfma(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
@@ -151,6 +153,124 @@ __global__ void __launch_bounds__(64) k_conv_dw_mfma(const float* __restrict__ x
             if (gci < cin) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + co[t]] = acc[t][reg];
         }
     }
+}
+
+// ---- dW on the matrix cores, second design (the default; insmos_debug_dw_kernel selects the older two) -------------------
+// One wave = one (row chunk, tap, ci block, co block) with up to 4 x 4 accumulator tiles.  What it does differently:
+//  * PRESENT rows only: per 64 output rows the rows that have a neighbour under tap k are compacted (ballot + prefix popcount
+//    -> a 64-entry list in LDS) and walked four at a time, so the matrix cores see no absent rows (a 4D layer has a neighbour in
+//    ~35 % of its (row, tap) slots) and the inner loop has no skip branches;
+//  * WIDE loads: with VA (VB) = 1, 2 or 4 channel tiles per block, lane (r, i) loads the VA consecutive channels
+//    VA*i .. VA*i + VA-1 of its row in ONE dword / b64 / b128 load and element t feeds tile t -- tile t of a block is the
+//    channel set {VA*i + t}, a permutation that only matters when the 16 x 16 results are written out.  A 64 x 64 block costs two
+//    b128 loads per 4-row step for 16 MFMAs (the first design: 1 + NT dword loads for NT MFMAs);
+//  * buffer loads with the row offset in the voffset: the padding rows of the last step of a list read past the end of the
+//    buffer and contribute zeros.
+// Rows are visited in ascending order and the chunk partials are reduced in fixed order: deterministic (summation order differs
+// from the other two kernels').
+template <int VA, int VB>
+__global__ void __launch_bounds__(64) k_conv_dw_rows(const float* __restrict__ x, uint32_t x_bytes, int ld_x,
+                                                     const float* __restrict__ dy, uint32_t dy_bytes, int ld_dy,
+                                                     const int32_t* __restrict__ nbr, int64_t n_out, int cin, int cout,
+                                                     int rows_per_chunk, int n_co_blk, float* __restrict__ partial, int K) {
+    __shared__ int2 list[2][64];
+    const int chunk = blockIdx.x, k = blockIdx.y;
+    const int ci_b = blockIdx.z / n_co_blk, co_b = blockIdx.z % n_co_blk;
+    const int lane = threadIdx.x, li = lane & 15, lr = lane >> 4;
+    const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
+    const int64_t r_end = min(r_begin + rows_per_chunk, n_out);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
+    // this lane's first channel inside the block, as a byte offset; lanes whose channels lie beyond the layer read zeros
+    const int ca = ci_b * 16 * VA + VA * li, cb = co_b * 16 * VB + VB * li;
+    const bool a_ok = ca + VA - 1 < cin, b_ok = cb + VB - 1 < cout;
+    const uint32_t offa = (uint32_t)ca * 4u, offb = (uint32_t)cb * 4u;
+    const uint32_t ldx4 = (uint32_t)ld_x * 4u, ldd4 = (uint32_t)ld_dy * 4u;
+
+    dw_f32x4 acc[VA][VB];
+#pragma unroll
+    for (int ta = 0; ta < VA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < VB; ++tb) acc[ta][tb] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_a = [&](uint32_t off, float (&a)[VA]) {
+        if constexpr (VA == 4) {
+            dw_f32x4 v = __builtin_bit_cast(dw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+            a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+        } else if constexpr (VA == 2) {
+            dw_f32x2 v = __builtin_bit_cast(dw_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0));
+            a[0] = v[0]; a[1] = v[1];
+        } else {
+            a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        }
+    };
+    auto load_b = [&](uint32_t off, float (&b)[VB]) {
+        if constexpr (VB == 4) {
+            dw_f32x4 v = __builtin_bit_cast(dw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0));
+            b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+        } else if constexpr (VB == 2) {
+            dw_f32x2 v = __builtin_bit_cast(dw_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off, 0, 0));
+            b[0] = v[0]; b[1] = v[1];
+        } else {
+            b[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, off, 0, 0));
+        }
+    };
+    auto mma = [&](const float (&a)[VA], const float (&b)[VB]) {
+#pragma unroll
+        for (int ta = 0; ta < VA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < VB; ++tb) acc[ta][tb] = DW_MFMA(a[ta], b[tb], acc[ta][tb]);
+    };
+
+    int buf = 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 64, buf ^= 1) {
+        const int64_t o_mine = r0 + lane;
+        const int idx64 = (o_mine < r_end) ? (nbr ? nbr[(int64_t)k * n_out + o_mine] : (int)o_mine) : -1;
+        const uint64_t m = __ballot(idx64 >= 0);
+        if (m == 0ull) continue;
+        const int cnt = __builtin_popcountll(m);
+        if (idx64 >= 0) list[buf][__builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2((int)(o_mine - r_begin), idx64);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): one wave, in-order LDS -- the list is complete
+        const int ns = (cnt + 3) >> 2;
+        // step s: lane group r takes list entry 4 s + r (past the end: a row that reads zeros)
+        auto offsets = [&](int s, uint32_t& oa, uint32_t& ob) {
+            const int e = 4 * s + lr;
+            const int2 v = list[buf][e < cnt ? e : 0];
+            const bool ok = e < cnt;
+            oa = (ok && a_ok) ? (uint32_t)v.y * ldx4 + offa : 0xFFFFFFF0u;
+            ob = (ok && b_ok) ? (uint32_t)(r_begin + v.x) * ldd4 + offb : 0xFFFFFFF0u;
+        };
+        float a0[VA], b0[VB], a1[VA], b1[VB];
+        uint32_t oa, ob;
+        offsets(0, oa, ob);
+        load_a(oa, a0);
+        load_b(ob, b0);
+        int s = 0;
+        for (; s + 2 <= ns; s += 2) {
+            offsets(s + 1, oa, ob);
+            load_a(oa, a1);
+            load_b(ob, b1);
+            mma(a0, b0);
+            offsets(s + 2 < ns ? s + 2 : s + 1, oa, ob);  // (clamped re-request on the last pair)
+            load_a(oa, a0);
+            load_b(ob, b0);
+            mma(a1, b1);
+        }
+        if (s < ns) mma(a0, b0);
+    }
+    // D[i = 4 * (lane >> 4) + reg][j = lane & 15] of tile (ta, tb) = dW[ci = block + VA * i + ta][co = block + VB * j + tb]
+#pragma unroll
+    for (int ta = 0; ta < VA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < VB; ++tb) {
+            const int gco = co_b * 16 * VB + VB * li + tb;
+            if (gco >= cout) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gci = ci_b * 16 * VA + VA * (4 * lr + reg) + ta;
+                if (gci < cin) partial[(((int64_t)chunk * K + k) * cin + gci) * cout + gco] = acc[ta][tb][reg];
+            }
+        }
 }
 
 __global__ void k_conv_dw_reduce(const float* __restrict__ partial, int n_chunks, int64_t per_chunk, float* __restrict__ dw,
@@ -319,16 +439,40 @@ extern "C" int insmos_pack_weights_device(const float* taps, int K, int cin_real
     return INSMOS_OK;
 }
 
-static int dw_chunks(int64_t n_out, int* rows_per_chunk) {
+// dW kernel: 2 = k_conv_dw_rows (default), 1 = k_conv_dw_mfma (first MFMA design; INSMOS_DW_MFMA=1), 0 = k_conv_dw (LDS slabs)
+static int g_dw_mode = -1;
+static int dw_mode() {
+    if (g_dw_mode < 0) {
+        const char* e = getenv("INSMOS_DW_KERNEL");
+        const char* m = getenv("INSMOS_DW_MFMA");
+        g_dw_mode = e ? atoi(e) : (m && m[0] == '1') ? 1 : 2;
+        if (g_dw_mode < 0 || g_dw_mode > 2) g_dw_mode = 2;
+    }
+    return g_dw_mode;
+}
+extern "C" int insmos_debug_dw_kernel(int mode) {
+    if (mode < 0 || mode > 2) return INSMOS_EINVAL;
+    g_dw_mode = mode;
+    return INSMOS_OK;
+}
+
+static int dw_vec(int c) { return c <= 16 ? 1 : c <= 32 ? 2 : 4; }
+
+// rows per chunk (one partial dW per chunk): 4096 for the first two kernels; the row-compacting kernel takes smaller chunks on
+// small layers so that a launch has a few thousand waves
+static int dw_chunks(int64_t n_out, int K, int cin, int cout, int* rows_per_chunk) {
     int rpc = 4096;
-    int64_t nch = (n_out + rpc - 1) / rpc;
+    if (dw_mode() == 2) {
+        const int64_t nblk = (int64_t)cdiv(cin, 16 * dw_vec(cin)) * cdiv(cout, 16 * dw_vec(cout)) * K;
+        while (rpc > 512 && ((n_out + rpc - 1) / rpc) * nblk < 4096) rpc >>= 1;
+    }
     *rows_per_chunk = rpc;
-    return (int)nch;
+    return (int)((n_out + rpc - 1) / rpc);
 }
 
 extern "C" size_t insmos_sparse_conv_backward_weight_ws_floats(int64_t n_out, int K, int cin, int cout) {
     int rpc;
-    return (size_t)dw_chunks(n_out, &rpc) * (size_t)K * (size_t)cin * (size_t)cout;
+    return (size_t)dw_chunks(n_out, K, cin, cout, &rpc) * (size_t)K * (size_t)cin * (size_t)cout;
 }
 
 extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, int ld_x, int cin, const float* dy, int ld_dy,
@@ -340,11 +484,27 @@ extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, 
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int rpc;
-    const int nch = dw_chunks(n_out, &rpc);
+    const int nch = dw_chunks(n_out, K, cin, cout, &rpc);
     const int n_ci = (cin + 15) / 16, n_co = (cout + 15) / 16;
     ProfScope ps(KK_SPARSE_CONV, s);
-    static const bool use_mfma = [] { const char* e = getenv("INSMOS_DW_MFMA"); return e && e[0] == '1'; }();
-    if (use_mfma) {
+    const int mode = dw_mode();
+    // the row-compacting kernel addresses both operands through 32-bit buffer offsets and loads VA / VB channels per lane
+    const int64_t xb = ((int64_t)n_in - 1) * ld_x * 4 + (int64_t)cin * 4, db = ((int64_t)n_out - 1) * ld_dy * 4 + (int64_t)cout * 4;
+    int va = dw_vec(cin), vb = dw_vec(cout);
+    while (va > 1 && (ld_x % va != 0 || ((uintptr_t)x & (va * 4 - 1)))) va >>= 1;
+    while (vb > 1 && (ld_dy % vb != 0 || ((uintptr_t)dy & (vb * 4 - 1)))) vb >>= 1;
+    // (the chunk plan above assumed dw_vec(): a narrower vector only means more blocks per chunk)
+    if (mode == 2 && xb < (1ll << 31) && db < (1ll << 31)) {
+        const int n_cib = cdiv(cin, 16 * va), n_cob = cdiv(cout, 16 * vb);
+        const dim3 grid(nch, K, n_cib * n_cob);
+#define DW_GO(A, B)                                                                                                              \
+    INSMOS_LAUNCH((k_conv_dw_rows<A, B>), grid, dim3(64), 0, s, x, (uint32_t)xb, ld_x, dy, (uint32_t)db, ld_dy, nbr, n_out, cin, cout, \
+                  rpc, n_cob, ws, K)
+#define DW_B(A) do { if (vb == 4) DW_GO(A, 4); else if (vb == 2) DW_GO(A, 2); else DW_GO(A, 1); } while (0)
+        if (va == 4) DW_B(4); else if (va == 2) DW_B(2); else DW_B(1);
+#undef DW_B
+#undef DW_GO
+    } else if (mode >= 1) {
         // co tiles per wave: as many as the layer has, up to 8 (32 accumulator registers)
         const int nt = n_co >= 8 ? 8 : n_co >= 4 ? 4 : n_co >= 2 ? 2 : 1;
         const int n_cg = (n_co + nt - 1) / nt;

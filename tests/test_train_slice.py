@@ -50,9 +50,20 @@ def _subm_table(rng, n, shape=(12, 40, 40)):
     return R.spconv_nbr_subm(coords, keys[perm], perm, shape)
 
 
+@pytest.fixture(params=[2, 1, 0], ids=["dw_rows", "dw_mfma", "dw_lds"])
+def dw_kernel(request):
+    """Every d/dW kernel of insmos_sparse_conv_backward_weight (include/insmos_hip.h: insmos_debug_dw_kernel); 2 is the default."""
+    from insmos_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.insmos_debug_dw_kernel(request.param), "insmos_debug_dw_kernel")
+    yield request.param
+    lib.insmos_debug_dw_kernel(2)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,K", [(8, 8, 27), (16, 32, 27), (32, 16, 27), (5, 3, 27), (64, 64, 27), (16, 16, 1)])
-def test_sparse_conv_autograd_submanifold(cin, cout, K):
+@pytest.mark.parametrize("cin,cout,K", [(8, 8, 27), (16, 32, 27), (32, 16, 27), (5, 3, 27), (64, 64, 27), (16, 16, 1), (48, 32, 27),
+                                        (144, 128, 27), (128, 64, 27), (20, 128, 27)])
+def test_sparse_conv_autograd_submanifold(cin, cout, K, dw_kernel):
     import torch
     from insmos_amd.autograd import sparse_conv
     rng = np.random.default_rng(cin * 31 + cout)
@@ -86,7 +97,7 @@ def test_sparse_conv_autograd_submanifold(cin, cout, K):
 
 
 @pytest.mark.gpu
-def test_sparse_conv_autograd_strided_pair():
+def test_sparse_conv_autograd_strided_pair(dw_kernel):
     """A stride-2 layer: its transposed table is the inverse-conv table of the same pairs (down <-> inverse)."""
     import torch
     from insmos_amd.autograd import sparse_conv

@@ -40,22 +40,42 @@ opt = torch.optim.Adam(list(tr.params.values()), lr=float(cfg["TRAIN"]["LR"]),
                        weight_decay=float(cfg["TRAIN"].get("WEIGHT_DECAY", 0.0)))  # models/models.py:188-193
 lib = tr.motion.engine.lib
 steps, warm = 4, 2
-for i in range(warm + steps):
-    if i == warm:
-        torch.cuda.synchronize()
-        lib.insmos_prof_reset()
-        lib.insmos_prof_enable(1)
-        t0 = time.perf_counter()
-    opt.zero_grad(set_to_none=True)
-    loss, tb, _, _ = tr.forward(batch, "train")
-    loss.backward()
-    opt.step()
+
+
+def run_steps(n):
+    for _ in range(n):
+        opt.zero_grad(set_to_none=True)
+        out = tr.forward(batch, "train")
+        out[0].backward()
+        opt.step()
+    return out
+
+
+run_steps(warm)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+loss, tb, _, _ = run_steps(steps)                      # the timed steps: per-kernel profiler OFF
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+lib.insmos_prof_reset()
+lib.insmos_prof_enable(1)                              # a second pass for the per-kernel breakdown (HIP events per launch)
+run_steps(steps)
+torch.cuda.synchronize()
 prof = bench.read_profile(lib)
 lib.insmos_prof_enable(0)
-print(f"full training step, {len(w)} points: {dt * 1e3:.1f} ms (loss {float(loss.detach()):.4f}, {tb[0]}); "
-      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; INSMOS_DW_MFMA={os.environ.get('INSMOS_DW_MFMA', '0')} bf16_convs={tr.bf16_convs}",
-      flush=True)
+if os.environ.get("INSMOS_TRAIN_CPROFILE"):
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    run_steps(2)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+dev_ms = sum(ms for ms, _ in prof.values()) / steps
+print(f"full training step, {len(w)} points: {dt * 1e3:.1f} ms wall (profiler off), {dev_ms:.1f} ms in the library's kernels "
+      f"(loss {float(loss.detach()):.4f}, {tb[0]}); "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; dW kernel {os.environ.get('INSMOS_DW_KERNEL', '2 (default)')} "
+      f"bf16_convs={tr.bf16_convs}", flush=True)
 for k, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]:
     print(f"    {k:24s} {ms / steps:9.3f} ms/step  {cnt // steps:6d} launches/step")
