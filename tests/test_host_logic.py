@@ -406,3 +406,24 @@ def test_bench_timed_region_shard_and_aggregate_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_precision_modes_are_refused_unless_known():
+    """The reduced-precision switches are opt-in and validated on the host: the library refuses unknown modes (and stays in
+    exact fp32), the training switch accepts only 0 / 1, and the d/dW kernel selector only its three kernels."""
+    from insmos_amd import _lib, autograd
+    lib = _lib.load()
+    assert lib.insmos_conv_precision(0) == 0
+    for bad in (2, 4, -1, 7):
+        assert lib.insmos_conv_precision(bad) != 0
+    assert lib.insmos_register_split_weights(None, None) != 0
+    for bad in (2, 3, -1):
+        with pytest.raises(ValueError):
+            autograd.set_train_conv_precision(bad)
+    autograd.set_train_conv_precision(0)
+    assert lib.insmos_debug_dw_kernel(3) != 0 and lib.insmos_debug_dw_kernel(-1) != 0 and lib.insmos_debug_dw_kernel(2) == 0
+    # the workspace plan follows the kernel: smaller row chunks (more partials) for small layers under the row-compacting kernel
+    small = lib.insmos_sparse_conv_backward_weight_ws_floats(5000, 27, 128, 128)
+    assert lib.insmos_debug_dw_kernel(0) == 0
+    assert lib.insmos_sparse_conv_backward_weight_ws_floats(5000, 27, 128, 128) == 2 * 27 * 128 * 128 <= small
+    assert lib.insmos_debug_dw_kernel(2) == 0
