@@ -51,14 +51,15 @@ def set_train_conv_precision(mode):
     _TRAIN_CONV_PRECISION = int(mode)
 
 
-def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st):
+def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st, mask=None):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     mode = _TRAIN_CONV_PRECISION
     if mode:
         _lib.check(lib.insmos_conv_precision(mode), "insmos_conv_precision")
     try:
         _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
-                                          None, K, n_out, packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
+                                          mask.data_ptr() if (mask is not None and nbr is not None) else None, K, n_out,
+                                          packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
                                           0, 0, 0, 0, st), "insmos_sparse_conv")
     finally:
         if mode:
@@ -78,10 +79,12 @@ def _pad_cols(x, c):
 class SparseConvFunction(torch.autograd.Function):
     """y[o] = sum_k x[nbr[k][o]] @ taps[k] + bias.  nbr (K, n_out) int32 (-1 = no neighbour); nbr_t (K, n_in) int32 is the
     TRANSPOSED table (nbr_t[k][i] = o  <=>  nbr[k][o] = i); for a submanifold layer pass nbr_t=None and the layer's own
-    table is used with mirrored taps (nbr_t[k] = nbr[K-1-k])."""
+    table is used with mirrored taps (nbr_t[k] = nbr[K-1-k]).  mask / mask_t: the tables' active-tap bitmasks per 16-row group
+    (what insmos_build_nbr emits; optional): the kernels then walk only the taps a tile has -- half of the (tile, tap) slots of
+    a LiDAR table are empty.  A mask belongs to a table ROW set, so the mirrored-tap d/dx of a submanifold layer uses `mask`."""
 
     @staticmethod
-    def forward(ctx, x, taps, bias, nbr, nbr_t):
+    def forward(ctx, x, taps, bias, nbr, nbr_t, mask=None, mask_t=None):
         lib = _lib.load()
         st = _stream(x.device)
         K, cin, cout = taps.shape
@@ -92,7 +95,9 @@ class SparseConvFunction(torch.autograd.Function):
         bias_pad = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=x.device)
         if bias is not None:
             bias_pad[:cout] = bias
-        y = _conv(lib, xp, n_in, cin_pad, nbr, K, n_out, _packed(lib, taps, cin_pad, cout, False, False, st), bias_pad, cout, st)
+        y = _conv(lib, xp, n_in, cin_pad, nbr, K, n_out, _packed(lib, taps, cin_pad, cout, False, False, st), bias_pad, cout, st,
+                  mask)
+        ctx.masks = (mask, mask_t)
         ctx.save_for_backward(xp, taps, nbr if nbr is not None else torch.empty(0), nbr_t if nbr_t is not None else torch.empty(0))
         ctx.meta = (K, cin, cout, n_in, n_out, nbr is not None, nbr_t is not None, bias is not None)
         return y
@@ -102,6 +107,7 @@ class SparseConvFunction(torch.autograd.Function):
         lib = _lib.load()
         xp, taps, nbr, nbr_t = ctx.saved_tensors
         K, cin, cout, n_in, n_out, has_nbr, has_t, has_bias = ctx.meta
+        mask, mask_t = ctx.masks
         st = _stream(dy.device)
         dy = dy.contiguous().float()
         dx = dw = db = None
@@ -113,10 +119,10 @@ class SparseConvFunction(torch.autograd.Function):
             if not has_nbr:      # 1x1 / Linear
                 dx = _conv(lib, dyp, n_out, cp, None, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st)
             elif has_t:
-                dx = _conv(lib, dyp, n_out, cp, nbr_t, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st)
+                dx = _conv(lib, dyp, n_out, cp, nbr_t, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st, mask_t)
             else:                # submanifold: the layer's own table, taps mirrored
                 assert n_in == n_out
-                dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st)
+                dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st, mask)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
             ws = torch.empty(int(lib.insmos_sparse_conv_backward_weight_ws_floats(n_out, K, cin, cout)), dtype=torch.float32,
@@ -129,11 +135,14 @@ class SparseConvFunction(torch.autograd.Function):
             ws = torch.empty(int(lib.insmos_col_sum_ws_floats(n_out, cout)) + 1, dtype=torch.float32, device=dy.device)
             _lib.check(lib.insmos_col_sum(dy.data_ptr(), dy.stride(0), cout, n_out, db.data_ptr(), 0, ws.data_ptr(), st),
                        "insmos_col_sum")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def sparse_conv(x, taps, bias, nbr, nbr_t=None):
-    return SparseConvFunction.apply(x, taps, bias, nbr, nbr_t)
+    """nbr / nbr_t: (K, n) int32 tensors, or the engine's NbrTable objects (table + active-tap masks: the masks are used)."""
+    mask, mask_t = getattr(nbr, "mask16", None), getattr(nbr_t, "mask16", None)
+    nbr, nbr_t = getattr(nbr, "nbr", nbr), getattr(nbr_t, "nbr", nbr_t)
+    return SparseConvFunction.apply(x, taps, bias, nbr, nbr_t, mask, mask_t)
 
 
 class BatchNormTrainFunction(torch.autograd.Function):

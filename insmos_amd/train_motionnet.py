@@ -78,9 +78,9 @@ class MotionNetTrainer:
         eng, p = self.engine, self.params
         eng.motionnet(pts)  # (also runs the inference convs: only the kernel maps are used here)
         T = eng._me_tables
-        nbr125, n81 = T["nbr125"].nbr, [t.nbr for t in T["nbr81"]]
-        dn, up = [t.nbr for t in T["dn"]], [t.nbr for t in T["up"]]
-        n0 = n81[0].shape[1]
+        nbr125, n81 = T["nbr125"], list(T["nbr81"])     # NbrTable objects: sparse_conv uses their active-tap masks too
+        dn, up = list(T["dn"]), list(T["up"])
+        n0 = n81[0].nbr.shape[1]
         x = torch.full((n0, 1), 0.5, dtype=torch.float32, device=self.device)  # motionnet.py:29-32
         out_p1 = self._bn(sparse_conv(x, p["conv0p1s1.kernel"], None, nbr125), "bn0", True)
         out = self._bn(sparse_conv(out_p1, p["conv1p1s2.kernel"], None, dn[0], up[0]), "bn1", True)

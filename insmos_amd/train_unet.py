@@ -144,9 +144,9 @@ class UNetV2Trainer:
         with torch.no_grad():
             eng.unet(cur.detach())  # builds the kernel maps (and runs the inference convolutions, unused here)
         T = eng._un_tables
-        subm, down, inv = {l: t.nbr for l, t in T["subm"].items()}, {l: t.nbr for l, t in T["down"].items()}, \
-            {l: t.nbr for l, t in T["inv"].items()}
-        down5, inv5, coords = T["down5"].nbr, T["inv5"].nbr, T["coords"]
+        # (NbrTable objects: sparse_conv uses their active-tap masks too)
+        subm, down, inv = dict(T["subm"]), dict(T["down"]), dict(T["inv"])
+        down5, inv5, coords = T["down5"], T["inv5"], T["coords"]
         nv = {l: int(coords[l].shape[0]) for l in (1, 2, 3, 4, 5)}
         feat = T["feat"][:, :self.in_ch].detach()
 
