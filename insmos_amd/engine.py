@@ -116,6 +116,7 @@ class Engine:
         self.lib = _lib.load()
         self.native = native      # default path of forward_window (see there)
         self.prune_dead_rows = True  # MotionNet decoder layers skip rows nothing consumes
+        self.tables_only = False  # motionnet() / unet() stop after the coordinate sets and kernel maps (the trainers' use)
         self.fuse_deconv_head = True  # BEV deblock + heads in one kernel (the step path can run them separately)
         self.dense_bev_kernel = os.environ.get("INSMOS_BEV_KERNEL", "1") != "0"  # LDS-tiled 3x3 kernel for the BEV backbone
         self.keep_current_points = False  # 'eval' mode: keep current_point (Ncur, 8) of the last window (motion loss)
@@ -459,6 +460,8 @@ class Engine:
             dn.append(NbrTable(d_nb, d_mk))
             up.append(NbrTable(u_nb, u_mk))
         self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse)
+        if self.tables_only:
+            return None
 
         L, E = self.L, self._empty
         x_in = None
@@ -654,6 +657,8 @@ class Engine:
         inv5 = self.build_nbr(coords[4], nv[4], keys[5], None, nkeys[5], 1, self.shape[5], d_inv5, div=[1, 2, 1, 1])
         self._un_tables = dict(subm=subm, down=down, inv=inv, down5=down5, inv5=inv5, coords=coords, pcid=pcid,
                                feat=feat[:V], num_points=num_points[:V])
+        if self.tables_only:
+            return None
 
         # ---- encoder (spconv_unet.py:297-306)
         x0 = E((V, 16))

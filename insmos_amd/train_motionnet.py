@@ -76,7 +76,11 @@ class MotionNetTrainer:
     def forward(self, pts):
         """pts (N, 5) fp32 device [x, y, z, intensity, t] -> current-point motion logits (Ncur, 3) (motionnet.py:46)."""
         eng, p = self.engine, self.params
-        eng.motionnet(pts)  # (also runs the inference convs: only the kernel maps are used here)
+        eng.tables_only = True   # coordinate sets and kernel maps only: the inference convolutions are not needed here
+        try:
+            eng.motionnet(pts)
+        finally:
+            eng.tables_only = False
         T = eng._me_tables
         nbr125, n81 = T["nbr125"], list(T["nbr81"])     # NbrTable objects: sparse_conv uses their active-tap masks too
         dn, up = list(T["dn"]), list(T["up"])

@@ -142,7 +142,11 @@ class UNetV2Trainer:
         targets when gt_boxes (1, M, 8) is given)."""
         eng, p = self.engine, self.params
         with torch.no_grad():
-            eng.unet(cur.detach())  # builds the kernel maps (and runs the inference convolutions, unused here)
+            eng.tables_only = True   # voxelisation, coordinate sets and kernel maps only
+            try:
+                eng.unet(cur.detach())
+            finally:
+                eng.tables_only = False
         T = eng._un_tables
         # (NbrTable objects: sparse_conv uses their active-tap masks too)
         subm, down, inv = dict(T["subm"]), dict(T["down"]), dict(T["inv"])
