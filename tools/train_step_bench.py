@@ -39,7 +39,7 @@ tr = InsMOSTrainer(cfg, P.random_state_dict(cfg, 0, cls_bias=-2.0, box_w_std=0.0
 opt = torch.optim.Adam(list(tr.params.values()), lr=float(cfg["TRAIN"]["LR"]),
                        weight_decay=float(cfg["TRAIN"].get("WEIGHT_DECAY", 0.0)))  # models/models.py:188-193
 lib = tr.motion.engine.lib
-steps, warm = 4, 2
+steps, warm = 8, 4   # (the caching allocator needs a few steps to settle: with 2 + 4 the timed steps still hit hipMalloc)
 
 
 def run_steps(n):
@@ -71,7 +71,8 @@ if os.environ.get("INSMOS_TRAIN_CPROFILE"):
     run_steps(2)
     torch.cuda.synchronize()
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
 dev_ms = sum(ms for ms, _ in prof.values()) / steps
 print(f"full training step, {len(w)} points: {dt * 1e3:.1f} ms wall (profiler off), {dev_ms:.1f} ms in the library's kernels "
       f"(loss {float(loss.detach()):.4f}, {tb[0]}); "
