@@ -357,6 +357,37 @@ def test_training_convs_bf16_opt_in():
     assert torch.equal(a, run_conv(layer, x0, nbr, n)) and float((a - res[0][0]).abs().max()) < 1e-4
 
 
+def test_split_weights_bf16_is_round_to_nearest_even_hi_plus_lo():
+    """insmos_split_weights_bf16: every lane's 4 floats become (hi4 | lo4) with hi = bf16_rne(x), lo = bf16_rne(x - hi) -- checked
+    bit for bit against a numpy restatement (including ties, denormal-range residuals, zeros and negative values)."""
+    from gpu_util import dev, lib, stream
+    from insmos_amd import _lib
+    rng = np.random.default_rng(1)
+    x = (rng.normal(size=4096) * np.exp(rng.uniform(-20, 20, size=4096))).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, 1.00390625, 1.01171875, 3.0e-39, -65504.0]   # exact, ties (odd / even), tiny, large
+    xd = dev(x)
+    out = torch.empty(4096, dtype=torch.float32, device="cuda:0")
+    _lib.check(lib().insmos_split_weights_bf16(xd.data_ptr(), 4096, out.data_ptr(), stream()), "insmos_split_weights_bf16")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint16).reshape(-1, 8)              # per float4: hi0..hi3, lo0..lo3
+
+    def bf16_rne(v):
+        b = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16).astype(np.uint16)
+        return r
+
+    def widen(h):
+        return (h.astype(np.uint32) << 16).view(np.float32)
+
+    hi = bf16_rne(x)
+    lo = bf16_rne(x - widen(hi))
+    np.testing.assert_array_equal(got[:, :4].reshape(-1), hi)
+    np.testing.assert_array_equal(got[:, 4:].reshape(-1), lo)
+    rec = widen(hi).astype(np.float64) + widen(lo).astype(np.float64)
+    big = np.abs(x) > 1e-30
+    assert np.max(np.abs(rec[big] - x[big]) / np.abs(x[big])) < 2.0 ** -16
+
+
 def test_bev_kernel_split_bf16x3_experiment():
     from gpu_util import dev, pack_layer, lib, stream
     from insmos_amd import params as P, _lib
