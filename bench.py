@@ -14,6 +14,7 @@ end of the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
+import glob
 import json
 import math
 import os
@@ -97,13 +98,15 @@ def pmc_traffic(args, wpl):
     """HBM bytes of the conv launches from the rocprofv3 PMC passes of `bench.py --timed-only` at this configuration
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, units and gfx950 corrections as the microarch guide
     prescribes), committed under profiles/; null when the workload or the launch-set size differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if args.n_az != 1886 or not os.path.exists(path):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")))
+    if args.n_az != 1886 or not cands:
         return None
+    path = cands[-1]   # the latest round's passes
     with open(path) as f:
         j = json.load(f)
     if int(j.get("windows_per_launch", -1)) != int(wpl):
         return None
+    j["_path"] = path
     return j
 
 
@@ -151,7 +154,7 @@ def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * steps * len(batch) / dt   # every rank runs the same number of windows per step (weak scaling)
@@ -266,7 +269,7 @@ def main():
         torch.cuda.synchronize()
         sustained = k * W / (time.perf_counter() - t1)
         if world > 1:
-            t = torch.tensor([sustained], dtype=torch.float64, device=dev)
+            t = torch.tensor([sustained], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             sustained = float(t.item())
 
@@ -339,6 +342,9 @@ def main():
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic else None,
             "traffic_bytes_per_window": round(traffic["hbm_bytes_per_window"]) if traffic else None,
+            "traffic_source": ("NOT measured in this run: read from the committed %s (rocprofv3 --pmc passes of `bench.py "
+                               "--timed-only` at this configuration, tools/pmc_traffic.sh)" % os.path.relpath(traffic["_path"], ROOT))
+                              if traffic else None,
             "algorithmic_gflop_per_window": round(flops_w / 1e9, 3),
             "reference_gflop_per_window": round(flops_ref_w / 1e9, 3),
             "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed); MotionNet rows "
@@ -349,7 +355,9 @@ def main():
             "kernel_ms_per_window": round(conv_ms_per_window, 4),
             "avg_launch_us": round(1000.0 * conv_ms / max(conv_launches, 1), 2),
             "launches_per_window": round(conv_launches / n_win, 2),
-            "gather_gbs": round(gather_w / (conv_ms_per_window * 1e-3) / 1e9, 1) if conv_ms_per_window else 0,
+            # a MODEL figure, not a bandwidth measurement: the bytes a per-offset gather->GEMM->scatter with zero cache reuse
+            # would move (SURVEY.md 8d, 4*pairs*(Cin+Cout) + 8*pairs) over the measured kernel time
+            "gather_model_gbs": round(gather_w / (conv_ms_per_window * 1e-3) / 1e9, 1) if conv_ms_per_window else 0,
         }
         # the north star's framing ("scans/sec ... as fraction of HBM roofline"): compulsory bytes of one window (every
         # layer reads its input and its table rows and writes its output once; profiles/r01_layer_work_s0.csv) x windows/s
@@ -371,6 +379,28 @@ def main():
             eng.forward_window(pts)
         torch.cuda.synchronize()
         out["single_window_latency_ms"] = round((time.perf_counter() - t1) * 100.0, 3)
+        # the reference's own caller hands forward() ONE window (scripts/predict_mos.py:290 forces BATCH_SIZE = 1): the rate of
+        # the unmodified drop-in loop, through InsMOS_Model.forward (python boundary included), nothing batched
+        one = [batch[0]]
+        for _ in range(3):
+            model.forward(one, "test")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nb1 = 30
+        for _ in range(nb1):
+            model.forward(one, "test")
+        torch.cuda.synchronize()
+        out["value_b1"] = round(nb1 / (time.perf_counter() - t1), 3)
+        # the step with every slot holding the S0 window itself (seed 0: ~9 % more executed work than the mean of seeds 0..W-1)
+        s0_batch = [batch[0]] * W
+        model.forward(s0_batch, "test")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ns0 = max(3, min(args.steps, 10))
+        for _ in range(ns0):
+            model.forward(s0_batch, "test")
+        torch.cuda.synchronize()
+        out["value_s0_only"] = round(ns0 * W / (time.perf_counter() - t1), 3)
         if args.layer_times:
             eng.layer_timing = []
             eng.forward_window(pts, native=False)

@@ -30,7 +30,7 @@ extern "C" {
 #define INSMOS_EINVAL (-1)    /* bad argument */
 #define INSMOS_EHIP (-2)      /* a HIP runtime call failed; see insmos_last_hip_error() */
 #define INSMOS_EWORKSPACE (-3) /* workspace too small */
-#define INSMOS_EBATCH (-4)     /* launch set too large for 32-bit table offsets: run it as smaller sets */
+#define INSMOS_EBATCH (-4)     /* launch set too large (32-bit table offsets, or a window's time range beside B - 1 others): run it as smaller sets */
 
 int insmos_version(void);
 int insmos_last_hip_error(void);
@@ -286,6 +286,10 @@ int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const 
  * insmos_split_weights_bf16: out (n_floats * 4 bytes) = the packed fp32 weights with every lane's 4 floats replaced by
  * (hi4 | lo4) bf16; insmos_register_split_weights(wpacked, wsplit): table entry (wsplit = NULL removes it). */
 int insmos_conv_precision(int mode);
+/* The same switch for the CALLING HOST THREAD only (mode -1 removes the override; while set it wins over the process-wide mode):
+ * what the training convolutions use around their own launches, so that an inference forward issued from another host thread at
+ * the same time stays exact fp32. */
+int insmos_conv_precision_thread(int mode);
 int insmos_split_weights_bf16(const float* wpacked, int64_t n_floats, void* out, void* stream);
 int insmos_register_split_weights(const float* wpacked, const void* wsplit);
 int insmos_debug_conv_force(int cot, int jt, int ring);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "insmos_debug_conv_quad": (c_int, [c_int]),
     "insmos_debug_dw_kernel": (c_int, [c_int]),
     "insmos_conv_precision": (c_int, [c_int]),
+    "insmos_conv_precision_thread": (c_int, [c_int]),
     "insmos_split_weights_bf16": (c_int, [c_vp, c_i64, c_vp, c_vp]),
     "insmos_register_split_weights": (c_int, [c_vp, c_vp]),
     "insmos_dense_nbr2d": (c_int, [c_int, c_int, c_vp, c_vp]),

@@ -12,7 +12,9 @@ torch is used for what it is here for -- device memory, streams and the autograd
   * center_assign_targets() / center_head_loss(): CenterHead.assign_targets / get_loss (center_head.py:126-331).
 The optimiser step stays torch.optim's.
 """
+import contextlib
 import ctypes
+import threading
 
 import torch
 
@@ -37,11 +39,13 @@ def _packed(lib, taps, cin_pad, cout_store, transpose, mirror, st):
 
 
 # Precision of the TRAINING convolutions (forward and d/dx; d/dW and every other kernel stay fp32).  0 = exact fp32 (default);
-# 1 = operands rounded to bf16, fp32 accumulate (include/insmos_hip.h: insmos_conv_precision) -- opt-in through
-# set_train_conv_precision(1) / InsMOSTrainer(bf16_convs=True) / INSMOS_TRAIN_BF16=1.  The library mode is process-wide: it is
-# switched around each training conv launch and back to exact fp32 right after, so inference calls made between training
-# steps are untouched (do not run inference on another host thread while a training step is in progress).
+# 1 = operands rounded to bf16, fp32 accumulate (include/insmos_hip.h: insmos_conv_precision) -- opt-in PER TRAINER
+# (InsMOSTrainer(bf16_convs=True) / INSMOS_TRAIN_BF16=1 wrap their step in train_conv_precision(1)); set_train_conv_precision()
+# is the process default for bare sparse_conv() calls.  The mode of a node is fixed when its forward runs (kept in ctx: the
+# backward, which autograd runs on its own thread, uses the same one) and reaches the library as a HOST-THREAD-local override
+# around each launch (insmos_conv_precision_thread), so inference forwards on other host threads stay exact fp32.
 _TRAIN_CONV_PRECISION = 0
+_tls = threading.local()
 
 
 def set_train_conv_precision(mode):
@@ -51,11 +55,28 @@ def set_train_conv_precision(mode):
     _TRAIN_CONV_PRECISION = int(mode)
 
 
-def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st, mask=None):
+@contextlib.contextmanager
+def train_conv_precision(mode):
+    """Precision of the sparse_conv() nodes CREATED inside the block on this thread (a trainer instance's own setting)."""
+    if mode not in (0, 1):
+        raise ValueError("training conv precision: 0 (fp32) or 1 (bf16 operands, fp32 accumulate)")
+    prev = getattr(_tls, "mode", None)
+    _tls.mode = int(mode)
+    try:
+        yield
+    finally:
+        _tls.mode = prev
+
+
+def current_train_conv_precision():
+    m = getattr(_tls, "mode", None)
+    return _TRAIN_CONV_PRECISION if m is None else m
+
+
+def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st, mask=None, mode=0):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    mode = _TRAIN_CONV_PRECISION
     if mode:
-        _lib.check(lib.insmos_conv_precision(mode), "insmos_conv_precision")
+        _lib.check(lib.insmos_conv_precision_thread(mode), "insmos_conv_precision_thread")
     try:
         _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
                                           mask.data_ptr() if (mask is not None and nbr is not None) else None, K, n_out,
@@ -63,7 +84,7 @@ def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st, mask
                                           0, 0, 0, 0, st), "insmos_sparse_conv")
     finally:
         if mode:
-            lib.insmos_conv_precision(0)
+            lib.insmos_conv_precision_thread(-1)
     return out
 
 
@@ -95,8 +116,9 @@ class SparseConvFunction(torch.autograd.Function):
         bias_pad = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=x.device)
         if bias is not None:
             bias_pad[:cout] = bias
+        ctx.prec = current_train_conv_precision()
         y = _conv(lib, xp, n_in, cin_pad, nbr, K, n_out, _packed(lib, taps, cin_pad, cout, False, False, st), bias_pad, cout, st,
-                  mask)
+                  mask, mode=ctx.prec)
         ctx.masks = (mask, mask_t)
         ctx.save_for_backward(xp, taps, nbr if nbr is not None else torch.empty(0), nbr_t if nbr_t is not None else torch.empty(0))
         ctx.meta = (K, cin, cout, n_in, n_out, nbr is not None, nbr_t is not None, bias is not None)
@@ -117,12 +139,12 @@ class SparseConvFunction(torch.autograd.Function):
             dyp = _pad_cols(dy, cp)
             zero_b = torch.zeros((cin + 15) // 16 * 16, dtype=torch.float32, device=dy.device)
             if not has_nbr:      # 1x1 / Linear
-                dx = _conv(lib, dyp, n_out, cp, None, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st)
+                dx = _conv(lib, dyp, n_out, cp, None, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st, mode=ctx.prec)
             elif has_t:
-                dx = _conv(lib, dyp, n_out, cp, nbr_t, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st, mask_t)
+                dx = _conv(lib, dyp, n_out, cp, nbr_t, K, n_in, _packed(lib, taps, cp, cin, True, False, st), zero_b, cin, st, mask_t, mode=ctx.prec)
             else:                # submanifold: the layer's own table, taps mirrored
                 assert n_in == n_out
-                dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st, mask)
+                dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st, mask, mode=ctx.prec)
         if ctx.needs_input_grad[1]:
             dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
             ws = torch.empty(int(lib.insmos_sparse_conv_backward_weight_ws_floats(n_out, K, cin, cout)), dtype=torch.float32,

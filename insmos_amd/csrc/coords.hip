@@ -127,7 +127,8 @@ __global__ void k_quant_keys_b(WinPts W, int64_t n, int ld, float q0, float q1, 
     const int B = W.B;
     float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;   // the same fp32 ops as k_quant_keys
     const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz), tq = (int)floorf(ft);
-    const bool t_ok = tq > -2000 && tq < 2000;                              // t' must fit the 16-bit biased time field
+    const int tlim = 32768 / B - 1;                                         // |t'| = |tq * B + b| must fit the 16-bit biased
+    const bool t_ok = tq >= -tlim && tq <= tlim;                            // time field: a single window gets all of it
     uint64_t k = t_ok ? key4_encode(x, y, z, tq * B + b) : INSMOS_INVALID_KEY;
     if (k == INSMOS_INVALID_KEY) atomicAdd(&counts[2], 1);
     if (COMPACT && k != INSMOS_INVALID_KEY) {

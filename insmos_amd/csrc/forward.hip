@@ -190,7 +190,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     int32_t* cur_start_dev = A.take<int32_t>(INSMOS_MAX_BATCH + 1);
     NEED_ARENA();
     HIP_TRY(hipMemcpyAsync(cur_start_dev, counts + 4, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    if (hc[2] != 0) { out->n_out_of_window = hc[2]; return INSMOS_EINVAL; }
+    // (a batch narrows the time field by B: a window that is valid alone may not fit beside B - 1 others -- the caller
+    //  splits the set down to single windows, where the full +-32768 range applies, before giving up)
+    if (hc[2] != 0) { out->n_out_of_window = hc[2]; return B > 1 ? INSMOS_EBATCH : INSMOS_EINVAL; }
     out->me_voxels[0] = n[0];
     if (n[0] == 0) return INSMOS_EINVAL;
     for (int b = 0; b < B; ++b)

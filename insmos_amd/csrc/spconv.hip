@@ -808,6 +808,10 @@ ConvKernel pick_prec(int cot, int split, bool by_chunk) {
     return nullptr;
 }
 int g_prec = 0;  // 0 = exact fp32 (the product default), 1 = bf16 operands, 3 = split-bf16 x 3 (see insmos_conv_precision)
+// per-HOST-THREAD override (-1 = none): the training convolutions switch precision for their own launches only, so an
+// inference forward issued from another host thread meanwhile keeps exact fp32 (insmos_conv_precision_thread)
+thread_local int tl_prec = -1;
+inline int cur_prec() { return tl_prec >= 0 ? tl_prec : g_prec; }
 std::unordered_map<const float*, const void*> g_split_weights;  // packed fp32 weights -> their (hi | lo) bf16 split
 std::mutex g_split_mu;
 
@@ -842,7 +846,7 @@ int env_int(const char* name, int dflt) {
 }  // namespace
 
 namespace insmos {
-int conv_precision() { return g_prec; }
+int conv_precision() { return cur_prec(); }
 const void* split_weights_of(const float* wpacked) {
     std::lock_guard<std::mutex> lk(g_split_mu);
     auto it = g_split_weights.find(wpacked);
@@ -935,8 +939,8 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     }
     // reduced precision (opt-in, never the default): 16-channel-chunk layers with a neighbour table
     // (single-chunk layers stay fp32: they are vector-memory bound, measured 0.91x under the experiment)
-    if (g_prec && !ck && P.n16 >= 2 && !ident && best.jt == 1) {
-        int prec = g_prec;
+    if (cur_prec() && !ck && P.n16 >= 2 && !ident && best.jt == 1) {
+        int prec = cur_prec();
         if (prec == 3) {
             const void* ws = split_weights_of(wpacked);
             if (!ws) prec = 0;  // no split weights registered for this layer: exact fp32
@@ -1050,6 +1054,12 @@ extern "C" int insmos_register_split_weights(const float* wpacked, const void* w
 extern "C" int insmos_conv_precision(int mode) {
     if (mode != 0 && mode != 1 && mode != 3) return INSMOS_EINVAL;
     g_prec = mode;
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_conv_precision_thread(int mode) {
+    if (mode != -1 && mode != 0 && mode != 1 && mode != 3) return INSMOS_EINVAL;
+    tl_prec = mode;
     return INSMOS_OK;
 }
 

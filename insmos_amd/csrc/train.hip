@@ -491,8 +491,10 @@ extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, 
     // the row-compacting kernel addresses both operands through 32-bit buffer offsets and loads VA / VB channels per lane
     const int64_t xb = ((int64_t)n_in - 1) * ld_x * 4 + (int64_t)cin * 4, db = ((int64_t)n_out - 1) * ld_dy * 4 + (int64_t)cout * 4;
     int va = dw_vec(cin), vb = dw_vec(cout);
-    while (va > 1 && (ld_x % va != 0 || ((uintptr_t)x & (va * 4 - 1)))) va >>= 1;
-    while (vb > 1 && (ld_dy % vb != 0 || ((uintptr_t)dy & (vb * 4 - 1)))) vb >>= 1;
+    // a lane loads va (vb) consecutive channels and is all-or-nothing (a_ok / b_ok in the kernel): the width must divide the
+    // channel count, or the trailing channels of e.g. cin = 17 / 34 would silently get dW = 0
+    while (va > 1 && (cin % va != 0 || ld_x % va != 0 || ((uintptr_t)x & (va * 4 - 1)))) va >>= 1;
+    while (vb > 1 && (cout % vb != 0 || ld_dy % vb != 0 || ((uintptr_t)dy & (vb * 4 - 1)))) vb >>= 1;
     // (the chunk plan above assumed dw_vec(): a narrower vector only means more blocks per chunk)
     if (mode == 2 && xb < (1ll << 31) && db < (1ll << 31)) {
         const int n_cib = cdiv(cin, 16 * va), n_cob = cdiv(cout, 16 * vb);

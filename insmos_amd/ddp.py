@@ -12,10 +12,25 @@ arrive roughly last layer first); a post-accumulate hook on every parameter copi
 is all-reduced (async) as soon as it is complete AND every earlier bucket has been launched -- the launch order is the bucket
 order on every rank, whatever order the gradients arrive in and whether or not a rank produced all of them (a gradient that
 never arrives counts as zero and its bucket goes out in `reduce()`), so ranks can never pair up different collectives.
+
+Contract with overlap=True: exactly ONE backward() between two reduce() calls (no gradient accumulation, no retain_graph
+second pass) -- a gradient that arrives for a bucket whose all-reduce is already in flight raises instead of racing with it;
+call close() before building another reducer over the same parameters (the hooks are removed; a closed reducer raises).
 """
 
 import torch
 import torch.distributed as dist
+
+
+class _Staged:
+    """An async all-reduce on a host copy of a device bucket; wait() copies the result back."""
+
+    def __init__(self, work, host, flat):
+        self.work, self.host, self.flat = work, host, flat
+
+    def wait(self):
+        self.work.wait()
+        self.flat.copy_(self.host)
 
 
 class BucketedGradReducer:
@@ -42,10 +57,22 @@ class BucketedGradReducer:
             self._close(cur, off)
         self._works, self._launched, self._seen = [], 0, [set() for _ in self.buckets]
         self.launched_in_backward = 0   # collectives of the last step that went out before reduce() was called
+        self._hooks, self._closed = [], False
         if self.overlap:
             for bi, (_, members) in enumerate(self.buckets):
                 for mi, (p, _, _) in enumerate(members):
-                    p.register_post_accumulate_grad_hook(lambda t, bi=bi, mi=mi: self._on_grad(bi, mi))
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda t, bi=bi, mi=mi: self._on_grad(bi, mi)))
+
+    def close(self):
+        """Remove the backward hooks (overlap=True) -- required before another reducer is built over the same parameters, or
+        both would launch collectives for every gradient.  Outstanding collectives are waited for."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._closed = True
 
     def _close(self, cur, total):
         dev = cur[0][0].device
@@ -65,9 +92,19 @@ class BucketedGradReducer:
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
         if self._world() > 1:
-            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                # two ranks on one GPU (the dry run RCCL refuses): gloo moves host memory -- stage the bucket through it
+                host = flat.cpu()
+                self._works.append(_Staged(dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True), host, flat))
+            else:
+                self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, bi, mi):
+        if bi < self._launched or mi in self._seen[bi]:
+            # the bucket's all-reduce is already in flight (or this gradient was already packed): a second backward before
+            # reduce() -- gradient accumulation / retain_graph -- would write into a buffer RCCL is reading
+            raise RuntimeError("BucketedGradReducer(overlap=True): a gradient arrived twice between two reduce() calls "
+                               "(one backward per reduce(); use overlap=False to accumulate gradients over several)")
         flat, members = self.buckets[bi]
         p, off, n = members[mi]
         flat[off:off + n].copy_(p.grad.reshape(-1))
@@ -79,6 +116,8 @@ class BucketedGradReducer:
     def reduce(self, average=True):
         """All-reduce every parameter's .grad (missing grads count as zero) in place; returns the number of collectives.
         With overlap=True most of them are already in flight (or done) when this is called after backward()."""
+        if self._closed:
+            raise RuntimeError("BucketedGradReducer.reduce() after close()")
         world = self._world()
         self.launched_in_backward = self._launched
         while self._launched < len(self.buckets):

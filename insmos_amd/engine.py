@@ -175,7 +175,29 @@ class Engine:
         return (self._sd(stem + ".weight"), self._sd(stem + ".bias"), self._sd(stem + ".running_mean"),
                 self._sd(stem + ".running_var"))
 
+    def _drop_split_weights(self):
+        """Unregister this engine's split-bf16 weight copies (the library keys them by the packed weights' device address,
+        which the caching allocator may hand to another layer once these tensors are gone)."""
+        reg = getattr(self, "_split_reg", None)
+        if reg:
+            for wptr in reg:
+                self.lib.insmos_register_split_weights(wptr, None)
+        self._split_reg, self._split_w = [], None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_split_owner", False):
+                self._drop_split_weights()
+        except Exception:
+            pass
+
     def _load_weights(self, sd):
+        if getattr(self, "_split_owner", False):
+            self._drop_split_weights()   # new packed weights: the old split copies must not be found under a reused address
+            self._split_owner = False
+            if getattr(self, "conv_precision", 0) == 3:
+                self.lib.insmos_conv_precision(0)
+                self.conv_precision = 0
         self.sd = sd
         self._ctx_box = [None]  # a fresh box: clones made earlier keep (and may still run on) the old context
         L, dev, lib = {}, self.device, self.lib
@@ -295,7 +317,7 @@ class Engine:
         neighbour table (their weights are split once, here, and registered)."""
         mode = int(mode)
         if mode == 3 and not getattr(self, "_split_w", None):
-            self._split_w = {}
+            self._split_w, self._split_reg, self._split_owner = {}, [], True
             for name, l in self.L.items():
                 if l.cin % 16 == 0 and l.K > 1:
                     buf = torch.empty_like(l.w)
@@ -303,6 +325,7 @@ class Engine:
                                "insmos_split_weights_bf16")
                     _lib.check(self.lib.insmos_register_split_weights(l.w.data_ptr(), buf.data_ptr()), "insmos_register_split_weights")
                     self._split_w[name] = buf
+                    self._split_reg.append(l.w.data_ptr())
             torch.cuda.synchronize(self.device)
         _lib.check(self.lib.insmos_conv_precision(mode), "insmos_conv_precision")
         self.conv_precision = mode
@@ -852,7 +875,8 @@ class Engine:
                 break
             self._arena = None
             self._arena = torch.empty(max(int(outs[0].arena_needed * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
-        if rc == -4:  # INSMOS_EBATCH: the set's finest table would pass 2 GiB -> two smaller launch sets, same bits per window
+        if rc == -4:  # INSMOS_EBATCH: the set's finest table would pass 2 GiB, or a window's time range does not fit beside the
+            # others (the batch narrows the time field by B) -> two smaller launch sets, same bits per window
             h = B // 2
             return self.forward_windows(pts_list[:h]) + self.forward_windows(pts_list[h:])
         if rc == -1 and outs[0].n_out_of_window:
@@ -897,6 +921,7 @@ class Engine:
         import copy
         e = copy.copy(self)
         e._ws, e._arena, e._conv_log, e._conv_nin, e.last_counts, e.layer_timing = None, None, [], [], {}, None
+        e._split_owner = False   # the clone shares the weights (and their split copies); only the original unregisters them
         return e
 
     def algorithmic_work(self):

@@ -56,9 +56,12 @@ def all_gather_confusion(cm):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return cm
-    parts = [torch.empty_like(cm) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, cm.contiguous())
-    return torch.stack(parts, 0).sum(0)
+    src = cm.contiguous()
+    if src.is_cuda and dist.get_backend() == "gloo":
+        src = src.cpu()   # the two-ranks-on-one-GPU dry run (gloo moves host memory; RCCL takes the device tensor as is)
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, src)
+    return torch.stack(parts, 0).sum(0).to(cm.device)
 
 
 def shard_indices(n_items, rank, world_size):

@@ -112,7 +112,10 @@ class MotionNetTrainer:
         from .ddp import BucketedGradReducer
         # overlap: buckets are all-reduced while backward is still producing the earlier layers' gradients (the parameter
         # dict is in forward order: MotionNet first, the 3D branch's decoder last -- the reverse is the arrival order)
-        return BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
+        if getattr(self, "_reducer", None) is not None:
+            self._reducer.close()   # one live reducer per parameter set: its backward hooks would launch stray collectives
+        self._reducer = BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
+        return self._reducer
 
     def sgd_step(self, lr):
         with torch.no_grad():

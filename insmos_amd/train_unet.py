@@ -240,14 +240,13 @@ class InsMOSTrainer:
 
     def __init__(self, cfg, state_dict, device="cuda:0", bf16_convs=None):
         """bf16_convs (default: INSMOS_TRAIN_BF16=1 in the environment, else off): the training convolutions' forward and d/dx
-        round their operands to bf16 and accumulate in fp32 (autograd.set_train_conv_precision); everything else, and the
+        round their operands to bf16 and accumulate in fp32 (autograd.train_conv_precision, per instance); everything else, and the
         inference path always, stays fp32.  The reference trains in fp32 only (config/config.yaml has no precision key)."""
         from .train_motionnet import MotionNetTrainer
         from . import autograd
         if bf16_convs is None:
             bf16_convs = os.environ.get("INSMOS_TRAIN_BF16", "0") == "1"
-        self.bf16_convs = bool(bf16_convs)
-        autograd.set_train_conv_precision(1 if self.bf16_convs else 0)
+        self.bf16_convs = bool(bf16_convs)   # per trainer instance: forward() wraps its nodes in train_conv_precision(...)
         self.cfg, self.device = cfg, torch.device(device)
         self.use_motion_loss = bool(cfg["MODEL"].get("USE_MOTION_LOSS", False))
         self.motion = MotionNetTrainer(cfg, state_dict, device)
@@ -263,6 +262,11 @@ class InsMOSTrainer:
     def forward(self, list_batch_dict, Model_mode="train"):
         if Model_mode != "train":
             raise ValueError("InsMOSTrainer serves Model_mode == 'train'; use InsMOS_Model for 'test' / 'eval'")
+        from . import autograd
+        with autograd.train_conv_precision(1 if self.bf16_convs else 0):
+            return self._forward_train(list_batch_dict)
+
+    def _forward_train(self, list_batch_dict):
         loss = torch.zeros(1, device=self.device)
         train_loss_dict, gt_list, pred_list = [], [], []
         for b in list_batch_dict:
@@ -286,7 +290,10 @@ class InsMOSTrainer:
         from .ddp import BucketedGradReducer
         # overlap: buckets are all-reduced while backward is still producing the earlier layers' gradients (the parameter
         # dict is in forward order: MotionNet first, the 3D branch's decoder last -- the reverse is the arrival order)
-        return BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
+        if getattr(self, "_reducer", None) is not None:
+            self._reducer.close()   # one live reducer per parameter set: its backward hooks would launch stray collectives
+        self._reducer = BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
+        return self._reducer
 
     def sgd_step(self, lr):
         with torch.no_grad():

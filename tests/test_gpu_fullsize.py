@@ -109,23 +109,27 @@ def test_s0_full_size_against_the_oracle():
     assert got.shape == ref_logits.shape == (119817, 3)
     assert err < 1e-3
     lab, lab_ref = R.output_stage(got)[0], R.output_stage(ref_logits)[0]
-    top2 = np.sort(ref_logits[:, 1:], axis=1)
-    decided = (top2[:, -1] - top2[:, -2]) > 2 * err
-    # (the 1.2 % of current points outside the voxel range carry all-zero logits: exact ties, decided by the argmax rule)
-    assert decided.mean() > 0.98 and (decided | (ref_logits == 0).all(1)).mean() > 0.999
-    np.testing.assert_array_equal(lab[decided], lab_ref[decided])
-    assert int((lab != lab_ref).sum()) <= 2                    # (0 in practice; undecided points are coin tosses by definition)
-    # the same boxes: ~1400 candidates of a random-weight head go through greedy NMS at IoU 0.1, where one borderline pair
-    # (IoU within 1e-5 of the threshold) flips a keep decision and shifts the rest of the list -- so the lists are compared
-    # as SETS: every box of one list has its twin (all 7 numbers within 1e-3, same class) in the other, up to 1 % of them
+    # label-exact after argmax, every point (the north star's bar; the 1.2 % of current points outside the voxel range carry
+    # all-zero logits on both sides: exact ties, decided by the same first-maximum rule)
+    np.testing.assert_array_equal(lab, lab_ref)
+    # the same boxes in the same order: the keep list of greedy NMS over ~1400 candidates of a random-weight head.  A pair whose
+    # IoU sits within fp32 rounding of the threshold could flip one keep decision and shift the rest of the list; if that ever
+    # happens the test names the pair and its IoU instead of accepting a fuzzy match.
     pb, rb = single[1]["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"]
     pl, rl = single[1]["pred_labels"].cpu().numpy(), ref_pred["pred_labels"]
+    ps, rs = single[1]["pred_scores"].cpu().numpy(), ref_pred["pred_scores"]
     assert len(pb) == len(rb) >= 100
-    d = np.abs(pb[:, None, :] - rb[None, :, :]).max(2)
-    twin = d.argmin(1)
-    ok = (d.min(1) < 1e-3) & (pl == rl[twin])
-    print("boxes with a twin in the oracle's list: %d / %d (identical order: %s)" % (ok.sum(), len(pb), bool((twin == np.arange(len(pb))).all())))
-    assert ok.mean() >= 0.99 and len(set(twin[ok].tolist())) == int(ok.sum())
+    same = (np.abs(pb - rb).max(1) < 1e-3) & (pl == rl)
+    if not same.all():
+        i = int(np.flatnonzero(~same)[0])
+        prev = rb[:i] if i else rb[:1]
+        iou_g = R.iou_bev_matrix(pb[i:i + 1], prev).max() if i else 0.0
+        iou_r = R.iou_bev_matrix(rb[i:i + 1], prev).max() if i else 0.0
+        thr = float(cfg["MODEL"]["POST_PROCESSING"]["NMS_CONFIG"]["NMS_THRESH"])
+        raise AssertionError("keep lists diverge at position %d: GPU box %s (max IoU with the kept prefix %.7f) vs oracle box %s "
+                             "(%.7f), NMS threshold %.4f" % (i, pb[i].tolist(), iou_g, rb[i].tolist(), iou_r, thr))
+    np.testing.assert_allclose(ps, rs, atol=1e-5)
+    print("boxes: %d identical to the oracle's keep list, in order" % len(pb))
 
 
 def test_cfg4_dense_stress_full_size_properties():

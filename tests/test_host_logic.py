@@ -427,3 +427,50 @@ def test_precision_modes_are_refused_unless_known():
     assert lib.insmos_debug_dw_kernel(0) == 0
     assert lib.insmos_sparse_conv_backward_weight_ws_floats(5000, 27, 128, 128) == 2 * 27 * 128 * 128 <= small
     assert lib.insmos_debug_dw_kernel(2) == 0
+
+
+def test_overlapped_reducer_contract_one_backward_per_reduce_and_close():
+    """overlap=True: a second backward before reduce() would write into a bucket whose all-reduce is in flight -> it raises;
+    close() removes the hooks (a second reducer over the same parameters then sees every gradient exactly once)."""
+    import torch
+    from insmos_amd.ddp import BucketedGradReducer
+    params = {"a": torch.nn.Parameter(torch.ones(6)), "b": torch.nn.Parameter(torch.ones(3))}
+    red = BucketedGradReducer(params, bucket_bytes=16, overlap=True)     # one bucket per parameter
+    assert len(red.buckets) == 2
+    loss = lambda: (params["a"] ** 2).sum() + (params["b"] ** 3).sum()   # noqa: E731
+    loss().backward()
+    assert red._launched == 2
+    with pytest.raises(RuntimeError, match="arrived twice"):
+        loss().backward()
+    red.reduce()
+    g = params["a"].grad.clone()
+    red.close()
+    with pytest.raises(RuntimeError, match="after close"):
+        red.reduce()
+    red2 = BucketedGradReducer(params, bucket_bytes=16, overlap=True)
+    for p in params.values():
+        p.grad = None
+    loss().backward()                   # only red2's hooks fire now
+    assert red2._launched == 2 and red._launched == 0
+    red2.reduce()
+    assert torch.equal(params["a"].grad, g)
+    red2.close()
+
+
+def test_thread_local_precision_override_is_validated_and_per_trainer_context():
+    from insmos_amd import _lib, autograd
+    lib = _lib.load()
+    for ok in (1, 3, 0, -1):
+        assert lib.insmos_conv_precision_thread(ok) == 0
+    for bad in (2, -2, 5):
+        assert lib.insmos_conv_precision_thread(bad) != 0
+    assert autograd.current_train_conv_precision() == 0
+    with autograd.train_conv_precision(1):
+        assert autograd.current_train_conv_precision() == 1
+        with autograd.train_conv_precision(0):
+            assert autograd.current_train_conv_precision() == 0
+        assert autograd.current_train_conv_precision() == 1
+    assert autograd.current_train_conv_precision() == 0
+    with pytest.raises(ValueError):
+        with autograd.train_conv_precision(3):
+            pass

@@ -62,7 +62,9 @@ def dw_kernel(request):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,K", [(8, 8, 27), (16, 32, 27), (32, 16, 27), (5, 3, 27), (64, 64, 27), (16, 16, 1), (48, 32, 27),
-                                        (144, 128, 27), (128, 64, 27), (20, 128, 27)])
+                                        (144, 128, 27), (128, 64, 27), (20, 128, 27),
+                                        # widths that are NOT a multiple of the dW kernel's per-lane vector (2 for 16 < c <= 32, 4 above)
+                                        (17, 18, 27), (34, 34, 27), (20, 18, 1)])
 def test_sparse_conv_autograd_submanifold(cin, cout, K, dw_kernel):
     import torch
     from insmos_amd.autograd import sparse_conv
