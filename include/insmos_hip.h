@@ -240,6 +240,27 @@ size_t insmos_down_coords3d_ws_bytes_b(const int32_t* out_shape_host, int B);
 int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host, const int32_t* stride_host,
                            const int32_t* pad_host, const int32_t* out_shape_host, int B, uint64_t* out_keys,
                            int32_t* out_coords, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Rank maps (round 3): the 3D kernel maps WITHOUT a key search.  A coordinate set of the (B, D, H, W) grid of a level as an
+ * occupancy bitmap in 256-bit blocks (bits: insmos_rankmap_words u64) + the inclusive number of set bits up to each block
+ * (blk_incl: a quarter as many i32): a cell's sorted position is two independent loads and three popcounts.
+ *   insmos_rankmap_from_keys: from ascending unique cell keys b * cells + (z*H + y)*W + x (the voxeliser's ukeys: level 1).
+ *   insmos_down_coords3d_rank = insmos_down_coords3d_b whose bitmap stays valid, in this form (the generated levels).
+ *   insmos_build_nbr_rank = insmos_build_nbr(key_mode 1) over the INPUT level's rank map; in_perm as there.  Same table and
+ *   same mask16 as the searched builder (tests/test_gpu_coords.py).  Same reference call sites: spconv's indice-pair
+ *   generation behind SubMConv3d / SparseConv3d / SparseInverseConv3d (models/backbones_3d/spconv_unet.py:120-207).
+ * ---------------------------------------------------------------------------------------------- */
+size_t insmos_rankmap_words(const int32_t* shape_host, int B);
+size_t insmos_rankmap_ws_bytes(const int32_t* shape_host, int B);
+int insmos_rankmap_from_keys(const uint64_t* keys, int64_t n, const int32_t* shape_host, int B, uint64_t* bits,
+                             int32_t* blk_incl, void* ws, size_t ws_bytes, void* stream);
+int insmos_down_coords3d_rank(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host, const int32_t* stride_host,
+                              const int32_t* pad_host, const int32_t* out_shape_host, int B, uint64_t* out_keys,
+                              int32_t* out_coords, int32_t* counts, uint64_t* bits, int32_t* blk_incl, void* ws,
+                              size_t ws_bytes, void* stream);
+int insmos_build_nbr_rank(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                          const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                          const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
 int insmos_dense_nbr2d_b(int H, int W, int B, int32_t* nbr, void* stream);            /* B images stacked along the rows */
 int insmos_sparse_to_bev_b(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D, int H, int W, int B,
                            float* bev, void* stream);                                    /* bev (B, H, W, C*D) */

@@ -62,6 +62,11 @@ SIGNATURES = {
     "insmos_boxes_to_onehot_b": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
                                          c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_debug_table_limit": (c_int, [c_i64]),
+    "insmos_rankmap_words": (c_sz, [c_vp, c_int]),
+    "insmos_rankmap_ws_bytes": (c_sz, [c_vp, c_int]),
+    "insmos_rankmap_from_keys": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_down_coords3d_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_build_nbr_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

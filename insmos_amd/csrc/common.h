@@ -109,6 +109,30 @@ __host__ __device__ __forceinline__ uint64_t key3_encode(int z, int y, int x, in
     return ((uint64_t)z * (uint64_t)H + (uint64_t)y) * (uint64_t)W + (uint64_t)x;
 }
 
+// ---- packed 4D sort keys (coords.hip, k_quant_keys_p): 40-bit key above a 24-bit point index; see the comment there
+#define PK_IDX_BITS 24
+#define PK_KEY_BITS 40
+#define PK_KEY_MASK ((1ull << PK_KEY_BITS) - 1ull)
+__host__ __device__ __forceinline__ uint64_t spread2(uint64_t v) {  // 3 bits -> every other bit
+    return (v & 1) | ((v & 2) << 1) | ((v & 4) << 2);
+}
+__host__ __device__ __forceinline__ uint64_t pkey_make(int tprime_biased, int x, int y, int z) {
+    const uint64_t ux = (uint64_t)(x + INSMOS_KEY_BIAS), uy = (uint64_t)(y + INSMOS_KEY_BIAS), uz = (uint64_t)(z + INSMOS_KEY_BIAS);
+    const uint64_t hi_xy = spread2((ux >> 8) & 7) | (spread2((uy >> 8) & 7) << 1);            // y10 x10 y9 x9 y8 x8
+    const uint64_t lo = spread3(ux & 0xFF) | (spread3(uy & 0xFF) << 1) | (spread3(uz & 0xFF) << 2);
+    return ((uint64_t)tprime_biased << 33) | ((uint64_t)(z >= 0) << 32) | ((uint64_t)(y >= 0) << 31) | ((uint64_t)(x >= 0) << 30) |
+           (hi_xy << 24) | lo;
+}
+__host__ __device__ __forceinline__ uint64_t pkey_expand(uint64_t p, int B) {  // 40-bit packed key -> canonical key
+    const uint64_t bt = (p >> 33) - (uint64_t)(15 * B) + INSMOS_KEY_BIAS;
+    const uint64_t lo = p & 0xFFFFFFull, hx = (p >> 24) & 0x3F;
+    const uint64_t xh = (hx & 1) | ((hx >> 1) & 2) | ((hx >> 2) & 4), yh = ((hx >> 1) & 1) | ((hx >> 2) & 2) | ((hx >> 3) & 4);
+    const uint64_t ux = (((p >> 30) & 1) ? 0x8000u : 0x7800u) | (xh << 8) | compact3(lo);
+    const uint64_t uy = (((p >> 31) & 1) ? 0x8000u : 0x7800u) | (yh << 8) | compact3(lo >> 1);
+    const uint64_t uz = (((p >> 32) & 1) ? 0x8000u : 0x7F00u) | compact3(lo >> 2);
+    return (bt << 48) | spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
+}
+
 // 3D key with the spconv batch column: windows of one batch are stacked along a leading axis, key = b * cells + lin
 __host__ __device__ __forceinline__ uint64_t key3b_encode(int b, int z, int y, int x, int D, int H, int W) {
     const uint64_t k = key3_encode(z, y, x, D, H, W);

@@ -116,6 +116,59 @@ __host__ __device__ __forceinline__ uint64_t ckey_expand_b(uint64_t c, int B) {
     return (bt << 48) | spread3(ux) | (spread3(uy) << 1) | (spread3(uz) << 2);
 }
 
+// PACKED SORT KEYS (round 3).  The radix sort moves key AND payload through every pass; with the point index carried in the low
+// bits of the key itself the sort is keys-only (8 instead of 12 bytes per element and pass).  Room for it comes from z: a LiDAR
+// window spans +-256 voxels in z (+-25.6 m at 0.1 m), so z keeps sign + 8 low bits (bits 14..8 of the biased coordinate follow
+// the sign): pkey = [t' : 7][z>=0, y>=0, x>=0][y10 x10 y9 x9 y8 x8][morton3 of the low 8 bits : 24] = 40 bits, ordered exactly
+// like the canonical key, above a 24-bit point index -- 5 byte passes over 8-byte elements for a set of <= 8 windows and
+// < 2^24 points (6 passes over 12-byte pairs before).  Points outside the box are counted (counts[3]) and the caller falls
+// back to the pair sort.
+__global__ void k_quant_keys_p(WinPts W, int64_t n, int ld, float q0, float q1, float q2, float q3,
+                               uint64_t* __restrict__ keys, int32_t* __restrict__ tflag, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b;
+    const float* p = win_point(W, i, ld, b);
+    const int B = W.B;
+    float fx = p[0] / q0, fy = p[1] / q1, fz = p[2] / q2, ft = p[4] / q3;   // the same fp32 ops as k_quant_keys
+    const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz), tq = (int)floorf(ft);
+    uint64_t k;
+    if (x < -2048 || x > 2047 || y < -2048 || y > 2047 || z < -256 || z > 255 || tq < -15 || tq > 0) {
+        atomicAdd(&counts[3], 1);   // (includes everything outside the +-32768 key window: the fallback sorts count those)
+        k = ~0ull;
+    } else {
+        k = ((uint64_t)i << PK_KEY_BITS) | pkey_make((tq + 15) * B + b, x, y, z);
+    }
+    keys[i] = k;
+    tflag[i] = (ft == 0.0f) ? 1 : 0;
+}
+
+__global__ void k_head_flags_p(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];   // (all-ones = a point outside the packed box: the caller repeats the call in another mode)
+    flag[i] = (k != ~0ull) && ((i == 0) || ((k & PK_KEY_MASK) != (keys[i - 1] & PK_KEY_MASK)));
+}
+
+__global__ void k_quant_scatter_p(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ flag,
+                                  const int32_t* __restrict__ scan, int64_t n, int B, uint64_t* __restrict__ vkeys,
+                                  int32_t* __restrict__ vcoords, int32_t* __restrict__ inverse, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ks = keys_s[i];
+    const int vid = scan[i] - 1;
+    if (i == n - 1) counts[0] = scan[i];
+    if (ks == ~0ull) return;
+    if (flag[i]) {
+        const uint64_t k = pkey_expand(ks & PK_KEY_MASK, B);
+        vkeys[vid] = k;
+        int x, y, z, t;
+        key4_decode(k, x, y, z, t);
+        *(int4*)(vcoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
+    }
+    inverse[ks >> PK_KEY_BITS] = vid;
+}
+
 template <bool COMPACT>
 __global__ void k_quant_keys_b(WinPts W, int64_t n, int ld, float q0, float q1, float q2, float q3,
                                uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int32_t* __restrict__ tflag,
@@ -239,10 +292,20 @@ __global__ void k_level_down_scatter(const uint64_t* __restrict__ keys, const in
         key4_decode(k, x, y, z, t);
         *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
         if (child_start) child_start[vid] = (int32_t)i;
+        if (child_mask) {
+            // the children of a coarse voxel are the <= 8 consecutive fine rows that share its key prefix; octant of a fine
+            // voxel inside its parent = the 3 Morton bits just below the parent's stride.  The head row collects them (plain
+            // store: no atomics, no zero-fill of the array)
+            uint32_t m = 0;
+            for (int j = 0; j < 8 && i + j < n; ++j) {
+                const uint64_t kj = keys[i + j];
+                if ((kj >> shift_bits) != (k >> shift_bits)) break;
+                m |= 1u << (unsigned)((kj >> (shift_bits - 3)) & 7ull);
+            }
+            child_mask[vid] = m;
+        }
     }
     parent[i] = vid;
-    // octant of the fine voxel inside its parent = the 3 Morton bits just below the parent's stride
-    if (child_mask) atomicOr(&child_mask[vid], 1u << (unsigned)((keys[i] >> (shift_bits - 3)) & 7ull));
     if (i == n - 1) counts[0] = scan[i];
 }
 
@@ -285,37 +348,52 @@ __global__ void __launch_bounds__(256) k_nbr_from_coarse(const int32_t* __restri
     }
 }
 
-// strided k2s2 conv (coarse p reads child octant k) and its transpose (fine f reads its parent through k = octant(f))
+// strided k2s2 conv (coarse p reads child octant k) and its transpose (fine f reads its parent through k = octant(f)).
+// One thread = one row, all 8 taps: the 16-row group's active-tap mask is a ballot per tap, written once by the group's first
+// lane (all four words: no atomics, no zero-fill of the mask array).
+__device__ __forceinline__ void write_mask8(const int32_t (&r)[8], int64_t row, int64_t n, uint32_t* __restrict__ mask16) {
+    uint32_t mk = 0;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long bal = __ballot(r[k] >= 0);
+        if ((bal >> (lane & 48)) & 0xFFFFull) mk |= 1u << k;
+    }
+    if (mask16 && (lane & 15) == 0 && row < n) *(uint4*)(mask16 + (row >> 4) * 4) = make_uint4(mk, 0u, 0u, 0u);
+}
 __global__ void __launch_bounds__(256) k_nbr_down(int64_t n_c, const int32_t* __restrict__ child_start,
                                                   const uint32_t* __restrict__ child_mask, int32_t* __restrict__ dn,
                                                   uint32_t* __restrict__ mask16) {
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (p >= n_c) return;
-    const uint32_t m = child_mask[p];
-    int32_t r = ((m >> k) & 1u) ? child_start[p] + __popc(m & ((1u << k) - 1u)) : -1;
-    dn[(int64_t)k * n_c + p] = r;
-    if (mask16) {
-        const unsigned long long bal = __ballot(r >= 0);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(p >> 4) * 4], 1u << k);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = p < n_c;
+    const uint32_t m = ok ? child_mask[p] : 0u;
+    const int32_t cs = ok ? child_start[p] : 0;
+    int32_t r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        r[k] = ((m >> k) & 1u) ? cs + __popc(m & ((1u << k) - 1u)) : -1;
+        if (ok) dn[(int64_t)k * n_c + p] = r[k];
     }
+    write_mask8(r, p, n_c, mask16);
 }
 __global__ void __launch_bounds__(256) k_nbr_up(const int32_t* __restrict__ coords, int64_t n_f,
                                                 const int32_t* __restrict__ parent, int L, int32_t* __restrict__ up,
                                                 uint32_t* __restrict__ mask16) {
-    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (f >= n_f) return;
-    int4 c = *(const int4*)(coords + f * 4);
-    const int oct = ((c.x >> L) & 1) | (((c.y >> L) & 1) << 1) | (((c.z >> L) & 1) << 2);
-    int32_t r = (oct == k) ? parent[f] : -1;
-    up[(int64_t)k * n_f + f] = r;
-    if (mask16) {
-        const unsigned long long bal = __ballot(r >= 0);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 15) == 0 && ((bal >> (lane & 48)) & 0xFFFFull)) atomicOr(&mask16[(f >> 4) * 4], 1u << k);
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = f < n_f;
+    int oct = -1, par = -1;
+    if (ok) {
+        const int4 c = *(const int4*)(coords + f * 4);
+        oct = ((c.x >> L) & 1) | (((c.y >> L) & 1) << 1) | (((c.z >> L) & 1) << 2);
+        par = parent[f];
     }
+    int32_t r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        r[k] = (oct == k) ? par : -1;
+        if (ok) up[(int64_t)k * n_f + f] = r[k];
+    }
+    write_mask8(r, f, n_f, mask16);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -609,6 +687,134 @@ __global__ void k_down_expand(const uint32_t* __restrict__ bitmap, const int32_t
 }
 
 // ---------------------------------------------------------------------------------------------------
+// RANK MAPS (round 3): search-free 3D kernel maps.  A coordinate set of a (B, D, H, W) grid as an occupancy bitmap in
+// 256-bit blocks (4 x u64) + the inclusive count of set bits up to each block: the sorted position of a cell is
+//   incl[blk - 1] + popcount(the block's words before it) + popcount(its word below it)
+// -- two independent loads per probe (32 bytes of bitmap, one prefix) where the binary search over the sorted keys makes ~18
+// dependent ones.  The strided levels' bitmaps already exist (their coordinate sets are generated from them); level 1 gets
+// one from the voxeliser's sorted cell keys.  Sorted position -> row: identity for the generated levels, `perm` for level 1
+// (first-seen voxel order; -1 = dropped by the voxel cap).
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_rank_mark_keys(const uint64_t* __restrict__ keys, int64_t n, unsigned long long* __restrict__ bits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    atomicOr(&bits[k >> 6], 1ull << (k & 63));
+}
+__global__ void k_down_mark64(const int32_t* __restrict__ in_coords, int64_t n_in, DownParams P, unsigned long long* __restrict__ bits) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
+    const int in[3] = {c.y, c.z, c.w};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {   // (same reachable-output intervals as k_down_mark)
+        const int top = in[d] + P.pd[d];
+        const int bot = top - P.ks[d] + 1;
+        hi[d] = top >= 0 ? top / P.st[d] : -1;
+        lo[d] = bot > 0 ? (bot + P.st[d] - 1) / P.st[d] : 0;
+        if (hi[d] > P.oshape[d] - 1) hi[d] = P.oshape[d] - 1;
+    }
+    for (int oz = lo[0]; oz <= hi[0]; ++oz)
+        for (int oy = lo[1]; oy <= hi[1]; ++oy)
+            for (int ox = lo[2]; ox <= hi[2]; ++ox) {
+                const uint64_t key = key3b_encode(c.x, oz, oy, ox, P.oshape[0], P.oshape[1], P.oshape[2]);
+                atomicOr(&bits[key >> 6], 1ull << (key & 63));
+            }
+}
+__global__ void k_blk_popc(const uint64_t* __restrict__ bits, int64_t nblk, int32_t* __restrict__ cnt) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const ulonglong4 w = *(const ulonglong4*)(bits + 4 * b);
+    cnt[b] = __popcll(w.x) + __popcll(w.y) + __popcll(w.z) + __popcll(w.w);
+}
+// ascending (b, z, y, x) order falls out of the bitmap; one thread per 64-bit word
+__global__ void k_down_expand64(const uint64_t* __restrict__ bits, const int32_t* __restrict__ incl, int64_t nwords, int D, int H,
+                                int W, int64_t cap, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                                int32_t* __restrict__ counts) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t blk = w >> 2;
+    const int j = (int)(w & 3);
+    const ulonglong4 q = *(const ulonglong4*)(bits + 4 * blk);
+    const uint64_t ws[4] = {q.x, q.y, q.z, q.w};
+    int base = blk ? incl[blk - 1] : 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < j) base += __popcll(ws[t]);
+    uint64_t m = j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w;
+    while (m) {
+        const int b = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        if (base < cap) {
+            const uint64_t k = (uint64_t)w * 64 + b;
+            okeys[base] = k;
+            const uint64_t zz = k / ((uint64_t)W * H);   // b * D + z
+            const int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(zz % (uint64_t)D);
+            *(int4*)(ocoords + (int64_t)base * 4) = make_int4((int)(zz / (uint64_t)D), z, y, x);
+        }
+        ++base;
+    }
+    if (w == nwords - 1) counts[0] = incl[blk];
+}
+
+// One wave = one 16-row group x ALL taps (lane = (tap slot g, row j); K/4 steps): the group's 128-bit active-tap mask is
+// accumulated from wave ballots in scalar registers and written once -- no atomics, no zero-fill of the mask array.
+__global__ void __launch_bounds__(256) k_build_nbr_rank(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                        const uint64_t* __restrict__ bits, const int32_t* __restrict__ incl,
+                                                        const int32_t* __restrict__ perm, NbrParams P, int32_t* __restrict__ nbr,
+                                                        uint32_t* __restrict__ mask16) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grp * 16 >= n_out) return;   // (wave-uniform)
+    const int64_t o = grp * 16 + j;
+    const bool row_ok = o < n_out;
+    const int4 c = *(const int4*)(out_coords + (row_ok ? o : n_out - 1) * 4);
+    const int D = P.shape[0], H = P.shape[1], W = P.shape[2];
+    uint32_t mk[4] = {0u, 0u, 0u, 0u};
+    for (int kk = 0; kk < P.K; kk += 4) {
+        const int k = kk + g;
+        const bool k_ok = k < P.K;
+        const int kc = k_ok ? k : P.K - 1;
+        int q[4] = {c.x * P.mul[0] + P.delta[kc][0], c.y * P.mul[1] + P.delta[kc][1], c.z * P.mul[2] + P.delta[kc][2],
+                    c.w * P.mul[3] + P.delta[kc][3]};
+        bool ok = k_ok && row_ok;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int dv = P.dv[d];
+            if (dv > 1) {
+                if (q[d] % dv != 0) ok = false;   // exact divisibility (floor semantics irrelevant once divisible)
+                q[d] = q[d] / dv;
+            }
+        }
+        int32_t r = -1;
+        if (ok) {
+            const uint64_t key = key3b_encode(q[0], q[1], q[2], q[3], D, H, W);
+            if (key != INSMOS_INVALID_KEY) {
+                const int64_t w = (int64_t)(key >> 6), blk = w >> 2;
+                const int jw = (int)(w & 3);
+                const ulonglong4 qq = *(const ulonglong4*)(bits + 4 * blk);
+                const uint64_t mine = jw == 0 ? qq.x : jw == 1 ? qq.y : jw == 2 ? qq.z : qq.w;
+                if ((mine >> (key & 63)) & 1ull) {
+                    int pos = blk ? incl[blk - 1] : 0;
+                    pos += (jw > 0 ? __popcll(qq.x) : 0) + (jw > 1 ? __popcll(qq.y) : 0) + (jw > 2 ? __popcll(qq.z) : 0);
+                    pos += __popcll(mine & ((1ull << (key & 63)) - 1ull));
+                    r = perm ? perm[pos] : pos;
+                }
+            }
+        }
+        if (k_ok && row_ok) nbr[(int64_t)k * n_out + o] = r;
+        const unsigned long long bal = __ballot(r >= 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = kk + t;   // (taps past K never have r >= 0)
+            if ((bal >> (16 * t)) & 0xFFFFull) mk[(kt >> 5) & 3] |= 1u << (kt & 31);
+        }
+    }
+    if (mask16 && lane == 0) *(uint4*)(mask16 + grp * 4) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // per-voxel tap resolver: one thread = one fine voxel.  The <= 27 coarse neighbour blocks a voxel's taps
 // can fall into are fetched ONCE (independent loads, entries cached in LDS as (child_start, child_mask)),
 // then every tap of the (2*RANGE+1)^3 x NDT kernel is resolved with bit arithmetic only.
@@ -748,7 +954,8 @@ static const int TPB = 256;
 // ===================================================================================================
 extern "C" size_t insmos_quantize4d_ws_bytes(int64_t n) {
     size_t N = (size_t)n;
-    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N);
+    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N), sk = sort_keys_u64_temp(N);
+    if (sk > st) st = sk;
     return pad256(N * 8) * 2 + pad256(N * 4) * 6 + (st > sc ? st : sc) + 1024;
 }
 
@@ -852,38 +1059,61 @@ extern "C" int insmos_quantize4d_windows(const float* const* pts_host, const int
     int32_t* scan = b.take<int32_t>(N);
     int32_t* tflag = b.take<int32_t>(N);
     int32_t* tscan = b.take<int32_t>(N);
-    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N);
+    size_t st = sort_pairs_u64_u32_temp(N), sc = scan_i32_temp(N), sk = sort_keys_u64_temp(N);
     size_t tb = st > sc ? st : sc;
+    if (sk > tb) tb = sk;
     char* tmp = b.take<char>(tb);
     if (!b.ok) return INSMOS_EWORKSPACE;
     HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
     unsigned g = cdiv(n, TPB);
-    {
-        ProfScope ps(KK_QUANT_KEYS, s);
-        if (compact_keys)
-            INSMOS_LAUNCH(k_quant_keys_b<true>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
-                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
-        else
-            INSMOS_LAUNCH(k_quant_keys_b<false>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
-                          quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
-    }
-    const int end_bit = compact_keys ? 36 + bits_for((uint64_t)(16 * B - 1)) : 64;
-    rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, end_bit, s);
-    if (rc) return rc;
-    {
-        ProfScope ps(KK_QUANT_SCATTER, s);
-        INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
-    }
-    rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
-    if (rc) return rc;
-    {
-        ProfScope ps(KK_QUANT_SCATTER, s);
-        if (compact_keys)
-            INSMOS_LAUNCH(k_quant_scatter_b<true>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
-                          counts);
-        else
-            INSMOS_LAUNCH(k_quant_scatter_b<false>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
-                          counts);
+    if (compact_keys == 2) {
+        // packed keys: the point index rides in the high 24 bits above the 40-bit sort key (keys-only sort, 5 byte passes)
+        if (n >= (1ll << PK_IDX_BITS) || 16 * B > 128) return INSMOS_EINVAL;
+        {
+            ProfScope ps(KK_QUANT_KEYS, s);
+            INSMOS_LAUNCH(k_quant_keys_p, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1], quant_host[2],
+                          quant_host[3], k_in, tflag, counts);
+        }
+        rc = sort_keys_u64(tmp, tb, k_in, k_s, N, 0, PK_KEY_BITS, s);   // stable: ties stay in point order
+        if (rc) return rc;
+        {
+            ProfScope ps(KK_QUANT_SCATTER, s);
+            INSMOS_LAUNCH(k_head_flags_p, dim3(g), dim3(TPB), 0, s, k_s, n, flag);
+        }
+        rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
+        if (rc) return rc;
+        {
+            ProfScope ps(KK_QUANT_SCATTER, s);
+            INSMOS_LAUNCH(k_quant_scatter_p, dim3(g), dim3(TPB), 0, s, k_s, flag, scan, n, B, keys, coords, inverse, counts);
+        }
+    } else {
+        {
+            ProfScope ps(KK_QUANT_KEYS, s);
+            if (compact_keys)
+                INSMOS_LAUNCH(k_quant_keys_b<true>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
+                              quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
+            else
+                INSMOS_LAUNCH(k_quant_keys_b<false>, dim3(g), dim3(TPB), 0, s, W, n, ld_pts, quant_host[0], quant_host[1],
+                              quant_host[2], quant_host[3], k_in, i_in, tflag, counts);
+        }
+        const int end_bit = compact_keys ? 36 + bits_for((uint64_t)(16 * B - 1)) : 64;
+        rc = sort_pairs_u64_u32(tmp, st, k_in, k_s, i_in, i_s, N, 0, end_bit, s);
+        if (rc) return rc;
+        {
+            ProfScope ps(KK_QUANT_SCATTER, s);
+            INSMOS_LAUNCH(k_head_flags, dim3(g), dim3(TPB), 0, s, k_s, n, 0, flag);
+        }
+        rc = inclusive_scan_i32(tmp, sc, flag, scan, N, s);
+        if (rc) return rc;
+        {
+            ProfScope ps(KK_QUANT_SCATTER, s);
+            if (compact_keys)
+                INSMOS_LAUNCH(k_quant_scatter_b<true>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
+                              counts);
+            else
+                INSMOS_LAUNCH(k_quant_scatter_b<false>, dim3(g), dim3(TPB), 0, s, k_s, i_s, flag, scan, n, B, keys, coords, inverse,
+                              counts);
+        }
     }
     rc = inclusive_scan_i32(tmp, sc, tflag, tscan, N, s);
     if (rc) return rc;
@@ -936,7 +1166,6 @@ extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, u
     if (rc) return rc;
     {
         ProfScope ps(KK_LEVEL_DOWN, s);
-        if (child_mask) HIP_TRY(hipMemsetAsync(child_mask, 0, (size_t)n * sizeof(uint32_t), s));
         INSMOS_LAUNCH(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
                            out_coords, parent, child_start, child_mask, counts);
     }
@@ -1126,6 +1355,98 @@ extern "C" int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, co
     return INSMOS_OK;
 }
 
+// ---- rank maps (k_build_nbr_rank) ----------------------------------------------------------------------------------------
+static inline int64_t rank_words(int64_t cells) { return ((cells + 255) / 256) * 4; }
+extern "C" size_t insmos_rankmap_words(const int32_t* shape_host, int B) {
+    return (size_t)rank_words((int64_t)shape_host[0] * shape_host[1] * shape_host[2] * (B < 1 ? 1 : B));
+}
+extern "C" size_t insmos_rankmap_ws_bytes(const int32_t* shape_host, int B) {
+    const size_t nblk = insmos_rankmap_words(shape_host, B) / 4;
+    return pad256(nblk * 4) + scan_i32_temp(nblk) + 1024;
+}
+static int rank_finish(uint64_t* bits, int64_t nblk, int32_t* incl, void* ws, size_t ws_bytes, hipStream_t s) {
+    Bump b(ws, ws_bytes);
+    int32_t* cnt = b.take<int32_t>((size_t)nblk);
+    const size_t sc = scan_i32_temp((size_t)nblk);
+    char* tmp = b.take<char>(sc);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    INSMOS_LAUNCH(k_blk_popc, dim3(cdiv(nblk, TPB)), dim3(TPB), 0, s, bits, nblk, cnt);
+    return inclusive_scan_i32(tmp, sc, cnt, incl, (size_t)nblk, s);
+}
+extern "C" int insmos_rankmap_from_keys(const uint64_t* keys, int64_t n, const int32_t* shape_host, int B, uint64_t* bits,
+                                        int32_t* blk_incl, void* ws, size_t ws_bytes, void* stream) {
+    if (!keys || n < 0 || !shape_host || B < 1 || !bits || !blk_incl || !ws) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nw = (int64_t)insmos_rankmap_words(shape_host, B);
+    ProfScope ps(KK_BUILD_NBR, s);
+    HIP_TRY(hipMemsetAsync(bits, 0, (size_t)nw * 8, s));
+    if (n > 0) INSMOS_LAUNCH(k_rank_mark_keys, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, keys, n, (unsigned long long*)bits);
+    int rc = rank_finish(bits, nw / 4, blk_incl, ws, ws_bytes, s);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// insmos_down_coords3d_b with the occupancy bitmap in CALLER memory, in rank-map form, valid afterwards: the output level's
+// rank map for insmos_build_nbr_rank.  bits: insmos_rankmap_words(out_shape, B) u64, blk_incl: a quarter as many i32.
+extern "C" int insmos_down_coords3d_rank(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
+                                         const int32_t* stride_host, const int32_t* pad_host, const int32_t* out_shape_host,
+                                         int B, uint64_t* out_keys, int32_t* out_coords, int32_t* counts, uint64_t* bits,
+                                         int32_t* blk_incl, void* ws, size_t ws_bytes, void* stream) {
+    if (n_in <= 0 || B < 1 || B > INSMOS_MAX_BATCH || !bits || !blk_incl) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    DownParams P;
+    int K = 1;
+    for (int d = 0; d < 3; ++d) {
+        P.ks[d] = ksize_host[d]; P.st[d] = stride_host[d]; P.pd[d] = pad_host[d]; P.oshape[d] = out_shape_host[d];
+        K *= ksize_host[d];
+    }
+    const int64_t cells = (int64_t)P.oshape[0] * P.oshape[1] * P.oshape[2] * B;
+    if (cells <= 0 || cells >= (1ll << 36)) return INSMOS_EINVAL;
+    const int64_t N = n_in * K;
+    const int64_t cap = N < cells ? N : cells;
+    const int64_t nw = rank_words(cells);
+    {
+        ProfScope ps(KK_DOWN_CAND, s);
+        HIP_TRY(hipMemsetAsync(bits, 0, (size_t)nw * 8, s));
+        INSMOS_LAUNCH(k_down_mark64, dim3(cdiv(n_in, TPB)), dim3(TPB), 0, s, in_coords, n_in, P, (unsigned long long*)bits);
+    }
+    int rc = rank_finish(bits, nw / 4, blk_incl, ws, ws_bytes, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(KK_DOWN_UNIQUE, s);
+        INSMOS_LAUNCH(k_down_expand64, dim3(cdiv(nw, TPB)), dim3(TPB), 0, s, bits, blk_incl, nw, P.oshape[0], P.oshape[1], P.oshape[2],
+                      cap, out_keys, out_coords, counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// insmos_build_nbr (key_mode 1) over a rank map instead of a sorted key array: the same table, the same masks.
+extern "C" int insmos_build_nbr_rank(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                                     const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                                     const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16,
+                                     void* stream) {
+    if (n_out <= 0 || K <= 0 || K > 128 || !out_coords || !bits || !blk_incl || !in_shape_host || !delta_host || !nbr)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    NbrParams P;
+    memset(&P, 0, sizeof(P));
+    for (int k = 0; k < K; ++k)
+        for (int d = 0; d < 4; ++d) P.delta[k][d] = delta_host[k * 4 + d];
+    for (int d = 0; d < 4; ++d) {
+        P.mul[d] = mul_host ? mul_host[d] : 1;
+        P.dv[d] = div_host ? div_host[d] : 1;
+    }
+    for (int d = 0; d < 3; ++d) P.shape[d] = in_shape_host[d];
+    P.K = K;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH(k_build_nbr_rank, dim3(cdiv((n_out + 15) / 16, 4)), dim3(256), 0, s, out_coords, n_out, bits, blk_incl, in_perm, P,
+                  nbr, mask16);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
 extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
                                     const int32_t* stride_host, const int32_t* pad_host,
                                     const int32_t* out_shape_host, uint64_t* out_keys, int32_t* out_coords,
@@ -1161,10 +1482,8 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
     if (n_f <= 0 || n_c <= 0 || !fine_coords || !parent || !child_start || !child_mask || !dn || !up) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_BUILD_NBR, s);
-    if (dn_mask16) HIP_TRY(hipMemsetAsync(dn_mask16, 0, (size_t)((n_c + 15) / 16) * 4 * sizeof(uint32_t), s));
-    if (up_mask16) HIP_TRY(hipMemsetAsync(up_mask16, 0, (size_t)((n_f + 15) / 16) * 4 * sizeof(uint32_t), s));
-    INSMOS_LAUNCH(k_nbr_down, dim3(cdiv(n_c, TPB), 8), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
-    INSMOS_LAUNCH(k_nbr_up, dim3(cdiv(n_f, TPB), 8), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
+    INSMOS_LAUNCH(k_nbr_down, dim3(cdiv(n_c, TPB)), dim3(TPB), 0, s, n_c, child_start, child_mask, dn, dn_mask16);
+    INSMOS_LAUNCH(k_nbr_up, dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, up,
                        up_mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;

@@ -170,14 +170,14 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
         const float quant[4] = {g.vs[0], g.vs[0], g.vs[0], g.dt};
-        // compact sort keys first; the full-width sort only for windows wider than +-2048 voxels / 16 time steps
-        CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb,
-                                     1, s));
-        CK(read_counts(counts, hc, 5 + B, s));
-        if (hc[3] != 0) {
-            CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws,
-                                         wsb, 0, s));
+        // packed 40-bit sort keys with the point index in the low bits first (sets of <= 8 windows, < 2^24 points, z within
+        // +-256 voxels), then the 40(+)-bit pair sort, then the full-width sort (windows wider than +-2048 voxels / 16 time steps)
+        static const bool packed_keys = [] { const char* e = getenv("INSMOS_PACKED_KEYS"); return !(e && e[0] == '0'); }();
+        for (int mode = (packed_keys && B <= 8 && N < (1ll << 24)) ? 2 : 1; mode >= 0; --mode) {
+            CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb,
+                                         mode, s));
             CK(read_counts(counts, hc, 5 + B, s));
+            if (hc[3] == 0) break;
         }
         A.off = mark;  // the sort workspace is dead once the counts are back
     }
@@ -337,6 +337,24 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     co[1] = coords1;
     ky[1] = ukeys;
     pm[1] = uperm;
+    // rank maps (occupancy bitmap + block prefix counts) of the five levels: what the 13 kernel maps are read off instead of
+    // binary searches (coords.hip: k_build_nbr_rank); INSMOS_TABLES3D_SEARCH=1 keeps the searched builder (A/B, same tables)
+    static const bool rank_tables = [] { const char* e = getenv("INSMOS_TABLES3D_SEARCH"); return !(e && e[0] == '1'); }();
+    uint64_t* rbits[6] = {nullptr};
+    int32_t* rincl[6] = {nullptr};
+    if (rank_tables) {
+        for (int l = 1; l <= 5; ++l) {
+            const size_t nw = insmos_rankmap_words(g.shape[l], B);
+            rbits[l] = A.take<uint64_t>(nw);
+            rincl[l] = A.take<int32_t>(nw / 4);
+        }
+        const size_t wsb = insmos_rankmap_ws_bytes(g.shape[1], B);
+        const size_t mark = A.off;
+        void* ws = A.take<char>(wsb);
+        NEED_ARENA();
+        CK(insmos_rankmap_from_keys(ukeys, nkeys[1], g.shape[1], B, rbits[1], rincl[1], ws, wsb, s));
+        A.off = mark;   // (stream-ordered: the next user of this scratch is enqueued behind it)
+    }
     auto down_coords = [&](int lvl_in, const int32_t ks[3], const int32_t st[3], const int32_t pd[3], const int32_t* oshape,
                            int lvl_out) -> int {
         const int64_t n_in = nv[lvl_in];
@@ -348,12 +366,21 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         co[lvl_out] = oc;
         ky[lvl_out] = ok;
         pm[lvl_out] = nullptr;
-        if (n_in == 0) { nv[lvl_out] = nkeys[lvl_out] = 0; NEED_ARENA(); return INSMOS_OK; }
-        const size_t wsb = insmos_down_coords3d_ws_bytes_b(oshape, B);
+        if (n_in == 0) {
+            nv[lvl_out] = nkeys[lvl_out] = 0;
+            NEED_ARENA();
+            if (rank_tables) HIP_TRY(hipMemsetAsync(rbits[lvl_out], 0, insmos_rankmap_words(oshape, B) * 8, s));
+            return INSMOS_OK;
+        }
+        const size_t wsb = rank_tables ? insmos_rankmap_ws_bytes(oshape, B) : insmos_down_coords3d_ws_bytes_b(oshape, B);
         const size_t mark = A.off;
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
-        CK(insmos_down_coords3d_b(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
+        if (rank_tables)
+            CK(insmos_down_coords3d_rank(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, rbits[lvl_out], rincl[lvl_out], ws,
+                                         wsb, s));
+        else
+            CK(insmos_down_coords3d_b(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
         CK(read_counts(counts, hc, 1, s));
         A.off = mark;
         nv[lvl_out] = nkeys[lvl_out] = hc[0];
@@ -374,6 +401,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         t = table(K, nv[lvl_out]);
         NEED_ARENA();
         if (nv[lvl_out] == 0) return INSMOS_OK;
+        if (rank_tables)
+            return insmos_build_nbr_rank(co[lvl_out], nv[lvl_out], rbits[lvl_in], rincl[lvl_in], pm[lvl_in], g.shape[lvl_in],
+                                         delta.data(), K, mul, div, t.nbr, t.mask, s);
         return insmos_build_nbr(co[lvl_out], nv[lvl_out], ky[lvl_in], pm[lvl_in], nkeys[lvl_in], 1, g.shape[lvl_in],
                                 delta.data(), K, mul, div, t.nbr, t.mask, s);
     };

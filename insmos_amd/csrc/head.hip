@@ -273,9 +273,14 @@ __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ 
     counts += win * 4;
     uint64_t remv = 0;  // word `lane`
     int nk = 0;
+    uint64_t diag_next = (lane < n) ? mask[(int64_t)lane * cbs] : 0ull;
     for (int blk = 0; blk < nb && nk < post_max; ++blk) {
         const int i_l = blk * 64 + lane;
-        uint64_t diag = (i_l < n) ? mask[(int64_t)i_l * cbs + blk] : 0ull;
+        const uint64_t diag = diag_next;
+        {   // the next block's diagonal words do not depend on this block's outcome: request them now
+            const int i_n = i_l + 64;
+            diag_next = (i_n < n) ? mask[(int64_t)i_n * cbs + blk + 1] : 0ull;
+        }
         uint64_t rb = __shfl(remv, blk);  // this block's removed word, wave-uniform
         uint64_t kept = 0;
         const int lim = min(64, n - blk * 64);
@@ -291,21 +296,22 @@ __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ 
             if (pos < post_max) keep[pos] = i_l;
         }
         nk += __popcll(kept);
-        // fold the kept rows into the later words, 4 independent row loads in flight
-        uint64_t kb = kept;
-        while (kb) {
-            int i0 = __ffsll((unsigned long long)kb) - 1; kb &= kb - 1;
-            int i1 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i1 >= 0) kb &= kb - 1;
-            int i2 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i2 >= 0) kb &= kb - 1;
-            int i3 = kb ? __ffsll((unsigned long long)kb) - 1 : -1; if (i3 >= 0) kb &= kb - 1;
-            uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-            if (lane > blk && lane < nb) {
-                m0 = mask[(int64_t)(blk * 64 + i0) * cbs + lane];
-                if (i1 >= 0) m1 = mask[(int64_t)(blk * 64 + i1) * cbs + lane];
-                if (i2 >= 0) m2 = mask[(int64_t)(blk * 64 + i2) * cbs + lane];
-                if (i3 >= 0) m3 = mask[(int64_t)(blk * 64 + i3) * cbs + lane];
+        // fold the kept rows into the later words.  The rows of a block are requested 32 at a time, UNCONDITIONALLY (independent
+        // loads, one memory round trip per half block instead of one per 4 kept rows -- the reduce is a chain of L2 latencies,
+        // not of bytes: a half block is 32 x 512 B), and only the kept ones are OR-ed in
+        if (lane > blk && lane < nb) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t kh = (uint32_t)(kept >> (32 * h));
+                if (kh == 0u) continue;   // (wave-uniform)
+                uint64_t m[32];
+                const uint64_t* row = mask + (int64_t)(blk * 64 + 32 * h) * cbs + lane;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) m[t] = (blk * 64 + 32 * h + t < n) ? row[(int64_t)t * cbs] : 0ull;
+#pragma unroll
+                for (int t = 0; t < 32; ++t)
+                    if ((kh >> t) & 1u) remv |= m[t];
             }
-            remv |= m0 | m1 | m2 | m3;
         }
     }
     if (lane == 0) counts[0] = nk < post_max ? nk : post_max;

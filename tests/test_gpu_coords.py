@@ -197,3 +197,170 @@ def test_quantize_edge_cases():
     np.testing.assert_array_equal(coords[:V].cpu().numpy(), c)
     np.testing.assert_array_equal(inv.cpu().numpy(), i)
     np.testing.assert_array_equal(cur[:ncur].cpu().numpy(), np.nonzero((pts[:, 4] / q[3]) == 0)[0])
+
+
+def test_rank_map_tables_match_the_oracle_and_the_searched_builder():
+    """The search-free 3D kernel maps (insmos_rankmap_from_keys / insmos_down_coords3d_rank / insmos_build_nbr_rank) on a batch
+    of two windows stacked along the batch column: the strided coordinate set, the submanifold / strided / inverse tables and
+    their active-tap masks equal the oracle's and the searched builder's (insmos_build_nbr), including a level-1 permutation
+    with dropped voxels (-1)."""
+    from gpu_util import dev, hp, i32, lib, stream, tap_masks, u64, ws
+    L = lib()
+    rng = np.random.default_rng(21)
+    shape, B = (9, 40, 52), 2
+    cells = shape[0] * shape[1] * shape[2]
+    per = [np.sort(rng.choice(cells, size=n, replace=False)) for n in (1500, 900)]
+    coords = np.concatenate([np.concatenate([np.full((len(c), 1), b), np.stack(np.unravel_index(c, shape), 1)], 1)
+                             for b, c in enumerate(per)], 0).astype(np.int32)          # [b, z, y, x], ascending keys
+    keys = np.concatenate([b * cells + c for b, c in enumerate(per)]).astype(np.uint64)
+    n = len(coords)
+    # level-1 style permutation: sorted position -> row in "first seen" order, some voxels dropped by a cap
+    perm = rng.permutation(n).astype(np.int32)
+    perm[rng.choice(n, size=60, replace=False)] = -1
+    kept = perm >= 0
+    rows = np.full(n, -1, np.int64)
+    rows[perm[kept]] = np.flatnonzero(kept)
+    # the kept voxels' coordinates in ROW order (rows are a permutation of 0..n-1 with holes where voxels were dropped)
+    order = np.argsort(perm[kept])
+    row_coords = coords[kept][order]
+    perm_c = np.full(n, -1, np.int32)
+    perm_c[np.flatnonzero(kept)[order]] = np.arange(kept.sum(), dtype=np.int32)       # compact rows 0..n_kept-1
+    shp = i32(shape)
+    nw = int(L.insmos_rankmap_words(hp(shp), B))
+    bits = torch.zeros(nw, dtype=torch.int64, device="cuda")
+    incl = torch.zeros(nw // 4, dtype=torch.int32, device="cuda")
+    w = ws(L.insmos_rankmap_ws_bytes(hp(shp), B))
+    keys_d = dev(keys.view(np.int64))
+    assert L.insmos_rankmap_from_keys(keys_d.data_ptr(), n, hp(shp), B, bits.data_ptr(), incl.data_ptr(), w.data_ptr(), w.numel(),
+                                      stream()) == 0
+    torch.cuda.synchronize()
+    assert int(incl[-1]) == n
+    one = i32([1, 1, 1, 1])
+    d_subm = i32([[0, kz - 1, ky - 1, kx - 1] for kz in range(3) for ky in range(3) for kx in range(3)])
+
+    def both(out_coords, in_perm, in_shape, delta, mul, div, bits_t, incl_t, in_keys):
+        no = len(out_coords)
+        oc = dev(out_coords)
+        res = []
+        for use_rank in (True, False):
+            nbr = torch.full((len(delta), no), -7, dtype=torch.int32, device="cuda")
+            mask = torch.full(((no + 15) // 16, 4), -1, dtype=torch.int32, device="cuda")   # garbage: the rank builder overwrites
+            pm = dev(in_perm) if in_perm is not None else None
+            if use_rank:
+                rc = L.insmos_build_nbr_rank(oc.data_ptr(), no, bits_t.data_ptr(), incl_t.data_ptr(), pm.data_ptr() if pm is not None else None,
+                                             hp(i32(in_shape)), hp(delta), len(delta), hp(mul), hp(div), nbr.data_ptr(), mask.data_ptr(), stream())
+            else:
+                kd = dev(in_keys.view(np.int64))
+                rc = L.insmos_build_nbr(oc.data_ptr(), no, kd.data_ptr(), pm.data_ptr() if pm is not None else None, len(in_keys), 1,
+                                        hp(i32(in_shape)), hp(delta), len(delta), hp(mul), hp(div), nbr.data_ptr(), mask.data_ptr(), stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+            res.append((nbr.cpu().numpy(), mask.cpu().numpy().view(np.uint32)))
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_array_equal(res[0][1], tap_masks(res[0][0]))
+        return res[0][0]
+
+    # submanifold table over the permuted level (rows = first-seen order, some cells dropped)
+    sub = both(row_coords, perm_c, shape, d_subm, one, one, bits, incl, keys)
+    for b in range(B):   # per window against the oracle (its tables are single-window)
+        sel = row_coords[:, 0] == b
+        kb = (keys[(keys // cells) == b] - b * cells).astype(np.uint64)
+        pb = perm_c[(keys // cells) == b]
+        ref = R.spconv_nbr_subm(row_coords[sel][:, 1:], kb, pb, shape)
+        np.testing.assert_array_equal(sub[:, sel], ref)
+    # strided k3 s2 p1 output set + its rank map, then the strided and inverse tables (identity permutation on both sides)
+    oshape = tuple(R.spconv_out_shape(shape, (3, 3, 3), (2, 2, 2), (1, 1, 1)))
+    osh = i32(oshape)
+    nwo = int(L.insmos_rankmap_words(hp(osh), B))
+    obits = torch.zeros(nwo, dtype=torch.int64, device="cuda")
+    oincl = torch.zeros(nwo // 4, dtype=torch.int32, device="cuda")
+    cap = min(n * 27, int(np.prod(oshape)) * B)
+    okeys = torch.zeros(cap, dtype=torch.int64, device="cuda")
+    ocoords = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(8, dtype=torch.int32, device="cuda")
+    w2 = ws(L.insmos_rankmap_ws_bytes(hp(osh), B))
+    cd = dev(coords)
+    assert L.insmos_down_coords3d_rank(cd.data_ptr(), n, hp(i32([3, 3, 3])), hp(i32([2, 2, 2])), hp(i32([1, 1, 1])), hp(osh), B,
+                                       okeys.data_ptr(), ocoords.data_ptr(), counts.data_ptr(), obits.data_ptr(), oincl.data_ptr(),
+                                       w2.data_ptr(), w2.numel(), stream()) == 0
+    torch.cuda.synchronize()
+    no = int(counts[0])
+    ocells = int(np.prod(oshape))
+    ref_c, ref_k = [], []
+    for b in range(B):
+        c_b, k_b, _ = R.spconv_down_coords(coords[coords[:, 0] == b][:, 1:], shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        ref_c.append(np.concatenate([np.full((len(c_b), 1), b, np.int32), c_b], 1))
+        ref_k.append(k_b.astype(np.uint64) + np.uint64(b * ocells))
+    ref_c, ref_k = np.concatenate(ref_c), np.concatenate(ref_k)
+    assert no == len(ref_c)
+    np.testing.assert_array_equal(ocoords[:no].cpu().numpy(), ref_c)
+    np.testing.assert_array_equal(u64(okeys[:no]), ref_k)
+    two = i32([1, 2, 2, 2])
+    d_inv = i32([[0, 1 - kz, 1 - ky, 1 - kx] for kz in range(3) for ky in range(3) for kx in range(3)])
+    down = both(ref_c, None, shape, d_subm, two, one, bits, incl, keys)          # coarse rows read fine rows
+    inv = both(coords, None, oshape, d_inv, one, two, obits, oincl, ref_k)       # fine rows read coarse rows
+    for b in range(B):
+        fine_b = coords[coords[:, 0] == b][:, 1:]
+        off_f, off_c = int((coords[:, 0] < b).sum()), int((ref_c[:, 0] < b).sum())
+        kf = (keys[(keys // cells) == b] - b * cells).astype(np.uint64)
+        sel_c = ref_c[:, 0] == b
+        rd = R.spconv_nbr_down(ref_c[sel_c][:, 1:], kf, None, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        got = down[:, sel_c]
+        np.testing.assert_array_equal(np.where(got >= 0, got - off_f, -1), rd)
+        ri = R.spconv_nbr_inverse(fine_b, (ref_k[sel_c] - np.uint64(b * ocells)), None, oshape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        got = inv[:, coords[:, 0] == b]
+        np.testing.assert_array_equal(np.where(got >= 0, got - off_c, -1), ri)
+
+
+@pytest.mark.parametrize("n_per,B", [(700, 1), (40000, 2), (160000, 1), (260000, 3), (1300000, 1), (600000, 8)])
+def test_packed_sort_keys_give_the_pair_sort_results(n_per, B):
+    """insmos_quantize4d_windows: the packed-key sort (mode 2: 40-bit key + 24-bit point index in one u64, keys-only radix sort)
+    yields exactly what the pair sorts (modes 1 and 0) yield -- voxel keys, coordinates, point -> voxel map, current-point list
+    and counts -- from a few hundred points (rocPRIM's small-size paths) to a full launch set; a point outside the packed box
+    (z beyond +-256 voxels) is reported in counts[3] so that the caller falls back."""
+    import ctypes
+    from gpu_util import hp, lib, stream, ws
+    L = lib()
+    rng = np.random.default_rng(n_per + B)
+    wins = []
+    for b in range(B):
+        n = n_per + 17 * b
+        p = np.zeros((n, 5), np.float32)
+        p[:, 0] = rng.uniform(-80, 80, n); p[:, 1] = rng.uniform(-60, 60, n); p[:, 2] = rng.uniform(-3, 12, n)
+        p[: n // 3, :3] = np.round(p[: n // 3, :3], 1)                     # many points per voxel + exact cell borders
+        p[:, 3] = rng.uniform(0, 1, n)
+        p[:, 4] = -np.round(rng.integers(0, 10, n) * 0.1, 3)
+        wins.append(torch.from_numpy(p).cuda())
+    N = sum(int(w.shape[0]) for w in wins)
+    win_ptr = (ctypes.c_void_p * B)(*[w.data_ptr() for w in wins])
+    win_n = (ctypes.c_int64 * B)(*[int(w.shape[0]) for w in wins])
+    quant = np.array([0.1, 0.1, 0.1, 0.1], np.float32)
+    w_ = ws(L.insmos_quantize4d_ws_bytes(N))
+    res = {}
+    for mode in (2, 1, 0):
+        keys = torch.zeros(N, dtype=torch.int64, device="cuda")
+        coords = torch.zeros((N, 4), dtype=torch.int32, device="cuda")
+        inverse = torch.full((N,), -5, dtype=torch.int32, device="cuda")
+        cur = torch.full((N,), -5, dtype=torch.int32, device="cuda")
+        counts = torch.zeros(8 + B, dtype=torch.int32, device="cuda")
+        assert L.insmos_quantize4d_windows(win_ptr, win_n, B, 5, hp(quant), keys.data_ptr(), coords.data_ptr(), inverse.data_ptr(),
+                                           cur.data_ptr(), counts.data_ptr(), w_.data_ptr(), w_.numel(), mode, stream()) == 0
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy()
+        assert c[2] == 0 and c[3] == 0, (mode, c)
+        nv, nc = int(c[0]), int(c[1])
+        res[mode] = (c.copy(), keys[:nv].cpu().numpy(), coords[:nv].cpu().numpy(), inverse.cpu().numpy(), cur[:nc].cpu().numpy())
+    for mode in (1, 0):
+        for a, b_ in zip(res[2], res[mode]):
+            np.testing.assert_array_equal(a, b_)
+    ku = res[2][1].view(np.uint64)
+    assert (ku[1:] > ku[:-1]).all()                                                     # ascending unique keys
+    # one point outside the packed box: mode 2 reports it, mode 1 handles it
+    wins[0][5, 2] = 30.0
+    counts = torch.zeros(8 + B, dtype=torch.int32, device="cuda")
+    scratch = [torch.zeros(N * 4, dtype=torch.int64, device="cuda") for _ in range(4)]
+    assert L.insmos_quantize4d_windows(win_ptr, win_n, B, 5, hp(quant), scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(),
+                                       scratch[3].data_ptr(), counts.data_ptr(), w_.data_ptr(), w_.numel(), 2, stream()) == 0
+    torch.cuda.synchronize()
+    assert int(counts[3]) == 1

@@ -112,24 +112,30 @@ def test_s0_full_size_against_the_oracle():
     # label-exact after argmax, every point (the north star's bar; the 1.2 % of current points outside the voxel range carry
     # all-zero logits on both sides: exact ties, decided by the same first-maximum rule)
     np.testing.assert_array_equal(lab, lab_ref)
-    # the same boxes in the same order: the keep list of greedy NMS over ~1400 candidates of a random-weight head.  A pair whose
-    # IoU sits within fp32 rounding of the threshold could flip one keep decision and shift the rest of the list; if that ever
-    # happens the test names the pair and its IoU instead of accepting a fuzzy match.
+    # the same keep list: greedy NMS over ~1400 candidates of a random-weight head, walked in descending score order.  Scores are
+    # sigmoids of logits that agree to ~3e-5, so two candidates whose scores differ by less than that may swap places in the
+    # walk; nothing else may differ.  Checked: the score SEQUENCES agree position by position (1e-4), every kept box has exactly
+    # one twin in the oracle's list (a bijection over ALL boxes: 7 numbers within 1e-3, same class), and a box sits at another
+    # position than its twin only where the two scores are within 1e-4 of each other (an order swap among near-ties).  A
+    # borderline IoU flipping a keep decision would break the bijection, and the message names the first box without a twin.
     pb, rb = single[1]["pred_boxes"].cpu().numpy(), ref_pred["pred_boxes"]
     pl, rl = single[1]["pred_labels"].cpu().numpy(), ref_pred["pred_labels"]
     ps, rs = single[1]["pred_scores"].cpu().numpy(), ref_pred["pred_scores"]
     assert len(pb) == len(rb) >= 100
-    same = (np.abs(pb - rb).max(1) < 1e-3) & (pl == rl)
-    if not same.all():
-        i = int(np.flatnonzero(~same)[0])
-        prev = rb[:i] if i else rb[:1]
-        iou_g = R.iou_bev_matrix(pb[i:i + 1], prev).max() if i else 0.0
-        iou_r = R.iou_bev_matrix(rb[i:i + 1], prev).max() if i else 0.0
+    np.testing.assert_allclose(ps, rs, atol=1e-4)
+    d = np.abs(pb[:, None, :] - rb[None, :, :]).max(2)
+    twin = d.argmin(1)
+    ok = (d.min(1) < 1e-3) & (pl == rl[twin])
+    if not ok.all():
+        i = int(np.flatnonzero(~ok)[0])
         thr = float(cfg["MODEL"]["POST_PROCESSING"]["NMS_CONFIG"]["NMS_THRESH"])
-        raise AssertionError("keep lists diverge at position %d: GPU box %s (max IoU with the kept prefix %.7f) vs oracle box %s "
-                             "(%.7f), NMS threshold %.4f" % (i, pb[i].tolist(), iou_g, rb[i].tolist(), iou_r, thr))
-    np.testing.assert_allclose(ps, rs, atol=1e-5)
-    print("boxes: %d identical to the oracle's keep list, in order" % len(pb))
+        iou = R.iou_bev_matrix(pb[i:i + 1], rb).max()
+        raise AssertionError("GPU keep list position %d (score %.7f) has no twin in the oracle's list: box %s, largest IoU with an "
+                             "oracle box %.7f (NMS threshold %.4f)" % (i, ps[i], pb[i].tolist(), iou, thr))
+    assert len(set(twin.tolist())) == len(pb)                   # one-to-one
+    moved = np.flatnonzero(twin != np.arange(len(pb)))
+    assert (np.abs(ps[moved] - rs[twin[moved]]) < 1e-4).all() and (np.abs(ps[moved] - rs[moved]) < 1e-4).all()
+    print("boxes: %d, each with its twin in the oracle's keep list; %d at a swapped position among near-tied scores" % (len(pb), len(moved)))
 
 
 def test_cfg4_dense_stress_full_size_properties():
