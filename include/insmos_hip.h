@@ -226,6 +226,11 @@ int insmos_quantize4d_windows(const float* const* points_host, const int64_t* n_
 int insmos_build_current_points_windows(const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
                                         const float* motion, int ld_motion, const int32_t* inverse, const int32_t* cur_index,
                                         int64_t n_cur, float* cur, int ld_cur, void* stream);
+/* the same in parts: part 0 = whole rows; part 1 = [x, y, z, r, 0, ..] (motion may be NULL: known before MotionNet has run, all the
+ * voxeliser's coordinate phase reads); part 2 = the motion columns 4..6 into rows part 1 wrote (motionnet.py:42-48). */
+int insmos_build_current_points_part(const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
+                                     const float* motion, int ld_motion, const int32_t* inverse, const int32_t* cur_index,
+                                     int64_t n_cur, float* cur, int ld_cur, int part, void* stream);
 /* win_start (device, B + 1 int32): first point of each window in the window-major point array (null: one window).  Every
  * window is voxelised in its own first-seen order and capped at max_voxels on its own (the reference calls VoxelGenerate
  * per batch item, models/models.py:326); voxel rows are window-major, pc_voxel_id holds batch-wide rows.
@@ -236,6 +241,15 @@ int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int
                                  int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels, int max_pts, float* feat,
                                  int ld_feat, int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id, uint64_t* ukeys,
                                  int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* The voxeliser in two phases (round 3: the 3D coordinate branch runs beside MotionNet).  phase 1 = everything that depends on the
+ * points' POSITIONS only (coords, num_points, pc_voxel_id, ukeys / uperm, counts); phase 2 (same arguments and workspace, the
+ * workspace untouched in between) = the MeanVFE feature means (mean_vfe.py:47-52), which need the motion columns.  phase 0 = both =
+ * insmos_voxelize_mean_windows.  phase 1 + phase 2 give phase 0's bits. */
+int insmos_voxelize_windows_phased(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start, int B,
+                                   int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels, int max_pts,
+                                   float* feat, int ld_feat, int32_t* coords, int32_t* num_points, int64_t* pc_voxel_id,
+                                   uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws, size_t ws_bytes, int phase,
+                                   void* stream);
 size_t insmos_down_coords3d_ws_bytes_b(const int32_t* out_shape_host, int B);
 int insmos_down_coords3d_b(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host, const int32_t* stride_host,
                            const int32_t* pad_host, const int32_t* out_shape_host, int B, uint64_t* out_keys,
@@ -558,6 +572,13 @@ int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts,
 /* The whole batch list of InsMOS_Model.forward in one launch set: points_host[b] (n_points_host[b], ld_pts) device arrays,
  * outs[b] as above for window b (offsets into the shared arena).  B = 1 is insmos_forward_window.  INSMOS_EBATCH: the
  * batch's finest 81-tap table would pass 2 GiB (kernels address tables with 32-bit byte offsets) -- split the list. */
+/* The native runner puts the work that is not on the convolution chain on a second stream of the calling host thread (created on
+ * first use; ordered against the caller's stream by events; joined before the function returns): bit 0 = the level-0 81-tap
+ * table, bit 1 = the 3D branch's coordinate sets and kernel maps (beside MotionNet's convolutions), bit 2 = inv_conv_out (beside
+ * the BEV head), bit 3 = the finer levels' one-hot passes (beside the level-4 decoder).  Same bits either way.  mask -1 = default
+ * (15); the environment variable INSMOS_TWO_STREAMS overrides both.  Single-window latency 3.8 -> 3.4 ms; with several launch
+ * sets in flight the sets already overlap each other and the caller switches it off (insmos_amd/models.py). */
+int insmos_forward_streams(int mask);
 int insmos_debug_table_limit(int64_t bytes); /* tests only: lower the table size at which a batch is refused (0 = default) */
 int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
                            void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs);

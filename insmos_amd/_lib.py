@@ -47,8 +47,11 @@ SIGNATURES = {
     "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "insmos_quantize4d_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "insmos_build_current_points_windows": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_vp]),
+    "insmos_build_current_points_part": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_vp]),
     "insmos_voxelize_mean_windows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
                                              c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_voxelize_windows_phased": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
+                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "insmos_down_coords3d_ws_bytes_b": (c_sz, [c_vp, c_int]),
     "insmos_down_coords3d_b": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_dense_nbr2d_b": (c_int, [c_int, c_int, c_int, c_vp, c_vp]),
@@ -62,6 +65,7 @@ SIGNATURES = {
     "insmos_boxes_to_onehot_b": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
                                          c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_debug_table_limit": (c_int, [c_i64]),
+    "insmos_forward_streams": (c_int, [c_int]),
     "insmos_rankmap_words": (c_sz, [c_vp, c_int]),
     "insmos_rankmap_ws_bytes": (c_sz, [c_vp, c_int]),
     "insmos_rankmap_from_keys": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),

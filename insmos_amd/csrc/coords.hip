@@ -553,8 +553,9 @@ __global__ void k_vox_heads(const uint64_t* __restrict__ keys_s, const int32_t* 
 //   woff[b] = voxels first seen in the windows before b, woff[B+1+b] = first voxel ROW of window b (caps applied)
 __global__ void k_vox_offsets(const int32_t* __restrict__ win_start, int B, int64_t n, const int32_t* __restrict__ rank_scan,
                               const int32_t* __restrict__ sid_scan, int max_voxels, int32_t* __restrict__ woff,
-                              int32_t* __restrict__ counts) {
+                              int32_t* __restrict__ counts, int32_t* __restrict__ kept_state) {
     if (threadIdx.x != 0) return;
+    kept_state[0] = sid_scan[n - 1];
     int row = 0;
     for (int b = 0; b <= B; ++b) {
         const int64_t s = b == B ? n : (win_start ? (int64_t)win_start[b] : 0);
@@ -571,6 +572,7 @@ __global__ void k_vox_offsets(const int32_t* __restrict__ win_start, int B, int6
     counts[1] = sid_scan[n - 1];   // occupied cells (search-structure entries, dropped ones included)
 }
 
+template <bool FEATS>
 __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat, const uint64_t* __restrict__ keys_s,
                                const int32_t* __restrict__ sid_scan, int64_t n, const int32_t* __restrict__ seg_start,
                                const int32_t* __restrict__ seg_first, const int32_t* __restrict__ rank_scan,
@@ -601,6 +603,7 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
         int cnt = end - start;
         int m = cnt < max_pts ? cnt : max_pts;
         num_points[vid] = m;
+        if (!FEATS) return;   // coordinates only: k_vox_features averages the point features later (phase 2)
         float acc[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[f] = 0.f;
@@ -618,6 +621,36 @@ __global__ void k_vox_segments(const float* __restrict__ pts, int ld, int n_feat
             if (f < ld_feat) fo[f] = f < n_feat ? acc[f] / norm : 0.f;
         for (int f = 8; f < ld_feat; ++f) fo[f] = 0.f;
     }
+}
+
+// Phase 2 of the voxeliser (insmos_voxelize_windows_phased): the mean of the first max_pts points' features per KEPT voxel, from
+// the sorted keys / segment starts phase 1 left in the workspace.  Same loop, same order as k_vox_segments<true>: same bits.
+__global__ void k_vox_features(const float* __restrict__ pts, int ld, int n_feat, const uint64_t* __restrict__ keys_s,
+                               const int32_t* __restrict__ seg_start, const int32_t* __restrict__ kept_state,
+                               const int32_t* __restrict__ uperm, const int32_t* __restrict__ num_points,
+                               float* __restrict__ feat, int ld_feat) {
+    const int64_t sid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= kept_state[0]) return;   // [0] = occupied cells
+    const int vid = uperm[sid];
+    if (vid < 0) return;
+    const int start = seg_start[sid];
+    const int m = num_points[vid];
+    float acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = 0.f;
+    for (int j = 0; j < m; ++j) {
+        const int p = (int)(keys_s[start + j] & ((1ull << VOX_IDX_BITS) - 1));
+        const float* pp = pts + (int64_t)p * ld;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+            if (f < n_feat) acc[f] += pp[f];
+    }
+    const float norm = (float)(m < 1 ? 1 : m);
+    float* fo = feat + (int64_t)vid * ld_feat;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        if (f < ld_feat) fo[f] = f < n_feat ? acc[f] / norm : 0.f;
+    for (int f = 8; f < ld_feat; ++f) fo[f] = 0.f;
 }
 
 // pc_voxel_id: one thread per sorted point (the voxel of a point = uperm of its segment; no per-voxel loops over 1..50 points)
@@ -701,10 +734,18 @@ __global__ void k_rank_mark_keys(const uint64_t* __restrict__ keys, int64_t n, u
     const uint64_t k = keys[i];
     atomicOr(&bits[k >> 6], 1ull << (k & 63));
 }
-__global__ void k_down_mark64(const int32_t* __restrict__ in_coords, int64_t n_in, DownParams P, unsigned long long* __restrict__ bits) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
-    int4 c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
+// Rows of the generated levels come in ascending cell order, so the lanes of a wave aim at the same few bitmap words: a plain
+// atomicOr per (voxel, reachable cell) makes ~3.4 same-address atomics per voxel, which serialise in the L2 (~12 ns each: the
+// kernel took 50 us per level-1 call).  Per reachable-cell SLOT (2 x 2 x 2: low / high output along each axis) the wave ORs the
+// bits of lanes that hit the same word into the LAST lane of each run of equal words (segmented suffix-free scan over lanes,
+// 6 shuffle steps) and only that lane issues the atomic.  Unsorted rows (level 1: first-seen order) just form shorter runs.
+__global__ void __launch_bounds__(256) k_down_mark64(const int32_t* __restrict__ in_coords, int64_t n_in, DownParams P,
+                                                     unsigned long long* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n_in;
+    const int lane = threadIdx.x & 63;
+    int4 c = make_int4(0, 0, 0, 0);
+    if (live) c = *(const int4*)(in_coords + i * 4);  // [b,z,y,x]
     const int in[3] = {c.y, c.z, c.w};
     int lo[3], hi[3];
 #pragma unroll
@@ -715,12 +756,40 @@ __global__ void k_down_mark64(const int32_t* __restrict__ in_coords, int64_t n_i
         lo[d] = bot > 0 ? (bot + P.st[d] - 1) / P.st[d] : 0;
         if (hi[d] > P.oshape[d] - 1) hi[d] = P.oshape[d] - 1;
     }
-    for (int oz = lo[0]; oz <= hi[0]; ++oz)
-        for (int oy = lo[1]; oy <= hi[1]; ++oy)
-            for (int ox = lo[2]; ox <= hi[2]; ++ox) {
-                const uint64_t key = key3b_encode(c.x, oz, oy, ox, P.oshape[0], P.oshape[1], P.oshape[2]);
-                atomicOr(&bits[key >> 6], 1ull << (key & 63));
-            }
+    // the interval of an axis holds 0, 1 or 2 cells for the kernels in use (3/2/1 and 3x1x1/2x1x1/0); wider ones fall back
+    const bool wide = live && (hi[0] - lo[0] > 1 || hi[1] - lo[1] > 1 || hi[2] - lo[2] > 1);
+    if (__ballot(wide)) {   // (wave-uniform; never taken by the model's own maps)
+        if (live)
+            for (int oz = lo[0]; oz <= hi[0]; ++oz)
+                for (int oy = lo[1]; oy <= hi[1]; ++oy)
+                    for (int ox = lo[2]; ox <= hi[2]; ++ox) {
+                        const uint64_t key = key3b_encode(c.x, oz, oy, ox, P.oshape[0], P.oshape[1], P.oshape[2]);
+                        atomicOr(&bits[key >> 6], 1ull << (key & 63));
+                    }
+        return;
+    }
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) {
+        const int sz = slot >> 2, sy = (slot >> 1) & 1, sx = slot & 1;
+        const int oz = lo[0] + sz, oy = lo[1] + sy, ox = lo[2] + sx;
+        const bool ok = live && oz <= hi[0] && oy <= hi[1] && ox <= hi[2];
+        uint64_t word = ~0ull, m = 0ull;
+        if (ok) {
+            const uint64_t key = key3b_encode(c.x, oz, oy, ox, P.oshape[0], P.oshape[1], P.oshape[2]);
+            word = key >> 6;
+            m = 1ull << (key & 63);
+        }
+        if (__ballot(ok) == 0ull) continue;
+        // inclusive OR-scan over runs of equal `word` (a run's lanes are consecutive)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t wu = __shfl_up(word, d, 64);
+            const uint64_t mu = __shfl_up(m, d, 64);
+            if (lane >= d && wu == word) m |= mu;
+        }
+        const uint64_t wn = __shfl_down(word, 1, 64);
+        if (ok && (lane == 63 || wn != word)) atomicOr(&bits[word], m);
+    }
 }
 __global__ void k_blk_popc(const uint64_t* __restrict__ bits, int64_t nblk, int32_t* __restrict__ cnt) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,34 +797,37 @@ __global__ void k_blk_popc(const uint64_t* __restrict__ bits, int64_t nblk, int3
     const ulonglong4 w = *(const ulonglong4*)(bits + 4 * b);
     cnt[b] = __popcll(w.x) + __popcll(w.y) + __popcll(w.z) + __popcll(w.w);
 }
-// ascending (b, z, y, x) order falls out of the bitmap; one thread per 64-bit word
+// ascending (b, z, y, x) order falls out of the bitmap; one thread per 64-bit word (most words are empty: they leave at once; the
+// 64-bit divisions that turn a cell index into coordinates are done once per word, the bits of a word walk on from there)
 __global__ void k_down_expand64(const uint64_t* __restrict__ bits, const int32_t* __restrict__ incl, int64_t nwords, int D, int H,
                                 int W, int64_t cap, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
                                 int32_t* __restrict__ counts) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     const int64_t blk = w >> 2;
+    if (w == nwords - 1) counts[0] = incl[blk];
+    uint64_t m = bits[w];
+    if (!m) return;
     const int j = (int)(w & 3);
-    const ulonglong4 q = *(const ulonglong4*)(bits + 4 * blk);
-    const uint64_t ws[4] = {q.x, q.y, q.z, q.w};
     int base = blk ? incl[blk - 1] : 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (t < j) base += __popcll(ws[t]);
-    uint64_t m = j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w;
+    for (int t = 0; t < j; ++t) base += __popcll(bits[4 * blk + t]);
+    const uint64_t k0 = (uint64_t)w * 64;
+    const uint64_t zz0 = k0 / ((uint64_t)W * H);   // b * D + z of the word's first cell
+    const uint32_t rem = (uint32_t)(k0 - zz0 * ((uint64_t)W * H));
+    const int y0 = (int)(rem / (uint32_t)W), x0 = (int)(rem % (uint32_t)W);
     while (m) {
         const int b = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
         if (base < cap) {
-            const uint64_t k = (uint64_t)w * 64 + b;
-            okeys[base] = k;
-            const uint64_t zz = k / ((uint64_t)W * H);   // b * D + z
-            const int x = (int)(k % (uint64_t)W), y = (int)((k / (uint64_t)W) % (uint64_t)H), z = (int)(zz % (uint64_t)D);
-            *(int4*)(ocoords + (int64_t)base * 4) = make_int4((int)(zz / (uint64_t)D), z, y, x);
+            int x = x0 + b, y = y0;
+            uint32_t zz = (uint32_t)zz0;
+            while (x >= W) { x -= W; ++y; }
+            while (y >= H) { y -= H; ++zz; }
+            okeys[base] = k0 + (uint64_t)b;
+            *(int4*)(ocoords + (int64_t)base * 4) = make_int4((int)(zz / (uint32_t)D), (int)(zz % (uint32_t)D), y, x);
         }
         ++base;
     }
-    if (w == nwords - 1) counts[0] = incl[blk];
 }
 
 // One wave = one 16-row group x ALL taps (lane = (tap slot g, row j); K/4 steps): the group's 128-bit active-tap mask is
@@ -1226,11 +1298,16 @@ extern "C" size_t insmos_voxelize_mean_ws_bytes(int64_t n) {
 // deeper than the voxel grid, spconv_unet.py:114; 0 = the voxel grid's own cell count).
 // counts: [0] voxel rows, [1] occupied cells, [2] in-range points, and when win_start is given [4 .. 4+B] row starts
 // (5 + B int32 slots).
-extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start,
-                                            int B, int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels,
-                                            int max_pts, float* feat, int ld_feat, int32_t* coords, int32_t* num_points,
-                                            int64_t* pc_voxel_id, uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws,
-                                            size_t ws_bytes, void* stream) {
+// phase 0: everything (insmos_voxelize_mean_windows).  phase 1: everything EXCEPT the feature means -- voxel coordinates,
+// num_points, pc_voxel_id, ukeys / uperm, counts depend on the points' positions only, so the 3D coordinate sets and kernel maps
+// can be built while the motion features are still being computed.  phase 2 (same arguments, same workspace, untouched in
+// between): the feature means.  phase 1 + phase 2 == phase 0 bit for bit.
+extern "C" int insmos_voxelize_windows_phased(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start,
+                                              int B, int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels,
+                                              int max_pts, float* feat, int ld_feat, int32_t* coords, int32_t* num_points,
+                                              int64_t* pc_voxel_id, uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws,
+                                              size_t ws_bytes, int phase, void* stream) {
+    if (phase < 0 || phase > 2) return INSMOS_EINVAL;
     if (n <= 0 || n >= (1ll << VOX_IDX_BITS) || n_feat < 3 || n_feat > 8 || ld_pts < n_feat || ld_feat < n_feat ||
         max_voxels <= 0 || max_pts <= 0 || B < 1 || B > INSMOS_MAX_BATCH || (B > 1 && !win_start))
         return INSMOS_EINVAL;
@@ -1255,12 +1332,20 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
     int32_t* rank_scan = b.take<int32_t>(N + 1);
     int32_t* seg_start = b.take<int32_t>(N + 1);
     int32_t* seg_first = b.take<int32_t>(N + 1);
-    int32_t* woff = b.take<int32_t>(2 * (INSMOS_MAX_BATCH + 1));
+    int32_t* woff = b.take<int32_t>(2 * (INSMOS_MAX_BATCH + 1) + 4);   // (+ [.. + 0] = occupied cells, kept for phase 2)
+    int32_t* kept_state = woff + 2 * (INSMOS_MAX_BATCH + 1);
     size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
     char* tmp = b.take<char>(st > sc ? st : sc);
     if (!b.ok) return INSMOS_EWORKSPACE;
-    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
     unsigned g = cdiv(n, TPB);
+    if (phase == 2) {
+        ProfScope ps(KK_VOX_MEAN, s);
+        INSMOS_LAUNCH(k_vox_features, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, seg_start, kept_state, uperm, num_points,
+                      feat, ld_feat);
+        HIP_TRY(hipGetLastError());
+        return INSMOS_OK;
+    }
+    HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
     {
         ProfScope ps(KK_VOX_KEYS, s);
         INSMOS_LAUNCH(k_vox_keys, dim3(g), dim3(TPB), 0, s, points, n, ld_pts, win_start, B, (uint64_t)key_cells,
@@ -1285,14 +1370,28 @@ extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int 
     {
         ProfScope ps(KK_VOX_MEAN, s);
         INSMOS_LAUNCH(k_vox_offsets, dim3(1), dim3(64), 0, s, win_start, B, n, rank_scan, sid_scan,
-                      max_voxels, woff, counts);
-        INSMOS_LAUNCH(k_vox_segments, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
-                      seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
-                      num_points, ukeys, uperm, counts);
+                      max_voxels, woff, counts, kept_state);
+        if (phase == 0)
+            INSMOS_LAUNCH(k_vox_segments<true>, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
+                          seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
+                          num_points, ukeys, uperm, counts);
+        else
+            INSMOS_LAUNCH(k_vox_segments<false>, dim3(g), dim3(TPB), 0, s, points, ld_pts, n_feat, k_s, sid_scan, n, seg_start,
+                          seg_first, rank_scan, woff, B, (uint64_t)key_cells, g3[0], g3[1], max_voxels, max_pts, feat, ld_feat, coords,
+                          num_points, ukeys, uperm, counts);
         INSMOS_LAUNCH(k_vox_pcid, dim3(g), dim3(TPB), 0, s, k_s, sid_scan, n, uperm, pc_voxel_id);
     }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_voxelize_mean_windows(const float* points, int64_t n, int ld_pts, int n_feat, const int32_t* win_start,
+                                            int B, int64_t key_cells, const float* range_host, const float* vsize_host, int max_voxels,
+                                            int max_pts, float* feat, int ld_feat, int32_t* coords, int32_t* num_points,
+                                            int64_t* pc_voxel_id, uint64_t* ukeys, int32_t* uperm, int32_t* counts, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    return insmos_voxelize_windows_phased(points, n, ld_pts, n_feat, win_start, B, key_cells, range_host, vsize_host, max_voxels, max_pts,
+                                          feat, ld_feat, coords, num_points, pc_voxel_id, ukeys, uperm, counts, ws, ws_bytes, 0, stream);
 }
 
 // one window (the reference's single VoxelGenerate call): counts = 4 int32 slots ([0] voxels, [1] cells, [2] points)

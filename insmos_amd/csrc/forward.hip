@@ -69,6 +69,48 @@ int64_t g_table_limit = 1ll << 31;  // bytes a neighbour table may span (32-bit 
         if (!A.ok) { out->arena_needed = (int64_t)A.off; return INSMOS_EWORKSPACE; } \
     } while (0)
 
+// A second stream per HOST THREAD (the launch-set workers of InsMOS_Model are persistent threads) for the work that does not sit
+// on the convolution chain: the 3D branch's coordinate sets and kernel maps depend on the points' positions only, so they are
+// built on this stream WHILE MotionNet's convolutions run on the caller's; the level-0 81-tap table and the later one-hot
+// passes go there too.  Cross-stream order is explicit (events); INSMOS_TWO_STREAMS=0 puts everything back on one stream.
+struct Aux {
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    int init() {
+        if (!s2) HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        used = 0;
+        return INSMOS_OK;
+    }
+    int next(hipEvent_t* e) {
+        if (used == ev.size()) {
+            hipEvent_t n;
+            HIP_TRY(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+            ev.push_back(n);
+        }
+        *e = ev[used++];
+        return INSMOS_OK;
+    }
+};
+thread_local Aux tl_aux;
+thread_local int tl_stream_mask = -1;   // per-host-thread override of INSMOS_TWO_STREAMS (insmos_forward_streams); -1 = none
+
+// `to` waits for everything enqueued on `from` so far
+int link_streams(hipStream_t from, hipStream_t to) {
+    if (from == to) return INSMOS_OK;
+    hipEvent_t e;
+    int rc = tl_aux.next(&e);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e, from));
+    HIP_TRY(hipStreamWaitEvent(to, e, 0));
+    return INSMOS_OK;
+}
+// whatever path the function leaves by, the caller's stream ends up behind the second one (the arena is the caller's to reuse)
+struct JoinGuard {
+    hipStream_t s, s2;
+    ~JoinGuard() { (void)link_streams(s2, s); }
+};
+
 int read_counts(const int32_t* dev, int32_t* host, int n, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(host, dev, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -122,6 +164,18 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     const Ctx& C = *(const Ctx*)ctx;
     const InsmosNetCfg& g = C.cfg;
     hipStream_t s = (hipStream_t)stream;
+    // INSMOS_TWO_STREAMS: bit 0 = level-0 table, bit 1 = the 3D coordinate phase, bit 2 = inv_conv_out, bit 3 = the finer one-hot
+    // passes on the second stream (default 15 = all; 0 = everything on the caller's stream)
+    static const int ts_env = [] { const char* e = getenv("INSMOS_TWO_STREAMS"); return e ? atoi(e) : -1; }();
+    const int ts_mask = ts_env >= 0 ? ts_env : tl_stream_mask >= 0 ? tl_stream_mask : 15;
+    hipStream_t s2 = s;
+    if (ts_mask) {
+        CK(tl_aux.init());
+        s2 = tl_aux.s2;
+    }
+    JoinGuard join_guard{s, s2};
+    const hipStream_t s2_tab0 = (ts_mask & 1) ? s2 : s, s2_coords = (ts_mask & 2) ? s2 : s, s2_inv = (ts_mask & 4) ? s2 : s,
+                      s2_oh = (ts_mask & 8) ? s2 : s;
     memset(outs, 0, sizeof(*outs) * (size_t)B);
     InsmosForwardOut* out = outs;  // batch-wide figures and error details go to the first entry
     for (int b = 0; b < B; ++b) outs[b].batch = B;
@@ -133,14 +187,14 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // out[:, col_out : col_out + cout] = epilogue(conv(x[:, col_in : col_in + cin]))  (Engine.conv)
     auto conv = [&](const char* name, const float* x, int64_t n_in, int ld_in, int col_in, const Table* t, int64_t n_out,
                     float* o, int ld_out, int col_out, const float* res, int ld_res, int col_res, int res_mode,
-                    int relu_pre, int relu_post, int64_t row0 = 0) -> int {
+                    int relu_pre, int relu_post, int64_t row0 = 0, hipStream_t cs = nullptr) -> int {
         const InsmosConvW* w = Lr(name);
         if (!w) return INSMOS_EINVAL;
         if (n_out == 0) return INSMOS_OK;
         if (t && (t->K != w->K || t->n != n_out)) return INSMOS_EINVAL;
         return insmos_sparse_conv_rows(x + col_in, n_in, ld_in, w->cin, t ? t->nbr : nullptr, t ? t->mask : nullptr, w->K,
                                        n_out, row0, w->w, w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr,
-                                       ld_res, res_mode, relu_pre, relu_post, s);
+                                       ld_res, res_mode, relu_pre, relu_post, cs ? cs : s);
     };
     auto table = [&](int K, int64_t n) {
         Table t;
@@ -245,9 +299,16 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     for (int l = 2; l >= 0; --l) {
         nbr81[l] = table(81, n[l]);
         NEED_ARENA();
-        // (the level-0 table is read by block8 only: rows of the last two scans)
+        // (the level-0 table is read by block8 only -- rows of the last two scans, at the very end of the branch: it is built on
+        //  the second stream, off the convolution chain)
+        if (l == 0) CK(link_streams(s, s2_tab0));
         CK(insmos_nbr81_from_coarse_rows(coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1],
-                                         cstart[l], cmask[l], nbr81[l].nbr, nbr81[l].mask, s));
+                                         cstart[l], cmask[l], nbr81[l].nbr, nbr81[l].mask, l == 0 ? s2_tab0 : s));
+    }
+    hipEvent_t ev_tab0 = nullptr;
+    if (s2_tab0 != s) {
+        CK(tl_aux.next(&ev_tab0));
+        HIP_TRY(hipEventRecord(ev_tab0, s2_tab0));
     }
     Table dn[3], up[3];
     for (int l = 0; l < 3; ++l) {
@@ -303,9 +364,15 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     CK(conv("convtr6p4s2", b6, n[2], 32, 0, &up[1], n[1], cat7, 32, 0, nullptr, 0, 0, 0, 0, 1, row_from(1, 4)));
     CK(block("block7.0", cat7, n[1], 32, 0, &nbr81[1], 16, b7, 16, 0, 1, 2));
     CK(conv("convtr7p2s2", b7, n[1], 16, 0, &up[0], n[0], cat8, 16, 0, nullptr, 0, 0, 0, 0, 1, row_from(0, 2)));
+    if (ev_tab0) HIP_TRY(hipStreamWaitEvent(s, ev_tab0, 0));
     CK(block("block8.0", cat8, n[0], 16, 0, &nbr81[0], 8, b8, 8, 0, 0, 0));
     CK(conv("final", b8, n[0], 8, 0, nullptr, n[0], motion, 4, 0, nullptr, 0, 0, 0, 0, 0, row_from(0, 0)));
-    CK(insmos_build_current_points_windows(pts_host, n_pts_host, B, ld, motion, 4, inverse, cur_index, ncur, cur, 8, s));
+    // MotionNet is now ENQUEUED on the caller's stream (no host synchronisation above this line since the level counts).  The 3D
+    // branch's coordinate work -- voxel cells, strided coordinate sets, 13 kernel maps: sorts, scans and table kernels with five
+    // count read-backs -- needs the current points' POSITIONS only, so it runs on the second stream while those convolutions
+    // execute; the motion columns and the MeanVFE feature means follow on the caller's stream once both are done.
+    hipStream_t sm = s;   // the stream the rest of the function calls `s`: swapped for the 3D coordinate phase below
+    CK(insmos_build_current_points_part(pts_host, n_pts_host, B, ld, nullptr, 0, inverse, cur_index, ncur, cur, 8, 1, s2_coords));
 
     // =============================== UNetV2 (3D) ===============================
     const int ncls = g.ncls;
@@ -316,17 +383,14 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     int64_t* pcid = A.take<int64_t>(ncur);
     uint64_t* ukeys = A.take<uint64_t>(ncur);
     int32_t* uperm = A.take<int32_t>(ncur);
-    {
-        const size_t wsb = insmos_voxelize_mean_ws_bytes(ncur);
-        const size_t mark = A.off;
-        void* ws = A.take<char>(wsb);
-        NEED_ARENA();
-        CK(insmos_voxelize_mean_windows(cur, ncur, 8, g.in_ch, cur_start_dev, B,
-                                        (int64_t)g.shape[1][0] * g.shape[1][1] * g.shape[1][2], g.range, g.vs, g.max_voxels, g.max_points, feat,
-                                        8, coords1, num_points, pcid, ukeys, uperm, counts, ws, wsb, s));
-        CK(read_counts(counts, hc, 5 + B, s));
-        A.off = mark;
-    }
+    const size_t vox_wsb = insmos_voxelize_mean_ws_bytes(ncur);
+    void* vox_ws = A.take<char>(vox_wsb);   // (kept: phase 2 reads the sorted cell keys and segment starts phase 1 leaves here)
+    NEED_ARENA();
+    const int64_t key_cells1 = (int64_t)g.shape[1][0] * g.shape[1][1] * g.shape[1][2];
+    s = s2_coords;   // ---- from here to the join below every launch and read-back goes to the second stream
+    CK(insmos_voxelize_windows_phased(cur, ncur, 8, g.in_ch, cur_start_dev, B, key_cells1, g.range, g.vs, g.max_voxels, g.max_points,
+                                      feat, 8, coords1, num_points, pcid, ukeys, uperm, counts, vox_ws, vox_wsb, 1, s));
+    CK(read_counts(counts, hc, 5 + B, s));
     for (int b = 0; b < B; ++b) outs[b].unet_voxels[0] = hc[4 + b + 1] - hc[4 + b];
     int64_t nv[6] = {0}, nkeys[6] = {0};
     const int32_t* co[6] = {nullptr};
@@ -414,6 +478,12 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     for (int l = 2; l <= 4; ++l) CK(build(inv[l], l - 1, l, C.d_inv, one4, two3));
     CK(build(down5, 5, 4, C.d_down5, two1, one4));
     CK(build(inv5, 4, 5, C.d_inv5, one4, two1));
+    // ---- join: the caller's stream (MotionNet done) fills in the motion columns, waits for the coordinate phase, and averages
+    s = sm;
+    CK(insmos_build_current_points_part(pts_host, n_pts_host, B, ld, motion, 4, inverse, cur_index, ncur, cur, 8, 2, s));
+    CK(link_streams(s2_coords, s));
+    CK(insmos_voxelize_windows_phased(cur, ncur, 8, g.in_ch, cur_start_dev, B, key_cells1, g.range, g.vs, g.max_voxels, g.max_points,
+                                      feat, 8, coords1, num_points, pcid, ukeys, uperm, counts, vox_ws, vox_wsb, 2, s));
 
     // ---- encoder (spconv_unet.py:297-306)
     float* x0 = A.take<float>(V * 16);
@@ -439,6 +509,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     float* enc = A.take<float>(std::max<int64_t>(nv[5], 1) * 128);
     NEED_ARENA();
     CK(conv("conv_out.0", xc[4], nv[4], 128, 0, &down5, nv[5], enc, 128, 0, nullptr, 0, 0, 0, 0, 1));
+    CK(link_streams(s, s2_inv));   // (inv_conv_out reads `enc` only: it runs on the second stream beside the BEV head, see below)
 
     // ---- BEV detection head in NHWC (height_compression.py:24-31, base_bev_backbone.py:84-115)
     const int64_t nsite = (int64_t)g.bevH * g.bevW * B;  // B images stacked along the row axis
@@ -504,7 +575,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         NEED_ARENA();
         CK(insmos_center_decode_select_b(head, g.head_ld, ncls, 2 * g.bevH, 2 * g.bevW, 2, B, g.out_factor, g.tvs[0], g.tvs[1],
                                          g.range[0], g.range[1], g.score_thresh, g.pre_max, cb, cs, cl, cc, cnt_c, ws, wsb, s));
-        A.off = mark;
+        // (no rewind of the decode scratch: what is allocated below is written on the SECOND stream -- inv_conv_out into ci4 --
+        //  while the decode kernels may still be running on this one; a region is only handed on inside one stream's order)
+        (void)mark;
         const size_t wsn = insmos_nms_ws_bytes_b(g.pre_max, B);
         ws = A.take<char>(wsn);
         NEED_ARENA();
@@ -549,20 +622,46 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     float* vox_logits = A.take<float>(V * 4);
     float* logits = A.take<float>(ncur * 3);
     NEED_ARENA();
-    CK(conv("inv_conv_out", enc, nv[5], 128, 0, &inv5, nv[4], ci4, 144, 0, nullptr, 0, 0, 0, 0, 0));
+    CK(conv("inv_conv_out", enc, nv[5], 128, 0, &inv5, nv[4], ci4, 144, 0, nullptr, 0, 0, 0, 0, 0, 0, s2_inv));
+    hipEvent_t ev_inv = nullptr;
+    if (s2_inv != s) {
+        CK(tl_aux.next(&ev_inv));
+        HIP_TRY(hipEventRecord(ev_inv, s2_inv));
+    }
     CK(onehot(4, 1.0f, ci4, 144, 128));
+    // the finer levels' one-hot columns are not needed before their decoder level: second stream (behind onehot(4): the passes
+    // share one scratch array), each consumer waits for its own
+    hipEvent_t ev_oh[4] = {nullptr, nullptr, nullptr, nullptr};
+    CK(link_streams(s, s2_oh));
+    {
+        s = s2_oh;
+        const float mult[4] = {0.f, 8.0f, 4.0f, 2.0f};
+        float* const dst[4] = {nullptr, ci1, ci2, ci3};
+        const int ldo[4] = {0, 32, 48, 80}, col[4] = {0, 16, 32, 64};
+        int rc = INSMOS_OK;
+        for (int l = 3; l >= 1 && rc == INSMOS_OK; --l) {
+            rc = onehot(l, mult[l], dst[l], ldo[l], col[l]);
+            if (rc == INSMOS_OK && s2_oh != sm) {
+                rc = tl_aux.next(&ev_oh[l]);
+                if (rc == INSMOS_OK && hipEventRecord(ev_oh[l], s2_oh) != hipSuccess) rc = INSMOS_EHIP;
+            }
+        }
+        s = sm;
+        CK(rc);
+    }
+    if (ev_inv) HIP_TRY(hipStreamWaitEvent(s, ev_inv, 0));
     CK(conv("conv_up_instance_block.0", ci4, nv[4], 144, 0, &subm[4], nv[4], catm4, 256, 0, nullptr, 0, 0, 0, 0, 1));
     CK(ur_block(4, 128, catm4, 256, catm4, m4));
     CK(conv("inv_conv4.0", m4, nv[4], 128, 0, &inv[4], nv[3], ci3, 80, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(onehot(3, 2.0f, ci3, 80, 64));
+    if (ev_oh[3]) HIP_TRY(hipStreamWaitEvent(s, ev_oh[3], 0));
     CK(conv("conv_up_instance_block_up4.0", ci3, nv[3], 80, 0, &subm[3], nv[3], catm3, 128, 0, nullptr, 0, 0, 0, 0, 1));
     CK(ur_block(3, 64, xc[3], 64, catm3, m3));
     CK(conv("inv_conv3.0", m3, nv[3], 64, 0, &inv[3], nv[2], ci2, 48, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(onehot(2, 4.0f, ci2, 48, 32));
+    if (ev_oh[2]) HIP_TRY(hipStreamWaitEvent(s, ev_oh[2], 0));
     CK(conv("conv_up_instance_block_up3.0", ci2, nv[2], 48, 0, &subm[2], nv[2], catm2, 64, 0, nullptr, 0, 0, 0, 0, 1));
     CK(ur_block(2, 32, xc[2], 32, catm2, m2));
     CK(conv("inv_conv2.0", m2, nv[2], 32, 0, &inv[2], V, ci1, 32, 0, nullptr, 0, 0, 0, 0, 1));
-    CK(onehot(1, 8.0f, ci1, 32, 16));
+    if (ev_oh[1]) HIP_TRY(hipStreamWaitEvent(s, ev_oh[1], 0));
     CK(conv("conv_up_instance_block_up2.0", ci1, V, 32, 0, &subm[1], V, catm1, 32, 0, nullptr, 0, 0, 0, 0, 1));
     CK(ur_block(1, 16, xc[1], 16, catm1, m1));
     CK(conv("conv_up_out.0.0", m1, V, 16, 0, &subm[1], V, ci0, 32, 0, nullptr, 0, 0, 0, 0, 1));
@@ -602,6 +701,14 @@ extern "C" int insmos_forward_windows(void* ctx, const float* const* points_host
 extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int ld, void* arena, size_t arena_bytes,
                                      void* stream, InsmosForwardOut* out) {
     return forward_windows_impl(ctx, &pts, &N, 1, ld, arena, arena_bytes, stream, out);
+}
+
+// Which pieces of the calling host thread's next forwards go to its second stream (bits as INSMOS_TWO_STREAMS, which wins when
+// set; -1 = default 15).  A caller that keeps several launch sets in flight turns it off: the sets overlap each other already.
+extern "C" int insmos_forward_streams(int mask) {
+    if (mask < -1 || mask > 15) return INSMOS_EINVAL;
+    tl_stream_mask = mask;
+    return INSMOS_OK;
 }
 
 extern "C" int insmos_debug_table_limit(int64_t bytes) {

@@ -281,14 +281,23 @@ __global__ void __launch_bounds__(64) k_nms_reduce(const uint64_t* __restrict__ 
             const int i_n = i_l + 64;
             diag_next = (i_n < n) ? mask[(int64_t)i_n * cbs + blk + 1] : 0ull;
         }
-        uint64_t rb = __shfl(remv, blk);  // this block's removed word, wave-uniform
+        // this block's removed word, wave-uniform (scalar registers: v_readlane with a uniform lane index, not an LDS permute)
+        const uint32_t ub = __builtin_amdgcn_readfirstlane((uint32_t)blk);
+        uint64_t rb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(remv >> 32), ub) << 32) |
+                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)remv, ub);
         uint64_t kept = 0;
         const int lim = min(64, n - blk * 64);
-        for (int i = 0; i < lim; ++i) {
-            if (!((rb >> i) & 1ull)) {
-                kept |= 1ull << i;
-                rb |= __shfl(diag, i);
-            }
+        const uint64_t in_range = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+        // walk the SURVIVORS only (the next clear bit of the removed word), not all 64 candidates: a scalar chain of
+        // ctz -> readlane -> or per kept box
+        uint64_t avail = ~rb & in_range;
+        while (avail) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(avail);
+            kept |= 1ull << i;
+            const uint32_t ui = __builtin_amdgcn_readfirstlane(i);
+            rb |= ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(diag >> 32), ui) << 32) |
+                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, ui);
+            avail = ~rb & in_range & ~((2ull << i) - 1ull);
         }
         // emit kept indices in ascending order
         if ((kept >> lane) & 1ull) {

@@ -29,19 +29,26 @@ __global__ void k_current_points(const float* __restrict__ pts, int ld_pts, cons
 }
 
 // the same for the B windows of a batch: cur_index holds batch-wide (window-major) point indices
+// PART 0: the whole row; 1: the point's own columns [x, y, z, r] (and zeros behind them) -- known before MotionNet has run;
+// 2: the motion columns only
+template <int PART>
 __global__ void k_current_points_w(WinPts W, int ld_pts, const float* __restrict__ motion, int ld_motion,
                                    const int32_t* __restrict__ inverse, const int32_t* __restrict__ cur_index,
                                    int64_t n_cur, float* __restrict__ cur, int ld_cur) {
     int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_cur) return;
     int p = cur_index[j];
-    int b;
-    const float* pp = win_point(W, (int64_t)p, ld_pts, b);
-    const float* mm = motion + (int64_t)inverse[p] * ld_motion;
     float* o = cur + j * ld_cur;
-    o[0] = pp[0]; o[1] = pp[1]; o[2] = pp[2]; o[3] = pp[3];
-    o[4] = mm[0]; o[5] = mm[1]; o[6] = mm[2];
-    for (int c = 7; c < ld_cur; ++c) o[c] = 0.f;
+    if (PART != 2) {
+        int b;
+        const float* pp = win_point(W, (int64_t)p, ld_pts, b);
+        o[0] = pp[0]; o[1] = pp[1]; o[2] = pp[2]; o[3] = pp[3];
+        for (int c = PART == 1 ? 4 : 7; c < ld_cur; ++c) o[c] = 0.f;
+    }
+    if (PART != 1) {
+        const float* mm = motion + (int64_t)inverse[p] * ld_motion;
+        o[4] = mm[0]; o[5] = mm[1]; o[6] = mm[2];
+    }
 }
 
 __global__ void k_fill_cols(float* __restrict__ dst, int64_t n, int ld, int c0, int c, float v) {
@@ -151,22 +158,35 @@ extern "C" int insmos_build_current_points(const float* points, int ld_pts, cons
     return INSMOS_OK;
 }
 
-extern "C" int insmos_build_current_points_windows(const float* const* pts_host, const int64_t* n_pts_host, int B, int ld_pts,
-                                                   const float* motion, int ld_motion, const int32_t* inverse,
-                                                   const int32_t* cur_index, int64_t n_cur, float* cur, int ld_cur,
-                                                   void* stream) {
+// part 0: whole rows; part 1: [x, y, z, r, 0, ...] (motion may be NULL) -- all the voxeliser's coordinate phase reads; part 2: the
+// motion columns 4..6 into rows part 1 wrote.  part 1 + part 2 == part 0.
+extern "C" int insmos_build_current_points_part(const float* const* pts_host, const int64_t* n_pts_host, int B, int ld_pts,
+                                                const float* motion, int ld_motion, const int32_t* inverse,
+                                                const int32_t* cur_index, int64_t n_cur, float* cur, int ld_cur, int part,
+                                                void* stream) {
     if (n_cur <= 0) return INSMOS_OK;
     WinPts W;
     int64_t n = 0;
     int rc = make_win_pts(pts_host, n_pts_host, B, &W, &n);
     if (rc) return rc;
-    if (!motion || !inverse || !cur_index || !cur || ld_cur < 7 || ld_pts < 5 || ld_motion < 3) return INSMOS_EINVAL;
+    if (part < 0 || part > 2 || (part != 1 && (!motion || !inverse || ld_motion < 3)) || !cur_index || !cur || ld_cur < 7 || ld_pts < 5)
+        return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_CUR_POINTS, s);
-    INSMOS_LAUNCH(k_current_points_w, dim3(cdiv(n_cur, 256)), dim3(256), 0, s, W, ld_pts, motion, ld_motion, inverse, cur_index,
-                  n_cur, cur, ld_cur);
+    const dim3 grid(cdiv(n_cur, 256)), block(256);
+    if (part == 0) INSMOS_LAUNCH(k_current_points_w<0>, grid, block, 0, s, W, ld_pts, motion, ld_motion, inverse, cur_index, n_cur, cur, ld_cur);
+    else if (part == 1) INSMOS_LAUNCH(k_current_points_w<1>, grid, block, 0, s, W, ld_pts, motion, ld_motion, inverse, cur_index, n_cur, cur, ld_cur);
+    else INSMOS_LAUNCH(k_current_points_w<2>, grid, block, 0, s, W, ld_pts, motion, ld_motion, inverse, cur_index, n_cur, cur, ld_cur);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_build_current_points_windows(const float* const* pts_host, const int64_t* n_pts_host, int B, int ld_pts,
+                                                   const float* motion, int ld_motion, const int32_t* inverse,
+                                                   const int32_t* cur_index, int64_t n_cur, float* cur, int ld_cur,
+                                                   void* stream) {
+    return insmos_build_current_points_part(pts_host, n_pts_host, B, ld_pts, motion, ld_motion, inverse, cur_index, n_cur, cur, ld_cur, 0,
+                                            stream);
 }
 
 extern "C" int insmos_fill_cols(float* dst, int64_t n, int ld, int c0, int c, float value, void* stream) {
