@@ -331,6 +331,10 @@ int insmos_debug_conv_force(int cot, int jt, int ring);
 /* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
  * both produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_quad(int on);
+/* test / tuning hook: the 81-tap single-chunk layers (Cin 8 / 16, contiguous rows, masked table) on the LDS-staged kernel (1;
+ * csrc/spconv_lds.hip; also INSMOS_CONV_LDS=1) or on the generic kernels (0, the default: the staged kernel is bit-identical but
+ * slower in its first form); same bits as the unsplit generic kernels (tests/test_gpu_conv.py). */
+int insmos_debug_conv_lds(int on);
 /* test / tuning hook: the d/dW kernel of insmos_sparse_conv_backward_weight -- 2 = row-compacting MFMA kernel (default),
  * 1 = first MFMA design (also INSMOS_DW_MFMA=1), 0 = LDS slabs.  All three are deterministic; they differ in summation order.
  * insmos_sparse_conv_backward_weight_ws_floats follows the mode: size the workspace after switching. */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
+    "insmos_debug_conv_lds": (c_int, [c_int]),
     "insmos_debug_dw_kernel": (c_int, [c_int]),
     "insmos_conv_precision": (c_int, [c_int]),
     "insmos_conv_precision_thread": (c_int, [c_int]),

@@ -1,0 +1,35 @@
+// insmos_amd/csrc/conv_common.h -- what the convolution kernels of libinsmos_hip.so share: the launch parameter block and the
+// fragment types (spconv.hip: generic / split / quad-index kernels; spconv_lds.hip: the LDS-staged 81-tap kernel).
+#pragma once
+#include "common.h"
+
+namespace insmos {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct ConvP {
+    const float* in;
+    const int32_t* nbr;
+    const uint32_t* mask16;  // [ceil(n_out/16)][4] active-tap bits per 16-row group, or null (all active)
+    const float* w;
+    const float* bias;
+    float* out;
+    const float* res;
+    uint32_t n_out;
+    uint32_t row0;  // first output row computed (multiple of 16): rows [row0, n_out) -- insmos_sparse_conv_rows
+    uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
+    int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
+    int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
+    int tap_mod;  // tap-split tiles: 1 = wave ws owns the taps k with k % SPLIT == ws (a row's sum does not depend on which
+                  // rows share its tile), 0 = every SPLIT-th ACTIVE tap of the tile (evenest load, tile-dependent order)
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// spconv_lds.hip: the LDS-staged kernel for the 81-tap single-chunk layers; false = not applicable (the caller goes on with the
+// generic kernels), true = launched (rc holds the status)
+bool conv_lds_ok(const ConvP& P, int ck, int cot);   // applicable (and not switched off)?
+bool conv_lds_try(const ConvP& P, int ck, int cot, long n_rows, hipStream_t s, int* rc);
+
+}  // namespace insmos

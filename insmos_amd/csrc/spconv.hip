@@ -23,32 +23,10 @@
 #include <mutex>
 #include <unordered_map>
 #include "common.h"
+#include "conv_common.h"
 #include "prec.h"
 
 namespace insmos {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct ConvP {
-    const float* in;
-    const int32_t* nbr;
-    const uint32_t* mask16;  // [ceil(n_out/16)][4] active-tap bits per 16-row group, or null (all active)
-    const float* w;
-    const float* bias;
-    float* out;
-    const float* res;
-    uint32_t n_out;
-    uint32_t row0;  // first output row computed (multiple of 16): rows [row0, n_out) -- insmos_sparse_conv_rows
-    uint32_t in_bytes;  // extent of the `in` view: (n_in - 1) * ld_in * 4 + cin * 4
-    int ld_in, cin, K, ld_out, cout, ld_res, res_mode, relu_pre, relu_post;
-    int n16, has8, has4, nblk, ntile_co, n_otiles, vec_store;
-    int tap_mod;  // tap-split tiles: 1 = wave ws owns the taps k with k % SPLIT == ws (a row's sum does not depend on which
-                  // rows share its tile), 0 = every SPLIT-th ACTIVE tap of the tile (evenest load, tile-dependent order)
-};
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
 
 // next active tap of the 128-bit set, or `keep` when the set is exhausted (branch-free scalar code)
 __device__ __forceinline__ int pop_or_keep(uint64_t& lo, uint64_t& hi, int keep) {
@@ -883,6 +861,13 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
                       : 0;
     const int ck = (cin == 4 || cin == 8) ? cin : 0;
     if (!ck && (cin % 16 != 0)) return INSMOS_EINVAL;  // supported widths: 4, 8, or a multiple of 16
+    // the 81-tap single-chunk layers (MotionNet's BasicBlocks with Cin 8 / 16): LDS-staged gathers (spconv_lds.hip)
+    if (!g_force_cot && !g_dbg && conv_lds_ok(P, ck, P.ntile_co)) {
+        int rc_lds = INSMOS_OK;
+        ProfScope ps(KK_SPARSE_CONV, s);
+        ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
+        if (conv_lds_try(P, ck, P.ntile_co, (long)n_rows, s, &rc_lds)) return rc_lds;
+    }
     // tile shape, from tools/conv_tune.py sweeps on MI355X: a 16-row gather is ~8x the cost of a coalesced
     // weight fragment, so generic layers always use 16-row tiles (JT = 1) and widen in channels instead:
     // 2 channel tiles per wave, 4 when the layer is large enough to still give >= 2 waves per SIMD.

@@ -432,3 +432,75 @@ def test_fused_deconv_head_is_bitwise_the_two_launches(n_site):
                                         lh.b.data_ptr(), hc, head.data_ptr(), hc, stream()), "insmos_deconv_head")
     torch.cuda.synchronize()
     assert torch.equal(head, ref)
+
+
+@pytest.mark.parametrize("cin,cout,res_mode", [(8, 8, 0), (8, 8, 1), (8, 16, 0), (16, 16, 1), (16, 32, 0), (16, 8, 2)])
+def test_lds_staged_81_tap_kernel_is_bitwise_the_generic_one(cin, cout, res_mode):
+    """The 81-tap single-chunk layers run on k_conv_lds (csrc/spconv_lds.hip: a window of input rows + an overflow area staged
+    in LDS per 64-row block and time offset, B fragments read from LDS).  Same bits as the unsplit generic kernels, on tables
+    built to visit every mode of the kernel: blocks whose neighbours all fall in the window, blocks with a few far neighbours
+    (overflow area), blocks with more far neighbours than the overflow area holds (gathers from memory), empty time offsets,
+    a missing centre tap, a row suffix (dead-row elimination) and a ragged last block; against the oracle too."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(1000 + cin * 10 + cout + res_mode)
+    K, n_out, n_in = 81, 64 * 37 + 23, 9000
+    nbr = np.full((K, n_out), -1, np.int32)
+    blocks = (n_out + 63) // 64
+    for b in range(blocks):
+        r = np.arange(b * 64, min(n_out, b * 64 + 64))
+        kind = b % 6
+        for dg in range(3):
+            if kind == 5 and dg == 1:
+                continue                                              # an empty time offset
+            base = int(rng.integers(300, n_in - 600))                # where this block's neighbours sit at this time offset
+            for k in range(27):
+                kt = dg * 27 + k
+                if rng.uniform() < 0.35:
+                    continue                                          # tap unused by the whole block
+                if kind == 4 and k == 13:
+                    continue                                          # no centre tap: the window centres on the smallest index
+                present = rng.uniform(size=len(r)) < 0.45
+                near = base + (r - r[0]) + rng.integers(-90, 90, size=len(r))
+                far = rng.integers(0, n_in, size=len(r))
+                p_far = {0: 0.0, 1: 0.05, 2: 0.6, 3: 0.12, 4: 0.03, 5: 0.1}[kind]
+                v = np.where(rng.uniform(size=len(r)) < p_far, far, near)
+                nbr[kt, r] = np.where(present, np.clip(v, 0, n_in - 1), -1)
+    nbr[:, 64 * 3:64 * 3 + 16] = -1                                    # a 16-row tile without any tap inside an active block
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.15)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    xd, nd, md = dev(x), dev(nbr), dev(tap_masks(nbr).view(np.int32))
+    ntile = (cout + 15) // 16
+
+    def run(lds, row0=0):
+        lib().insmos_debug_conv_lds(lds)
+        if not lds and cin == 16:
+            lib().insmos_debug_conv_force(ntile, 1, 3)                # the unsplit generic kernel (a tap-split tile sums in another order)
+        try:
+            out = torch.full((n_out, cout), -7.0, device="cuda:0")
+            _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr(), K, n_out, row0,
+                                                     layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout,
+                                                     res.data_ptr() if res is not None else None, ld_res if res_mode else 0, res_mode,
+                                                     1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib().insmos_debug_conv_lds(0)                              # (the default: off, DESIGN.md 3.1b)
+            lib().insmos_debug_conv_force(0, 0, 0)
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    a, b = run(1), run(0)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    assert torch.equal(a, b), float((a - b).abs().max())
+    assert torch.equal(run(1), a)                                       # deterministic
+    for r0 in (16, 64 * 5 + 32, 64 * 30):
+        assert torch.equal(run(1, r0)[r0:], b[r0:])                     # a row suffix: other block boundaries, the same rows' bits
