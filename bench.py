@@ -174,11 +174,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-az", type=int, default=1886, help="azimuth steps of the synthetic scan (1886 = S0, 120k pts)")
+    ap.add_argument("--config", type=str, default="cfg2", choices=["cfg2", "cfg4"],
+                    help="cfg2 (default, the headline): BASELINE.json configs[1], S0 windows, voxel 0.1 m.  cfg4: configs[3], the dense "
+                         "stress scene -- 300k pts/scan (n_az 4710), voxel 0.05 m, BEV 250 x 300 x 640, the 100 000-voxel cap hit "
+                         "(models/models.py:287); launch sets of 2 (a set's level-0 table must stay below 2 GiB), 4 windows per step")
+    ap.add_argument("--n-az", type=int, default=None, help="azimuth steps of the synthetic scan (default: 1886 = S0, 120k pts; cfg4: 4710)")
     ap.add_argument("--candidates", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-az", type=int, default=1886,
-                    help="azimuth steps of the CPU-baseline window (1886 = the bench window itself: ~20-30 s of oracle time)")
+    ap.add_argument("--cpu-sample-az", type=int, default=None,
+                    help="azimuth steps of the CPU-baseline window (default 1886 = the bench window itself: ~10-30 s of oracle time; "
+                         "cfg4: 1178 = a quarter of the azimuth steps, the full window takes the oracle minutes)")
     ap.add_argument("--calibration", type=str, default="/tmp/insmos_bench_calibration.json",
                     help="where the head-bias calibration of this workload is cached (so that a profiled run can skip it)")
     ap.add_argument("--timed-only", action="store_true",
@@ -186,7 +191,7 @@ def main():
                          "warm-up and the timed steps and nothing else -- every kernel launch in the trace belongs to a step")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
-    ap.add_argument("--windows-per-step", type=int, default=24, help="batch items of one forward() = one step")
+    ap.add_argument("--windows-per-step", type=int, default=None, help="batch items of one forward() = one step (default 24; cfg4: 4)")
     ap.add_argument("--conv-precision", type=int, default=0, choices=[0, 3],
                     help="EXPERIMENT ONLY (the line is then labelled as such and is not the benchmark): 3 = split-bf16 x 3 "
                          "convolutions (include/insmos_hip.h: insmos_conv_precision); 0 = exact fp32, the product path")
@@ -195,6 +200,17 @@ def main():
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; the dry run puts "
                                                                     "every rank on GPU 0)")
     args = ap.parse_args()
+    cfg4 = args.config == "cfg4"
+    if args.n_az is None:
+        args.n_az = 4710 if cfg4 else 1886
+    if args.cpu_sample_az is None:
+        args.cpu_sample_az = 1178 if cfg4 else 1886
+    if args.windows_per_step is None:
+        args.windows_per_step = 4 if cfg4 else 24
+    if cfg4:
+        os.environ.setdefault("INSMOS_WINDOWS_PER_LAUNCH", "2")
+        os.environ.setdefault("INSMOS_WINDOWS_IN_FLIGHT", "2")
+        args.calibration = args.calibration + ".cfg4"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +237,13 @@ def main():
     from insmos_amd.synth import make_labels
 
     cfg = P.default_cfg()
-    sd = P.random_state_dict(cfg, seed=0)
+    if cfg4:
+        import copy
+        cfg = copy.deepcopy(cfg)
+        cfg["DATA"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+        cfg["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"] = 640
+        cfg["MODEL"]["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
+    sd = P.random_state_dict(cfg, seed=4 if cfg4 else 0)
     # one step = one forward() over a batch of `windows_per_step` DIFFERENT windows (seeds rank*W .. rank*W+W-1);
     # InsMOS_Model keeps up to INSMOS_WINDOWS_IN_FLIGHT of them in flight (threads + streams, same device weights)
     W = max(1, args.windows_per_step)
@@ -279,8 +301,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not args.conv_precision else "EXPERIMENT split-bf16x3 (NOT the product path, NOT a benchmark line)",
         "data": "synthetic",
-        "config": {"workload": "cfg-2: synthetic S0 windows, N=10 scans, voxel 0.1 m, full InsMOS forward "
-                               "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)",
+        "config": {"workload": ("cfg-4 (BASELINE.json configs[3], NOT the headline): dense stress scene, 300k pts/scan, N=10 scans, voxel "
+                                "0.05 m, the 100 000-voxel cap hit, BEV 250 x 300 x 640, full InsMOS forward" if cfg4 else
+                                "cfg-2: synthetic S0 windows, N=10 scans, voxel 0.1 m, full InsMOS forward "
+                                "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)"),
                    "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
                    "n_az": args.n_az, "points_per_window": int(len(window)), "current_points": ncur,
                    "host_cores_per_rank": host_cores, "torch_threads": torch.get_num_threads(),

@@ -499,6 +499,22 @@ int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* out, int acc
  * minkunet.py under model.train()): batch mean / biased variance per channel, y = relu?(xhat * gamma + beta);
  * stats = [mean | invstd | biased var] (3c floats); xhat (n, c) is kept for the backward, which returns dx, dgamma,
  * dbeta (through the ReLU when relu != 0).  Running-statistics updates stay with the caller (two axpys). */
+/* Segmented, fused BatchNorm in training mode (round 3: B windows per training step with the reference's per-item statistics --
+ * models/models.py:313 walks the batch item by item, so a BatchNorm layer sees one window's rows at a time).  chunks: n_chunks x 4
+ * int32 (row_start, row_end, segment, 0), <= 1024 rows of ONE segment each, sorted by segment; seg_first (S + 1): chunk ranges;
+ * seg_rows (S): rows per segment; stats: S x 3c ([mean | invstd | biased var] per segment).  All device arrays.  S = 1 is the plain
+ * layer.  ticket: one zero int32 on the device (the statistics kernels fold their partials in the block that finishes last; it is
+ * left zero).  Forward = 2 launches: statistics (+ merge + running statistics, item after item), apply; backward = 2: both sums
+ * (+ merge), dx. */
+size_t insmos_batchnorm_seg_ws_floats(int n_chunks, int c, int S);
+int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int64_t n, const int32_t* chunks, int n_chunks,
+                                 const int32_t* seg_first, const int32_t* seg_rows, int S, const float* gamma, const float* beta,
+                                 float eps, int relu, float* y, int ld_y, float* xhat, float* stats, float* running_mean,
+                                 float* running_var, float momentum, int32_t* ticket, float* ws, void* stream);
+int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* xhat, int c, int64_t n,
+                                  const int32_t* chunks, int n_chunks, const int32_t* seg_first, const int32_t* seg_rows, int S,
+                                  const float* gamma, const float* stats, int relu, float* dx, int ld_dx, float* dgamma,
+                                  float* dbeta, int32_t* ticket, float* ws, void* stream);
 size_t insmos_batchnorm_ws_floats(int64_t n, int c);
 int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, int64_t n, const float* gamma, const float* beta, float eps,
                                    int relu, float* y, int ld_y, float* xhat, float* stats, float* ws, void* stream);

@@ -222,6 +222,108 @@ def batch_norm_train(x, gamma, beta, running_mean=None, running_var=None, moment
     return y
 
 
+class BnPlan:
+    """Which rows a BatchNorm layer normalises together (insmos_batchnorm_seg_*, csrc/train.hip): S segments -- the windows of a
+    training batch, each normalised on its own like the reference's item-by-item forwards (models/models.py:313) -- as a table
+    of <= 1024-row chunks of one segment each, sorted by segment.  Built once per coordinate level and step, shared by every
+    layer on that level."""
+
+    CHUNK = 1024
+
+    def __init__(self, runs, n_rows, n_seg, device):
+        """runs: iterable of (row_start, row_end, segment) covering [0, n_rows) (any order)."""
+        import numpy as np
+        ch = []
+        for r0, r1, sg in runs:
+            for a in range(int(r0), int(r1), self.CHUNK):
+                ch.append((a, min(a + self.CHUNK, int(r1)), int(sg), 0))
+        ch = np.asarray(ch, np.int32).reshape(-1, 4)
+        ch = ch[np.argsort(ch[:, 2], kind="stable")]
+        first = np.searchsorted(ch[:, 2], np.arange(n_seg + 1)).astype(np.int32)
+        rows = np.zeros(n_seg, np.int32)
+        np.add.at(rows, ch[:, 2], ch[:, 1] - ch[:, 0])
+        assert int(rows.sum()) == int(n_rows), (int(rows.sum()), n_rows)
+        self.n_rows, self.S, self.n_chunks = int(n_rows), int(n_seg), int(len(ch))
+        self.seg_rows_host = rows
+        self.chunks = torch.from_numpy(np.ascontiguousarray(ch)).to(device)
+        self.seg_first = torch.from_numpy(first).to(device)
+        self.seg_rows = torch.from_numpy(rows).to(device)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)   # the kernels' last-block counter (left zero by each launch)
+
+    @classmethod
+    def whole(cls, n_rows, device):
+        return cls([(0, n_rows, 0)], n_rows, 1, device)
+
+    @classmethod
+    def from_segment_ids(cls, seg, n_seg):
+        """seg: (n,) integer device tensor, the segment of every row (runs of equal ids become the chunk runs)."""
+        n = int(seg.shape[0])
+        seg = seg.contiguous()
+        cut = (torch.nonzero(seg[1:] != seg[:-1]).flatten() + 1).cpu().numpy() if n > 1 else []
+        starts = [0] + [int(v) for v in cut]
+        ends = [int(v) for v in cut] + [n]
+        ids = seg[torch.as_tensor(starts, device=seg.device)].cpu().numpy()
+        return cls(zip(starts, ends, ids), n, n_seg, seg.device)
+
+
+class BatchNormSegFunction(torch.autograd.Function):
+    """BatchNorm1d in training mode with per-segment statistics (BnPlan), fused ReLU; forward and backward are HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, plan, running_mean, running_var, momentum):
+        lib = _lib.load()
+        st = _stream(x.device)
+        x = x.float()
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n, c = x.shape
+        if n != plan.n_rows:
+            raise ValueError(f"BatchNorm plan covers {plan.n_rows} rows, the input has {n}")
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        xhat = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        stats = torch.empty(plan.S * 3 * c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(plan.n_chunks, c, plan.S)), dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.contiguous().float(), beta.contiguous().float()
+        _lib.check(lib.insmos_batchnorm_seg_forward(
+            x.data_ptr(), x.stride(0), c, n, plan.chunks.data_ptr(), plan.n_chunks, plan.seg_first.data_ptr(), plan.seg_rows.data_ptr(),
+            plan.S, g32.data_ptr(), b32.data_ptr(), float(eps), 1 if relu else 0, y.data_ptr(), c, xhat.data_ptr(), stats.data_ptr(),
+            running_mean.data_ptr() if running_mean is not None else None, running_var.data_ptr() if running_var is not None else None,
+            float(momentum), plan.ticket.data_ptr(), ws.data_ptr(), st), "insmos_batchnorm_seg_forward")
+        ctx.save_for_backward(y, xhat, g32, stats)
+        ctx.relu, ctx.plan = bool(relu), plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, xhat, gamma, stats = ctx.saved_tensors
+        plan = ctx.plan
+        st = _stream(dy.device)
+        dy = dy.contiguous().float()
+        n, c = dy.shape
+        dx = torch.empty((n, c), dtype=torch.float32, device=dy.device)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(plan.n_chunks, c, plan.S)), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.insmos_batchnorm_seg_backward(
+            dy.data_ptr(), c, y.data_ptr(), c, xhat.data_ptr(), c, n, plan.chunks.data_ptr(), plan.n_chunks, plan.seg_first.data_ptr(),
+            plan.seg_rows.data_ptr(), plan.S, gamma.data_ptr(), stats.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), c,
+            dgamma.data_ptr(), dbeta.data_ptr(), plan.ticket.data_ptr(), ws.data_ptr(), st), "insmos_batchnorm_seg_backward")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_train_seg(x, gamma, beta, plan, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=False,
+                         force_segmented=False):
+    """batch_norm_train with the statistics taken per segment of `plan` (one window of a training batch each); the running
+    statistics move segment after segment, as the reference's item-by-item forwards move them.  A single segment runs on the
+    first BatchNorm kernels (batch_norm_train: the same layer; measured 9.1 vs 11.3 ms per one-window step, and their rounding is
+    the one tests/golden/train_wiring.npz -- the reference's own training code -- was matched to 1e-4 with) unless
+    force_segmented (tests)."""
+    if plan.S == 1 and not force_segmented:
+        return batch_norm_train(x, gamma, beta, running_mean, running_var, momentum, eps, relu)
+    return BatchNormSegFunction.apply(x, gamma, beta, eps, relu, plan, running_mean, running_var, momentum)
+
+
 class MosLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, gt, class_weights, ignore_mask):
@@ -327,7 +429,7 @@ class CenterHeadLossFunction(torch.autograd.Function):
         return g_cls * g_total, g_box * g_total, None, None, None, None, None, None, None
 
 
-def center_head_loss(cls_preds, box_preds, targets, head_cfg):
+def center_head_loss(cls_preds, box_preds, targets, head_cfg, as_tensors=False):
     """CenterHead.get_loss() (center_head.py:279-288) for NHWC maps cls_preds (B, H, W, C) / box_preds (B, H, W, 8) and the
     dict assign_targets returned -> (rpn_loss, tb_dict) with the reference's keys.  Differentiable in both maps
     (through rpn_loss).  B = 1 is what the reference trains with per model call (models/models.py:313 walks the list);
@@ -340,6 +442,8 @@ def center_head_loss(cls_preds, box_preds, targets, head_cfg):
     parts, total = CenterHeadLossFunction.apply(cls_preds.reshape(-1, nc), box_preds.reshape(-1, 8), targets["heatmaps"][0][0],
                                                 targets["anno_boxes"][0][0], targets["inds"][0][0], targets["masks"][0][0],
                                                 lw["cls_weight"], lw["loc_weight"], lw["code_weights"])
+    if as_tensors:   # (no host read-back here: a step over several windows reads all its reported numbers once at the end)
+        return total, torch.cat([parts, total.detach().reshape(1)])
     host = torch.cat([parts, total.detach().reshape(1)]).cpu()
     tb = {"rpn_loss_cls": float(host[0]), "rpn_loss_loc": float(host[1]), "rpn_loss": float(host[2])}
     return total, tb

@@ -412,6 +412,226 @@ __global__ void k_bn_backward_dx(const float* __restrict__ g, const float* __res
     dx[r * ld_dx + col] = gamma[col] * invstd[col] * (g[t] - dbeta[col] * inv_n - xhat[t] * (dgamma[col] * inv_n));
 }
 
+
+// ---- BatchNorm1d over sparse rows, SEGMENTED and fused (round 3) -----------------------------------------------------------
+// A training step over B windows in one set of launches must keep the reference's statistics: models/models.py:313 walks the
+// batch list item by item, so every BatchNorm sees ONE window's rows (batch statistics per item, running statistics updated
+// item after item).  Rows of a window are one contiguous range in the 3D branch and B x 10 interleaved runs in the 4D branch
+// (rows are (t * B + b)-major), so the kernels take a CHUNK TABLE: (row_start, row_end, segment) with <= 1024 rows of ONE segment
+// per chunk, sorted by segment (seg_first[s] .. seg_first[s + 1]).  S = 1 with plain 1024-row chunks is the unsegmented layer.
+// Fewer passes than the first BatchNorm kernels: forward = one statistics read (per-chunk mean and centred sum of squares, merged
+// per segment with Chan's formula in fixed order, in double) + apply; backward = one read of (dy, y, x^) for both sums with the
+// ReLU mask applied on the fly + dx.  Deterministic.
+struct BnChunk { int r0, r1, seg, pad; };
+
+// "Last block done": every block of a partial-sum kernel takes a ticket after publishing its partials; the block that draws the
+// last one folds them (fixed table order: the result does not depend on which block that is) -- the merge costs no launch.
+__device__ __forceinline__ bool last_block_done(int* __restrict__ counter, int total_blocks) {
+    __shared__ int s_last;
+    __threadfence();   // this block's partials are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(counter, 1);
+        s_last = (t == total_blocks - 1) ? 1 : 0;
+        if (s_last) *counter = 0;   // (the plan's counter is ready for the next layer: launches of one stream are ordered)
+    }
+    __syncthreads();
+    if (s_last) __threadfence();
+    return s_last != 0;
+}
+
+// block = 16 row lanes x 16 channels; grid (chunks, ceil(c / 16)).  part[chunk][0][col] = chunk mean, [1][col] = centred M2.
+// The last block merges every (segment, channel) with Chan's formula in table order (in double; 256 / (S c) threads share a pair,
+// each over a contiguous part of the segment's chunk list, then one of them folds their aggregates in order) and moves the running
+// statistics segment after segment.  stats[s] = [mean (c) | invstd (c) | biased var (c)].
+__global__ void __launch_bounds__(256) k_bnseg_stats(const float* __restrict__ x, int ld, int c, const BnChunk* __restrict__ chunks,
+                                                     float* __restrict__ part, int* __restrict__ counter,
+                                                     const int* __restrict__ seg_first, const int* __restrict__ seg_rows, int S, float eps,
+                                                     float* __restrict__ stats, float momentum, float* __restrict__ rmean,
+                                                     float* __restrict__ rvar) {
+    __shared__ float sm[16][17];
+    __shared__ double sagg[256][3];
+    const BnChunk ch = chunks[blockIdx.x];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.y * 16 + cl;
+    const bool ok = col < c;
+    float acc = 0.f;
+    if (ok)
+        for (int r = ch.r0 + rl; r < ch.r1; r += 16) acc += x[(int64_t)r * ld + col];
+    sm[rl][cl] = acc;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += sm[q][cl];
+    const float mean = tot / (float)(ch.r1 - ch.r0);
+    __syncthreads();
+    acc = 0.f;
+    if (ok)
+        for (int r = ch.r0 + rl; r < ch.r1; r += 16) {
+            const float d = x[(int64_t)r * ld + col] - mean;
+            acc += d * d;
+        }
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m2 += sm[q][cl];
+        part[((int64_t)blockIdx.x * 2 + 0) * c + col] = mean;
+        part[((int64_t)blockIdx.x * 2 + 1) * c + col] = m2;
+    }
+    if (!last_block_done(counter, (int)(gridDim.x * gridDim.y))) return;
+    const int pairs = S * c;
+    int tpp = 1;
+    while (tpp * 2 * pairs <= 256) tpp *= 2;   // threads per (segment, channel) pair
+    for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
+        const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
+        double n = 0.0, mu = 0.0, m2 = 0.0;
+        if (pr < pairs) {
+            const int sgi = pr / c, cc = pr % c;
+            const int q0 = seg_first[sgi], q1 = seg_first[sgi + 1];
+            const int per = (q1 - q0 + tpp - 1) / tpp;
+            const int a0 = q0 + sub * per, a1 = min(a0 + per, q1);
+            for (int q = a0; q < a1; ++q) {
+                const double nb = (double)(chunks[q].r1 - chunks[q].r0);
+                const double mb = part[((int64_t)q * 2 + 0) * c + cc], m2b = part[((int64_t)q * 2 + 1) * c + cc];
+                const double d = mb - mu, nt = n + nb;
+                mu += d * nb / nt;
+                m2 += m2b + d * d * n * nb / nt;
+                n = nt;
+            }
+        }
+        sagg[threadIdx.x][0] = n; sagg[threadIdx.x][1] = mu; sagg[threadIdx.x][2] = m2;
+        __syncthreads();
+        if (pr < pairs && sub == 0) {
+            double N = 0.0, MU = 0.0, M2 = 0.0;
+            for (int t = 0; t < tpp; ++t) {
+                const double nb = sagg[threadIdx.x + t][0], mb = sagg[threadIdx.x + t][1], m2b = sagg[threadIdx.x + t][2];
+                if (nb <= 0.0) continue;
+                const double d = mb - MU, nt = N + nb;
+                MU += d * nb / nt;
+                M2 += m2b + d * d * N * nb / nt;
+                N = nt;
+            }
+            const int sgi = pr / c, cc = pr % c;
+            const float var = N > 0.0 ? (float)(M2 / N) : 0.f;
+            float* st = stats + (int64_t)sgi * 3 * c;
+            st[cc] = (float)MU;
+            st[c + cc] = 1.0f / sqrtf(var + eps);
+            st[2 * c + cc] = var;
+        }
+        __syncthreads();
+    }
+    if (rmean && rvar) {   // running statistics, item after item like the reference's sequential forwards (unbiased variance)
+        __threadfence_block();
+        for (int cc = threadIdx.x; cc < c; cc += 256) {
+            float m = rmean[cc], v = rvar[cc];
+            for (int sgi = 0; sgi < S; ++sgi) {
+                const int n = seg_rows[sgi];
+                if (n <= 0) continue;
+                const float* st = stats + (int64_t)sgi * 3 * c;
+                m = m * (1.0f - momentum) + momentum * st[cc];
+                v = v * (1.0f - momentum) + momentum * (st[2 * c + cc] * ((float)n / (float)max(n - 1, 1)));
+            }
+            rmean[cc] = m;
+            rvar[cc] = v;
+        }
+    }
+}
+// grid (chunks, 4): a quarter of the chunk's rows per block
+__global__ void __launch_bounds__(256) k_bnseg_apply(const float* __restrict__ x, int ld_x, int c, const BnChunk* __restrict__ chunks,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int relu, float* __restrict__ xhat,
+                                                     float* __restrict__ y, int ld_y) {
+    const BnChunk ch = chunks[blockIdx.x];
+    const float* st = stats + (int64_t)ch.seg * 3 * c;
+    const int rows = ch.r1 - ch.r0, q = (rows + 3) / 4;
+    const int ra = ch.r0 + (int)blockIdx.y * q, rb = min(ra + q, ch.r1);
+    const int64_t total = (int64_t)max(rb - ra, 0) * c;
+    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+        const int64_t r = ra + t / c;
+        const int col = (int)(t % c);
+        const float h = (x[r * ld_x + col] - st[col]) * st[c + col];
+        xhat[r * c + col] = h;
+        const float v = h * gamma[col] + beta[col];
+        y[r * ld_y + col] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+// backward sums of one chunk: [0][col] = sum g, [1][col] = sum g * x^, g = dy masked by the ReLU (y > 0).  The last block folds
+// them per segment (segsum[s] = [sum g (c) | sum g x^ (c)], table order) and over the segments (dbeta, dgamma).
+__global__ void __launch_bounds__(256) k_bnseg_bwd_sums(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                        const float* __restrict__ xhat, int c, int relu,
+                                                        const BnChunk* __restrict__ chunks, float* __restrict__ part,
+                                                        int* __restrict__ counter, const int* __restrict__ seg_first, int S,
+                                                        float* __restrict__ segsum, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+    __shared__ float sa[16][17], sb[16][17];
+    const BnChunk ch = chunks[blockIdx.x];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.y * 16 + cl;
+    const bool ok = col < c;
+    float a = 0.f, b = 0.f;
+    if (ok)
+        for (int r = ch.r0 + rl; r < ch.r1; r += 16) {
+            float g = dy[(int64_t)r * ld_dy + col];
+            if (relu && !(y[(int64_t)r * ld_y + col] > 0.f)) g = 0.f;
+            a += g;
+            b += g * xhat[(int64_t)r * c + col];
+        }
+    sa[rl][cl] = a;
+    sb[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ta += sa[q][cl]; tb += sb[q][cl]; }
+        part[((int64_t)blockIdx.x * 2 + 0) * c + col] = ta;
+        part[((int64_t)blockIdx.x * 2 + 1) * c + col] = tb;
+    }
+    if (!last_block_done(counter, (int)(gridDim.x * gridDim.y))) return;
+    for (int pr = threadIdx.x; pr < S * c; pr += 256) {   // per (segment, channel), chunks in table order
+        const int sgi = pr / c, cc = pr % c;
+        float ta = 0.f, tb = 0.f;
+        for (int q = seg_first[sgi]; q < seg_first[sgi + 1]; ++q) {
+            ta += part[((int64_t)q * 2 + 0) * c + cc];
+            tb += part[((int64_t)q * 2 + 1) * c + cc];
+        }
+        segsum[((int64_t)sgi * 2 + 0) * c + cc] = ta;
+        segsum[((int64_t)sgi * 2 + 1) * c + cc] = tb;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < c; cc += 256) {   // dgamma / dbeta = sums over the segments (fixed order)
+        float ta = 0.f, tb = 0.f;
+        for (int sgi = 0; sgi < S; ++sgi) {
+            ta += segsum[((int64_t)sgi * 2 + 0) * c + cc];
+            tb += segsum[((int64_t)sgi * 2 + 1) * c + cc];
+        }
+        dbeta[cc] = ta;
+        dgamma[cc] = tb;
+    }
+}
+// dx = gamma * invstd_s * (g - mean_s(g) - x^ * mean_s(g x^)); grid (chunks, 4)
+__global__ void __launch_bounds__(256) k_bnseg_bwd_dx(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                      const float* __restrict__ xhat, int c, int relu,
+                                                      const BnChunk* __restrict__ chunks, const int* __restrict__ seg_rows,
+                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                      const float* __restrict__ segsum, float* __restrict__ dx, int ld_dx) {
+    const BnChunk ch = chunks[blockIdx.x];
+    const float* st = stats + (int64_t)ch.seg * 3 * c;
+    const float* sg = segsum + (int64_t)ch.seg * 2 * c;
+    const float inv_n = 1.0f / (float)seg_rows[ch.seg];
+    const int rows = ch.r1 - ch.r0, q = (rows + 3) / 4;
+    const int ra = ch.r0 + (int)blockIdx.y * q, rb = min(ra + q, ch.r1);
+    const int64_t total = (int64_t)max(rb - ra, 0) * c;
+    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+        const int64_t r = ra + t / c;
+        const int col = (int)(t % c);
+        float g = dy[r * ld_dy + col];
+        if (relu && !(y[r * ld_y + col] > 0.f)) g = 0.f;
+        dx[r * ld_dx + col] = gamma[col] * st[c + col] * (g - sg[col] * inv_n - xhat[r * c + col] * (sg[c + col] * inv_n));
+    }
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -578,6 +798,55 @@ extern "C" int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, i
     INSMOS_LAUNCH(k_bn_partial, dim3(nb, c), dim3(256), 0, s, x, ld_x, (const float*)nullptr, 0, mean, c, n, 1, ws);
     INSMOS_LAUNCH(k_bn_finish_stats, dim3(cdiv(c, 64)), dim3(64), 0, s, ws, nb, c, n, invstd, 1, eps);
     INSMOS_LAUNCH(k_bn_apply, dim3(cdiv(n * c, 256)), dim3(256), 0, s, x, ld_x, mean, invstd, gamma, beta, c, n, relu, xhat, y, ld_y);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// ---- segmented BatchNorm (see k_bnseg_stats): chunks (n_chunks x 4 int32: row_start, row_end, segment, 0) sorted by segment,
+// seg_first (S + 1 int32, chunk index ranges), seg_rows (S int32, rows per segment), ticket (one int32, zero: the last-block counter,
+// left zero) are DEVICE arrays; stats: S x 3c floats
+// ([mean | invstd | biased var] per segment); ws: insmos_batchnorm_seg_ws_floats.  running_mean / running_var (optional) are updated
+// segment after segment (momentum, unbiased variance), as the reference's item-by-item forwards do.
+extern "C" size_t insmos_batchnorm_seg_ws_floats(int n_chunks, int c, int S) {
+    return (size_t)2 * (size_t)(n_chunks > 0 ? n_chunks : 1) * (size_t)c + (size_t)2 * (size_t)(S > 0 ? S : 1) * (size_t)c + 64;
+}
+
+extern "C" int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int64_t n, const int32_t* chunks, int n_chunks,
+                                            const int32_t* seg_first, const int32_t* seg_rows, int S, const float* gamma,
+                                            const float* beta, float eps, int relu, float* y, int ld_y, float* xhat, float* stats,
+                                            float* running_mean, float* running_var, float momentum, int32_t* ticket, float* ws,
+                                            void* stream) {
+    if (n <= 0 || c <= 0 || n_chunks <= 0) return INSMOS_OK;
+    if (!x || !chunks || !seg_first || !seg_rows || S < 1 || !gamma || !beta || !y || !xhat || !stats || !ws || !ticket || ld_x < c ||
+        ld_y < c || n >= (1ll << 31))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const BnChunk* ch = (const BnChunk*)chunks;
+    ProfScope ps(KK_BATCHNORM, s);
+    INSMOS_LAUNCH(k_bnseg_stats, dim3(n_chunks, cdiv(c, 16)), dim3(256), 0, s, x, ld_x, c, ch, ws, ticket, seg_first, seg_rows, S, eps, stats,
+                  momentum, running_mean, running_var);
+    INSMOS_LAUNCH(k_bnseg_apply, dim3(n_chunks, 4), dim3(256), 0, s, x, ld_x, c, ch, stats, gamma, beta, relu, xhat, y, ld_y);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* xhat, int c, int64_t n,
+                                             const int32_t* chunks, int n_chunks, const int32_t* seg_first, const int32_t* seg_rows,
+                                             int S, const float* gamma, const float* stats, int relu, float* dx, int ld_dx,
+                                             float* dgamma, float* dbeta, int32_t* ticket, float* ws, void* stream) {
+    if (n <= 0 || c <= 0 || n_chunks <= 0) return INSMOS_OK;
+    if (!dy || !xhat || !chunks || !seg_first || !seg_rows || S < 1 || !gamma || !stats || !dx || !dgamma || !dbeta || !ws || !ticket ||
+        (relu && !y) || ld_dy < c || ld_dx < c)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const BnChunk* ch = (const BnChunk*)chunks;
+    float* part = ws;
+    float* segsum = ws + (size_t)2 * n_chunks * c;
+    ProfScope ps(KK_BATCHNORM, s);
+    INSMOS_LAUNCH(k_bnseg_bwd_sums, dim3(n_chunks, cdiv(c, 16)), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, relu, ch, part, ticket, seg_first,
+                  S, segsum, dgamma, dbeta);
+    INSMOS_LAUNCH(k_bnseg_bwd_dx, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, relu, ch, seg_rows, gamma, stats, segsum,
+                  dx, ld_dx);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

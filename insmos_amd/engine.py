@@ -790,6 +790,114 @@ class Engine:
         return logits, pred
 
     # ------------------------------------------------------------------------------------------------
+    # The 3D branch's coordinate side for a BATCH of windows on the step path (the training step, insmos_amd/train_unet.py):
+    # the same C entry points the native runner drives for a launch set (csrc/forward.hip), window = spconv's batch column.
+    def unet_tables_windows(self, cur, n_cur_list):
+        """cur (sum Ncur_b, 8) fp32: the windows' current points back to back; n_cur_list their counts -> the dict unet() leaves
+        in _un_tables (coordinate sets and kernel maps over window-major voxel rows) + 'B', 'win_rows' {level: (B + 1,) row
+        starts per window}.  Every window is voxelised on its own (first-seen order, its own max_voxels cap)."""
+        lib, st, E = self.lib, self._stream(), self._empty
+        B = len(n_cur_list)
+        ncur = int(cur.shape[0])
+        assert sum(int(v) for v in n_cur_list) == ncur and 1 <= B <= MAX_WINDOWS_PER_LAUNCH
+        counts = E((8 + B,), torch.int32)
+        Vcap = self.max_voxels * B
+        feat = E((Vcap, 8))
+        coords1 = E((Vcap, 4), torch.int32)
+        num_points = E((Vcap,), torch.int32)
+        pcid = E((max(ncur, 1),), torch.int64)
+        ukeys = E((max(ncur, 1),), torch.int64)
+        uperm = E((max(ncur, 1),), torch.int32)
+        starts = np.concatenate([[0], np.cumsum([int(v) for v in n_cur_list])]).astype(np.int32)
+        win_start = torch.from_numpy(starts).to(self.device)
+        ws = self._workspace(lib.insmos_voxelize_mean_ws_bytes(ncur))
+        rng = np.array(self.range, dtype=np.float32)
+        vsz = np.array(self.vs, dtype=np.float32)
+        key_cells = int(np.prod(self.shape[1]))
+        _lib.check(lib.insmos_voxelize_mean_windows(cur.data_ptr(), ncur, 8, self.in_ch, win_start.data_ptr(), B, key_cells, _hp(rng),
+                                                    _hp(vsz), self.max_voxels, self.max_points, feat.data_ptr(), 8, coords1.data_ptr(),
+                                                    num_points.data_ptr(), pcid.data_ptr(), ukeys.data_ptr(), uperm.data_ptr(),
+                                                    counts.data_ptr(), ws.data_ptr(), ws.numel(), st), "insmos_voxelize_mean_windows")
+        c = counts.cpu().numpy()
+        V, S = int(c[0]), int(c[1])
+        nv, coords, keys, perm, nkeys = {1: V}, {1: coords1[:V]}, {1: ukeys[:S]}, {1: uperm[:S]}, {1: S}
+        win_rows = {1: np.asarray(c[4:4 + B + 1], np.int64)}
+        k333, s222, p111 = _np_i32([3, 3, 3]), _np_i32([2, 2, 2]), _np_i32([1, 1, 1])
+        k311, s211, p000 = _np_i32([3, 1, 1]), _np_i32([2, 1, 1]), _np_i32([0, 0, 0])
+
+        def down_coords(lvl_in, ks, stv, pd, oshape):
+            n_in = nv[lvl_in]
+            cap = max(min(n_in * int(np.prod(ks)), int(np.prod(oshape)) * B), 1)
+            ok, oc = E((cap,), torch.int64), E((cap, 4), torch.int32)
+            if n_in == 0:
+                return ok[:0], oc[:0], 0
+            osh = _np_i32(oshape)
+            w = self._workspace(lib.insmos_down_coords3d_ws_bytes_b(_hp(osh), B))
+            _lib.check(lib.insmos_down_coords3d_b(coords[lvl_in].data_ptr(), n_in, _hp(ks), _hp(stv), _hp(pd), _hp(osh), B, ok.data_ptr(),
+                                                  oc.data_ptr(), counts.data_ptr(), w.data_ptr(), w.numel(), st), "insmos_down_coords3d_b")
+            no = int(counts[0].item())
+            return ok[:no], oc[:no], no
+
+        for l in (2, 3, 4):
+            keys[l], coords[l], nv[l] = down_coords(l - 1, k333, s222, p111, self.shape[l])
+            perm[l], nkeys[l] = None, nv[l]
+        keys[5], coords[5], nv[5] = down_coords(4, k311, s211, p000, self.shape[5])
+        perm[5], nkeys[5] = None, nv[5]
+        for l in (2, 3, 4, 5):   # rows of the generated levels are in ascending (b, z, y, x) order: a window's rows are one range
+            bcol = coords[l][:, 0].contiguous()
+            win_rows[l] = torch.searchsorted(bcol, torch.arange(B + 1, device=self.device, dtype=torch.int32)).cpu().numpy().astype(np.int64) \
+                if nv[l] else np.zeros(B + 1, np.int64)
+        self.last_counts["unet_voxels"] = [nv[l] for l in (1, 2, 3, 4, 5)]
+        t27, t3 = spconv_tap_offsets((3, 3, 3)), spconv_tap_offsets((3, 1, 1))
+        d_subm = [[0, kz - 1, ky - 1, kx - 1] for kz, ky, kx in t27]
+        d_inv = [[0, 1 - kz, 1 - ky, 1 - kx] for kz, ky, kx in t27]
+        d_down5 = [[0, kz, 0, 0] for kz, ky, kx in t3]
+        d_inv5 = [[0, -kz, 0, 0] for kz, ky, kx in t3]
+        subm = {l: self.build_nbr(coords[l], nv[l], keys[l], perm[l], nkeys[l], 1, self.shape[l], d_subm) for l in (1, 2, 3, 4)}
+        down = {l: self.build_nbr(coords[l], nv[l], keys[l - 1], perm[l - 1], nkeys[l - 1], 1, self.shape[l - 1], d_subm,
+                                  mul=[1, 2, 2, 2]) for l in (2, 3, 4)}
+        inv = {l: self.build_nbr(coords[l - 1], nv[l - 1], keys[l], perm[l], nkeys[l], 1, self.shape[l], d_inv,
+                                 div=[1, 2, 2, 2]) for l in (2, 3, 4)}
+        down5 = self.build_nbr(coords[5], nv[5], keys[4], None, nkeys[4], 1, self.shape[4], d_down5, mul=[1, 2, 1, 1])
+        inv5 = self.build_nbr(coords[4], nv[4], keys[5], None, nkeys[5], 1, self.shape[5], d_inv5, div=[1, 2, 1, 1])
+        self._un_tables = dict(subm=subm, down=down, inv=inv, down5=down5, inv5=inv5, coords=coords, pcid=pcid, feat=feat[:V],
+                               num_points=num_points[:V], B=B, win_rows=win_rows)
+        return self._un_tables
+
+    def detect_windows(self, head, up, B):
+        """detect() for B stacked head maps (rows [b][row][col]): -> pred_boxes (B, post_max, 7), scores (B, post_max), labels
+        (B, post_max) int64, kept counts (B, 4) int32 (slot 0), candidate counts (B, 4)."""
+        lib, st, E = self.lib, self._stream(), self._empty
+        H2, W2 = 2 * self.bevH, 2 * self.bevW
+        ncell = H2 * W2 * B
+        cb, cs = E((B, self.pre_max, 7)), E((B, self.pre_max))
+        cl, cc = E((B, self.pre_max), torch.int32), E((B, self.pre_max), torch.int32)
+        cnt_c, cnt_k = E((B, 4), torch.int32), E((B, 4), torch.int32)
+        w = self._workspace(lib.insmos_center_decode_select_ws_bytes(ncell))
+        _lib.check(lib.insmos_center_decode_select_b(head.data_ptr(), self.head_ld, self.ncls, H2, W2, up, B, self.out_factor, self.tvs[0],
+                                                     self.tvs[1], self.range[0], self.range[1], self.score_thresh, self.pre_max,
+                                                     cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), cc.data_ptr(), cnt_c.data_ptr(),
+                                                     w.data_ptr(), w.numel(), st), "insmos_center_decode_select_b")
+        keep = E((B, self.post_max), torch.int32)
+        w = self._workspace(lib.insmos_nms_ws_bytes_b(self.pre_max, B))
+        _lib.check(lib.insmos_nms_rotated_bev_b(cb.data_ptr(), cnt_c.data_ptr(), self.pre_max, self.nms_thresh, self.post_max, B,
+                                                keep.data_ptr(), cnt_k.data_ptr(), w.data_ptr(), w.numel(), st), "insmos_nms_rotated_bev_b")
+        pb, psc = E((B, self.post_max, 7)), E((B, self.post_max))
+        pl = E((B, self.post_max), torch.int64)
+        _lib.check(lib.insmos_gather_preds_b(cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), keep.data_ptr(), cnt_k.data_ptr(), self.pre_max,
+                                             self.post_max, B, pb.data_ptr(), psc.data_ptr(), pl.data_ptr(), st), "insmos_gather_preds_b")
+        return pb, psc, pl, cnt_k, cnt_c
+
+    def instance_onehot_windows(self, pb, pl, cnt_k, B, level_coords, n, mult, out, ld, col, scratch):
+        """instance_onehot() over window-major voxel rows: a voxel meets the boxes of ITS window (coords[:, 0]) only."""
+        lo = np.array(self.range[0:3], dtype=np.float32)
+        vsz = np.array(self.vs, dtype=np.float32)
+        _lib.check(self.lib.insmos_boxes_to_onehot_b(pb.data_ptr(), pl.data_ptr(), cnt_k.data_ptr(), self.post_max, B, _hp(lo), _hp(vsz), 8.0,
+                                                     float(mult), level_coords.data_ptr(), n, self.ncls, 16, 1 if self.quirk_exact else 0,
+                                                     out.data_ptr() + 4 * col, ld, scratch.data_ptr(), self._stream()),
+                   "insmos_boxes_to_onehot_b")
+
+    # ------------------------------------------------------------------------------------------------
     def forward_window(self, pts, native=None):
         """One batch item of InsMOS_Model.forward(..., 'test') (models/models.py:313-364).
 

@@ -198,6 +198,54 @@ def test_batchnorm_train_vs_torch(relu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("relu,S", [(False, 1), (True, 1), (True, 3), (False, 4)])
+def test_segmented_batchnorm_vs_torch_per_segment(relu, S):
+    """insmos_batchnorm_seg_*: every segment (one window of a training batch, here interleaved runs of rows like the 4D branch's
+    (t * B + b)-major order) is normalised with ITS OWN batch statistics, the running statistics move segment after segment, and
+    the gradients are those of torch's batch_norm applied to each segment's rows on their own (float64 reference); S = 1 is the
+    plain layer."""
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd.autograd import BnPlan, batch_norm_train_seg
+    rng = np.random.default_rng(40 + S)
+    c = 24
+    run_len = [int(v) for v in rng.integers(1, 2600, size=7 * S)]
+    seg_of_run = [int(i % S) for i in range(len(run_len))]          # interleaved, like time slices of B windows
+    seg = np.concatenate([np.full(l, sg, np.int32) for l, sg in zip(run_len, seg_of_run)])
+    n = len(seg)
+    x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 3, c) + rng.normal(size=c) + seg[:, None] * 0.7).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(size=c).astype(np.float32)
+    gy = rng.normal(size=(n, c)).astype(np.float32)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    gr, br = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    yr = torch.zeros((n, c), dtype=torch.float64)
+    segt = torch.from_numpy(seg).long()
+    for sg in range(S):                                               # item after item, like models/models.py:313
+        rows = torch.nonzero(segt == sg).flatten()
+        ys = F.batch_norm(xr[rows], rm, rv, gr, br, training=True, momentum=0.01, eps=1e-3)
+        yr = yr.index_copy(0, rows, torch.relu(ys) if relu else ys)
+    (yr * torch.from_numpy(gy).double()).sum().backward()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    gt_, bt = torch.from_numpy(gamma).cuda().requires_grad_(True), torch.from_numpy(beta).cuda().requires_grad_(True)
+    rm2, rv2 = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    plan = BnPlan.from_segment_ids(torch.from_numpy(seg).cuda(), S)
+    assert plan.S == S and plan.n_rows == n and int(plan.seg_rows_host.sum()) == n
+    y = batch_norm_train_seg(xt, gt_, bt, plan, rm2, rv2, momentum=0.01, eps=1e-3, relu=relu, force_segmented=True)
+    (y * torch.from_numpy(gy).cuda()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rm2.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv2.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(gt_.grad.cpu().numpy(), gr.grad.numpy(), rtol=1e-3, atol=5e-3)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=5e-3)
+    # deterministic
+    xt.grad = None
+    y2 = batch_norm_train_seg(xt, gt_, bt, plan, None, None, eps=1e-3, relu=relu, force_segmented=True)
+    assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
 def test_conv_bn_relu_conv_loss_graph_vs_torch_reference():
     """One trainable block (SubMConv3d -> BatchNorm1d -> ReLU -> SubMConv3d -> MOSLoss, train mode) on the HIP autograd
     nodes vs the same graph written with torch index ops in float64 on the CPU: loss and every parameter gradient."""

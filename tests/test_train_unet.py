@@ -233,3 +233,70 @@ def test_insmos_trainer_train_mode_signature_and_descent():
     with torch.no_grad():
         _, _, logits = model.forward([{"past_point_clouds": batch[0]["past_point_clouds"]}], "test")
     assert bool(torch.isfinite(logits[0]).all())
+
+
+def test_batched_training_step_equals_the_item_by_item_walk():
+    """cfg-5's batch dimension: B windows per training step in ONE set of launches per branch (window index folded into the 4D time
+    coordinate / spconv's batch column, per-window BatchNorm statistics, per-window losses) against the reference's walk over the
+    batch list (models/models.py:313-345; here the same trainer with one window per call): the same per-item losses, the same
+    predictions, the same gradient of the mean loss for every parameter (the sums run in another order: tolerance, not bits) and
+    the same running statistics afterwards."""
+    import copy
+    from insmos_amd import params as P
+    from insmos_amd.synth import make_labels, make_window
+    from insmos_amd.train_unet import InsMOSTrainer
+    rng = np.random.default_rng(21)
+    cfg = copy.deepcopy(P.default_cfg())
+    cfg["MODEL"]["USE_MOTION_LOSS"] = True
+    sd = P.random_state_dict(cfg, 2, cls_bias=-1.0, box_w_std=0.05)
+    batch = []
+    for s, (ns, az) in zip((3, 4, 5), ((3, 96), (4, 80), (3, 128))):          # windows of different sizes
+        w = make_window(seed=s, n_scans=ns, n_az=az)
+        batch.append({"past_point_clouds": torch.from_numpy(w).cuda(),
+                      "past_labels": [None, torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=s)).cuda()],
+                      "gt_boxes": torch.from_numpy(_gt_boxes(rng)).cuda()})
+    tr_b, tr_s = InsMOSTrainer(cfg, sd), InsMOSTrainer(cfg, sd)
+    loss_b, tb_b, gt_b, pred_b = tr_b.forward(batch, "train")
+    loss_b.backward()
+    # item by item: three one-window steps of the same model, losses averaged like models/models.py:365
+    loss_s = torch.zeros(1, device="cuda")
+    tb_s, pred_s = [], []
+    for item in batch:
+        l1, tb1, _, p1 = tr_s.forward([item], "train")
+        loss_s = loss_s + l1
+        tb_s.append(tb1[0])
+        pred_s.append(p1[0])
+    loss_s = loss_s / len(batch)
+    loss_s.backward()
+    assert abs(float(loss_b.detach()) - float(loss_s.detach())) < 1e-5 * max(1.0, abs(float(loss_s.detach())))
+    for a, b in zip(tb_b, tb_s):
+        assert set(a) == set(b) == {"loss_mos", "loss_motion_encoder", "rpn_loss_cls", "rpn_loss_loc", "rpn_loss"}
+        for k in a:
+            assert abs(a[k] - b[k]) < 1e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    for a, b in zip(pred_b, pred_s):
+        assert a.shape == b.shape and float((a - b).abs().max()) < 1e-4
+    bad = []
+    for k, v in tr_b.params.items():
+        g, h = v.grad, tr_s.params[k].grad
+        assert (g is None) == (h is None), k
+        if g is None:
+            continue
+        # (norm-wise: the two walks round differently in the last bits, which flips a handful of ReLU masks at cells whose
+        #  pre-activation is within an ulp of zero -- single elements of a gradient may then differ by their whole value)
+        err = float((g - h).norm())
+        scale = float(h.norm())
+        if err > 2e-2 * scale + 1e-6:
+            bad.append((k, err, scale))
+    assert not bad, sorted(bad, key=lambda t: -t[1] / (t[2] + 1e-12))[:6]
+    for trn_b, trn_s in ((tr_b.motion, tr_s.motion), (tr_b.unet, tr_s.unet)):
+        for k, v in trn_b.buffers.items():
+            np.testing.assert_allclose(v.cpu().numpy(), trn_s.buffers[k].cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    # the sequential switch walks the items with the same result
+    import os
+    os.environ["INSMOS_TRAIN_SEQUENTIAL"] = "1"
+    try:
+        tr_q = InsMOSTrainer(cfg, sd)
+        loss_q, tb_q, _, _ = tr_q.forward(batch, "train")
+    finally:
+        os.environ.pop("INSMOS_TRAIN_SEQUENTIAL")
+    assert abs(float(loss_q.detach()) - float(loss_s.detach())) < 1e-6 * max(1.0, abs(float(loss_s.detach()))) and len(tb_q) == 3
