@@ -335,6 +335,9 @@ int insmos_debug_conv_quad(int on);
  * csrc/spconv_lds.hip; also INSMOS_CONV_LDS=1) or on the generic kernels (0, the default: the staged kernel is bit-identical but
  * slower in its first form); same bits as the unsplit generic kernels (tests/test_gpu_conv.py). */
 int insmos_debug_conv_lds(int on);
+/* probe build of that kernel (insmos_debug_conv_lds(2) / INSMOS_CONV_LDS=2): per-phase cycle sums and counters, 16 u64 (host array);
+ * [0..5] wave 0's cycles in phases A, barrier, C, D, barrier, E; [8] groups, [9] raw groups, [10] overflow rows, [11] taps, [12] workgroups */
+int insmos_debug_conv_lds_stats(unsigned long long* out16_host, int reset);
 /* test / tuning hook: the d/dW kernel of insmos_sparse_conv_backward_weight -- 2 = row-compacting MFMA kernel (default),
  * 1 = first MFMA design (also INSMOS_DW_MFMA=1), 0 = LDS slabs.  All three are deterministic; they differ in summation order.
  * insmos_sparse_conv_backward_weight_ws_floats follows the mode: size the workspace after switching. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
     "insmos_debug_conv_lds": (c_int, [c_int]),
+    "insmos_debug_conv_lds_stats": (c_int, [c_vp, c_int]),
     "insmos_debug_dw_kernel": (c_int, [c_int]),
     "insmos_conv_precision": (c_int, [c_int]),
     "insmos_conv_precision_thread": (c_int, [c_int]),

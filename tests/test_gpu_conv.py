@@ -436,8 +436,8 @@ def test_fused_deconv_head_is_bitwise_the_two_launches(n_site):
 
 @pytest.mark.parametrize("cin,cout,res_mode", [(8, 8, 0), (8, 8, 1), (8, 16, 0), (16, 16, 1), (16, 32, 0), (16, 8, 2)])
 def test_lds_staged_81_tap_kernel_is_bitwise_the_generic_one(cin, cout, res_mode):
-    """The 81-tap single-chunk layers run on k_conv_lds (csrc/spconv_lds.hip: a window of input rows + an overflow area staged
-    in LDS per 64-row block and time offset, B fragments read from LDS).  Same bits as the unsplit generic kernels, on tables
+    """The 81-tap single-chunk layers can run on k_conv_ldsw (csrc/spconv_lds.hip: a window of input rows + an overflow area staged
+    in LDS per 256-row workgroup and time offset, B fragments read from LDS).  Same bits as the unsplit generic kernels, on tables
     built to visit every mode of the kernel: blocks whose neighbours all fall in the window, blocks with a few far neighbours
     (overflow area), blocks with more far neighbours than the overflow area holds (gathers from memory), empty time offsets,
     a missing centre tap, a row suffix (dead-row elimination) and a ragged last block; against the oracle too."""
@@ -463,7 +463,7 @@ def test_lds_staged_81_tap_kernel_is_bitwise_the_generic_one(cin, cout, res_mode
                 present = rng.uniform(size=len(r)) < 0.45
                 near = base + (r - r[0]) + rng.integers(-90, 90, size=len(r))
                 far = rng.integers(0, n_in, size=len(r))
-                p_far = {0: 0.0, 1: 0.05, 2: 0.6, 3: 0.12, 4: 0.03, 5: 0.1}[kind]
+                p_far = {0: 0.0, 1: 0.05, 2: 0.97, 3: 0.12, 4: 0.03, 5: 0.1}[kind]
                 v = np.where(rng.uniform(size=len(r)) < p_far, far, near)
                 nbr[kt, r] = np.where(present, np.clip(v, 0, n_in - 1), -1)
     nbr[:, 64 * 3:64 * 3 + 16] = -1                                    # a 16-row tile without any tap inside an active block
