@@ -110,6 +110,12 @@ int insmos_nbr81_from_coarse(const int32_t* fine_coords, int64_t n_f, const int3
 int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
                                   int fine_shift, const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                   const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);
+/* insmos_nbr81_from_coarse_rows with SPARSE stores: the 16 entries of a (16-row group, tap) pair that is not in the group's mask16
+ * are left unwritten -- insmos_sparse_conv (16-row tiles) reads a group's taps through its mask only; half of the table's bytes.
+ * mask16 is required.  Not for consumers that read every entry (the training kernels, multi-group tiles). */
+int insmos_nbr81_from_coarse_rows_sparse(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                         int fine_shift, const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                         const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);
 int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
                                      const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                      const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
@@ -275,6 +281,10 @@ int insmos_down_coords3d_rank(const int32_t* in_coords, int64_t n_in, const int3
 int insmos_build_nbr_rank(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
                           const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
                           const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
+int insmos_build_nbr_rank_sparse(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                                 const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                                 const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
+                                 /* (sparse stores, see insmos_nbr81_from_coarse_rows_sparse; mask16 required) */
 int insmos_dense_nbr2d_b(int H, int W, int B, int32_t* nbr, void* stream);            /* B images stacked along the rows */
 int insmos_sparse_to_bev_b(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D, int H, int W, int B,
                            float* bev, void* stream);                                    /* bev (B, H, W, C*D) */

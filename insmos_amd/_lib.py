@@ -29,6 +29,7 @@ SIGNATURES = {
     "insmos_nbr_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "insmos_nbr81_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_nbr81_from_coarse_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_nbr81_from_coarse_rows_sparse": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_const_conv125_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_int, c_int, c_vp]),
     "insmos_nbr_down_up": (c_int, [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "insmos_rankmap_from_keys": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_down_coords3d_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_build_nbr_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_build_nbr_rank_sparse": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

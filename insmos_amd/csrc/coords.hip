@@ -835,7 +835,7 @@ __global__ void k_down_expand64(const uint64_t* __restrict__ bits, const int32_t
 __global__ void __launch_bounds__(256) k_build_nbr_rank(const int32_t* __restrict__ out_coords, int64_t n_out,
                                                         const uint64_t* __restrict__ bits, const int32_t* __restrict__ incl,
                                                         const int32_t* __restrict__ perm, NbrParams P, int32_t* __restrict__ nbr,
-                                                        uint32_t* __restrict__ mask16) {
+                                                        uint32_t* __restrict__ mask16, int sparse) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (grp * 16 >= n_out) return;   // (wave-uniform)
@@ -875,8 +875,9 @@ __global__ void __launch_bounds__(256) k_build_nbr_rank(const int32_t* __restric
                 }
             }
         }
-        if (k_ok && row_ok) nbr[(int64_t)k * n_out + o] = r;
         const unsigned long long bal = __ballot(r >= 0);
+        // (sparse stores when asked for: the 16 entries of a tap none of the group's rows has are never read through the mask)
+        if (k_ok && row_ok && (!sparse || ((bal >> (16 * g)) & 0xFFFFull))) nbr[(int64_t)k * n_out + o] = r;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int kt = kk + t;   // (taps past K never have r >= 0)
@@ -891,6 +892,7 @@ __global__ void __launch_bounds__(256) k_build_nbr_rank(const int32_t* __restric
 // can fall into are fetched ONCE (independent loads, entries cached in LDS as (child_start, child_mask)),
 // then every tap of the (2*RANGE+1)^3 x NDT kernel is resolved with bit arithmetic only.
 //   MODE 0: write the neighbour table column-by-column (+ active-tap masks by a 16-lane OR reduction)
+//   MODE 2: the same table with SPARSE stores -- entries of (16-row group, tap) pairs that are not in the group's mask stay unwritten
 //   MODE 1: constant-input convolution -- out[o] = relu(bias + sum_{valid taps} w[k]) -- for the first
 //           MotionNet layer, whose input is 0.5 on every voxel (motionnet.py:29-32): no table, no gathers.
 // Tap order = ME kernel-region order (x fastest, then y, z, t).
@@ -952,9 +954,16 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
                     const unsigned oct = (vx & 1) | ((vy & 1) << 1) | ((vz & 1) << 2);
                     const uint32_t ent = sl[e][tid];
                     const bool hit = (ent >> oct) & 1u;
-                    if (MODE == 0) {
+                    if (MODE == 0 || MODE == 2) {
                         const int32_t r = hit ? (int32_t)(ent >> 8) + __popc(ent & ((1u << oct) - 1u)) : -1;
-                        if (live) nbr[(int64_t)k * n_f + o] = r;
+                        if (MODE == 2) {
+                            // sparse stores: a (16-row group, tap) none of whose rows has the tap is never read by the convolution
+                            // kernels (they walk the group's active-tap mask), so its 16 entries are not written -- half of the table
+                            const unsigned long long bal = __ballot(hit && live);
+                            if (live && ((bal >> (tid & 48)) & 0xFFFFull)) nbr[(int64_t)k * n_f + o] = r;
+                        } else if (live) {
+                            nbr[(int64_t)k * n_f + o] = r;
+                        }
                         if (hit && live) mw[k >> 5] |= 1u << (k & 31);
                     } else {
                         // a tap none of the wave's 64 (Morton-consecutive) voxels has is skipped wave-uniformly: its
@@ -967,7 +976,7 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
                     }
                 }
     static_assert(W1 * W1 * W1 * NDT <= 128, "tap count");
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         if (mask16) {
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
@@ -1522,10 +1531,30 @@ extern "C" int insmos_down_coords3d_rank(const int32_t* in_coords, int64_t n_in,
 }
 
 // insmos_build_nbr (key_mode 1) over a rank map instead of a sorted key array: the same table, the same masks.
+static int build_nbr_rank_impl(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                               const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                               const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, bool sparse_stores,
+                               void* stream);
 extern "C" int insmos_build_nbr_rank(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
                                      const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
                                      const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16,
                                      void* stream) {
+    return build_nbr_rank_impl(out_coords, n_out, bits, blk_incl, in_perm, in_shape_host, delta_host, K, mul_host, div_host, nbr, mask16,
+                               false, stream);
+}
+// the same with sparse stores (see insmos_nbr81_from_coarse_rows_sparse): mask16 required
+extern "C" int insmos_build_nbr_rank_sparse(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                                            const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                                            const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16,
+                                            void* stream) {
+    if (!mask16) return INSMOS_EINVAL;
+    return build_nbr_rank_impl(out_coords, n_out, bits, blk_incl, in_perm, in_shape_host, delta_host, K, mul_host, div_host, nbr, mask16,
+                               true, stream);
+}
+static int build_nbr_rank_impl(const int32_t* out_coords, int64_t n_out, const uint64_t* bits, const int32_t* blk_incl,
+                               const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
+                               const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, bool sparse_stores,
+                               void* stream) {
     if (n_out <= 0 || K <= 0 || K > 128 || !out_coords || !bits || !blk_incl || !in_shape_host || !delta_host || !nbr)
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -1541,7 +1570,7 @@ extern "C" int insmos_build_nbr_rank(const int32_t* out_coords, int64_t n_out, c
     P.K = K;
     ProfScope ps(KK_BUILD_NBR, s);
     INSMOS_LAUNCH(k_build_nbr_rank, dim3(cdiv((n_out + 15) / 16, 4)), dim3(256), 0, s, out_coords, n_out, bits, blk_incl, in_perm, P,
-                  nbr, mask16);
+                  nbr, mask16, sparse_stores ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -1588,10 +1617,29 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
     return INSMOS_OK;
 }
 
+static int nbr81_rows_impl(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent, int fine_shift,
+                           const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
+                           int32_t* nbr, uint32_t* mask16, bool sparse, void* stream);
 extern "C" int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
                                              int fine_shift, const int32_t* coarse_nbr81, int64_t n_c,
                                              const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr,
                                              uint32_t* mask16, void* stream) {
+    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, false,
+                           stream);
+}
+// The same table with the entries of inactive (16-row group, tap) pairs left UNWRITTEN (mask16 is required and complete): for
+// consumers that walk a group's taps through its mask only -- insmos_sparse_conv with 16-row tiles -- half the table's bytes.
+extern "C" int insmos_nbr81_from_coarse_rows_sparse(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                                    int fine_shift, const int32_t* coarse_nbr81, int64_t n_c,
+                                                    const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr,
+                                                    uint32_t* mask16, void* stream) {
+    if (!mask16) return INSMOS_EINVAL;
+    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, true,
+                           stream);
+}
+static int nbr81_rows_impl(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent, int fine_shift,
+                           const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
+                           int32_t* nbr, uint32_t* mask16, bool sparse, void* stream) {
     if (n_f <= 0 || n_f >= (1 << 24) || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
         !child_mask || !nbr || fine_shift < 0 || fine_shift > 14 || row0 < 0)
         return INSMOS_EINVAL;
@@ -1599,6 +1647,11 @@ extern "C" int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t
     if (row0 >= n_f) return INSMOS_OK;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_BUILD_NBR, s);
+    if (sparse)
+        INSMOS_LAUNCH((k_resolve_taps<1, 3, 2>), dim3(cdiv(n_f - row0, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift,
+                      coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr, (const float*)nullptr,
+                      (float*)nullptr, 0, 0, row0);
+    else
     INSMOS_LAUNCH((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f - row0, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, 0, 0, row0);

@@ -302,8 +302,15 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (the level-0 table is read by block8 only -- rows of the last two scans, at the very end of the branch: it is built on
         //  the second stream, off the convolution chain)
         if (l == 0) CK(link_streams(s, s2_tab0));
-        CK(insmos_nbr81_from_coarse_rows(coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1],
-                                         cstart[l], cmask[l], nbr81[l].nbr, nbr81[l].mask, l == 0 ? s2_tab0 : s));
+        // (sparse stores: entries outside a 16-row group's active-tap mask are never read by the 16-row-tile convolution kernels)
+        static const bool sparse_tab = [] {
+            const char* e = getenv("INSMOS_TABLES_DENSE");
+            const char* jt = getenv("INSMOS_CK_JT");
+            return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
+        }();
+        CK((sparse_tab ? insmos_nbr81_from_coarse_rows_sparse : insmos_nbr81_from_coarse_rows)(
+            coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1], cstart[l], cmask[l], nbr81[l].nbr,
+            nbr81[l].mask, l == 0 ? s2_tab0 : s));
     }
     hipEvent_t ev_tab0 = nullptr;
     if (s2_tab0 != s) {
@@ -465,9 +472,16 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         t = table(K, nv[lvl_out]);
         NEED_ARENA();
         if (nv[lvl_out] == 0) return INSMOS_OK;
-        if (rank_tables)
-            return insmos_build_nbr_rank(co[lvl_out], nv[lvl_out], rbits[lvl_in], rincl[lvl_in], pm[lvl_in], g.shape[lvl_in],
-                                         delta.data(), K, mul, div, t.nbr, t.mask, s);
+        if (rank_tables) {
+            static const bool sparse_tab = [] {
+                const char* e = getenv("INSMOS_TABLES_DENSE");
+                const char* jt = getenv("INSMOS_CK_JT");
+                return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
+            }();
+            return (sparse_tab ? insmos_build_nbr_rank_sparse : insmos_build_nbr_rank)(
+                co[lvl_out], nv[lvl_out], rbits[lvl_in], rincl[lvl_in], pm[lvl_in], g.shape[lvl_in], delta.data(), K, mul, div, t.nbr,
+                t.mask, s);
+        }
         return insmos_build_nbr(co[lvl_out], nv[lvl_out], ky[lvl_in], pm[lvl_in], nkeys[lvl_in], 1, g.shape[lvl_in],
                                 delta.data(), K, mul, div, t.nbr, t.mask, s);
     };

@@ -259,6 +259,23 @@ def test_rank_map_tables_match_the_oracle_and_the_searched_builder():
         np.testing.assert_array_equal(res[0][0], res[1][0])
         np.testing.assert_array_equal(res[0][1], res[1][1])
         np.testing.assert_array_equal(res[0][1], tap_masks(res[0][0]))
+        # sparse stores: the same masks, and the same entries wherever a (16-row group, tap) is in its group's mask (the others stay
+        # as they were -- here the prefill -- and are never read by the 16-row-tile convolution kernels)
+        nbr_s = torch.full((len(delta), no), -7, dtype=torch.int32, device="cuda")
+        mask_s = torch.zeros(((no + 15) // 16, 4), dtype=torch.int32, device="cuda")
+        pm = dev(in_perm) if in_perm is not None else None
+        assert L.insmos_build_nbr_rank_sparse(oc.data_ptr(), no, bits_t.data_ptr(), incl_t.data_ptr(), pm.data_ptr() if pm is not None else None,
+                                              hp(i32(in_shape)), hp(delta), len(delta), hp(mul), hp(div), nbr_s.data_ptr(), mask_s.data_ptr(),
+                                              stream()) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(mask_s.cpu().numpy().view(np.uint32), res[0][1])
+        ns_, full = nbr_s.cpu().numpy(), res[0][0]
+        act = np.zeros((len(delta), (no + 15) // 16), bool)
+        for k in range(len(delta)):
+            act[k] = (res[0][1][:, k >> 5] >> np.uint32(k & 31)) & 1
+        act_rows = np.repeat(act, 16, axis=1)[:, :no]
+        np.testing.assert_array_equal(ns_[act_rows], full[act_rows])
+        assert (ns_[~act_rows] == -7).all() and (~act_rows).any()
         return res[0][0]
 
     # submanifold table over the permuted level (rows = first-seen order, some cells dropped)
