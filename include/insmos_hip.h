@@ -112,7 +112,9 @@ int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64
                                   const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);
 /* insmos_nbr81_from_coarse_rows with SPARSE stores: the 16 entries of a (16-row group, tap) pair that is not in the group's mask16
  * are left unwritten -- insmos_sparse_conv (16-row tiles) reads a group's taps through its mask only; half of the table's bytes.
- * mask16 is required.  Not for consumers that read every entry (the training kernels, multi-group tiles). */
+ * mask16 is required.  Not for consumers that read every entry: the training kernels, multi-group tiles, and the derivation of the
+ * next finer level's table / the first layer's tap resolver (insmos_nbr81_from_coarse*, insmos_const_conv125_from_coarse) -- i.e. the
+ * finest level's table only. */
 int insmos_nbr81_from_coarse_rows_sparse(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
                                          int fine_shift, const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                          const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, void* stream);

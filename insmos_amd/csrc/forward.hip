@@ -288,13 +288,38 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     Table nbr81[4];
     nbr81[3] = table(81, n[3]);
     NEED_ARENA();
-    {
-        const int32_t one[4] = {1, 1, 1, 1};
-        // the only arithmetic on t in the whole branch: the searched table's time offsets move by B (t' = t * B + b)
-        std::vector<int32_t> off = C.off81[3];
+    // the time offsets of a SEARCHED table move by B (t' = t * B + b): the only arithmetic on t in the whole branch
+    auto search81 = [&](int lvl, const int32_t* cds, const uint64_t* kys, int64_t nn, Table& t) -> int {
+        const int k3[4] = {3, 3, 3, 3};
+        const int ts[4] = {1 << lvl, 1 << lvl, 1 << lvl, 1};
+        std::vector<int32_t> off = me_offsets(k3, ts);
         for (size_t k = 0; k < off.size() / 4; ++k) off[4 * k + 3] *= B;
-        CK(insmos_build_nbr(coords[3], n[3], keys[3], nullptr, n[3], 0, nullptr, off.data(), 81, one, one, nbr81[3].nbr,
-                            nbr81[3].mask, s));
+        const int32_t one[4] = {1, 1, 1, 1};
+        return insmos_build_nbr(cds, nn, kys, nullptr, nn, 0, nullptr, off.data(), 81, one, one, t.nbr, t.mask, s);
+    };
+    // One more level of the hierarchy for launch sets (B >= 2): searching 81 taps of the stride-16 voxels (a third of the stride-8
+    // ones) and deriving the stride-8 table from it costs a third of searching stride 8; a single window gains nothing (one more
+    // count read-back), so it searches stride 8 directly.
+    static const bool deep_tables = [] { const char* e = getenv("INSMOS_TABLES_LEVEL4"); return !(e && e[0] == '0'); }();
+    if (deep_tables && B >= 2) {
+        const int64_t np = n[3];
+        uint64_t* keys4 = A.take<uint64_t>(np);
+        int32_t* coords4 = A.take<int32_t>(4 * np);
+        int32_t* parent3 = A.take<int32_t>(np);
+        int32_t* cstart3 = A.take<int32_t>(np);
+        uint32_t* cmask3 = A.take<uint32_t>(np);
+        const size_t wsb = insmos_level_down4d_ws_bytes(np);
+        void* ws = A.take<char>(wsb);   // (not rewound: the level-0 table below is written on the second stream)
+        NEED_ARENA();
+        CK(insmos_level_down4d(keys[3], np, 4, keys4, coords4, parent3, cstart3, cmask3, counts, ws, wsb, s));
+        CK(read_counts(counts, hc, 1, s));
+        const int64_t n4 = hc[0];
+        Table t4 = table(81, n4);
+        NEED_ARENA();
+        CK(search81(4, coords4, keys4, n4, t4));
+        CK(insmos_nbr81_from_coarse_rows(coords[3], n[3], 0, parent3, 3, t4.nbr, n4, cstart3, cmask3, nbr81[3].nbr, nbr81[3].mask, s));
+    } else {
+        CK(search81(3, coords[3], keys[3], n[3], nbr81[3]));
     }
     for (int l = 2; l >= 0; --l) {
         nbr81[l] = table(81, n[l]);
@@ -302,13 +327,15 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (the level-0 table is read by block8 only -- rows of the last two scans, at the very end of the branch: it is built on
         //  the second stream, off the convolution chain)
         if (l == 0) CK(link_streams(s, s2_tab0));
-        // (sparse stores: entries outside a 16-row group's active-tap mask are never read by the 16-row-tile convolution kernels)
+        // (sparse stores for the FINEST table only: entries outside a 16-row group's active-tap mask are never read by the 16-row-tile
+        //  convolution kernels -- but a coarser table is also the input of the next finer one's derivation and of the first layer's
+        //  tap resolver, which read every entry)
         static const bool sparse_tab = [] {
             const char* e = getenv("INSMOS_TABLES_DENSE");
             const char* jt = getenv("INSMOS_CK_JT");
             return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
         }();
-        CK((sparse_tab ? insmos_nbr81_from_coarse_rows_sparse : insmos_nbr81_from_coarse_rows)(
+        CK(((sparse_tab && l == 0) ? insmos_nbr81_from_coarse_rows_sparse : insmos_nbr81_from_coarse_rows)(
             coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1], cstart[l], cmask[l], nbr81[l].nbr,
             nbr81[l].mask, l == 0 ? s2_tab0 : s));
     }

@@ -58,7 +58,7 @@ class InsMOS_Model:
         self.device = device
         self.quirk_exact = quirk_exact
         if windows_in_flight is None:
-            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "3"))
+            windows_in_flight = int(os.environ.get("INSMOS_WINDOWS_IN_FLIGHT", "4"))
         if windows_per_launch is None:
             windows_per_launch = int(os.environ.get("INSMOS_WINDOWS_PER_LAUNCH", "8"))
         self.windows_in_flight = max(1, int(windows_in_flight))         # launch sets (groups) in flight

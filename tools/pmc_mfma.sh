@@ -1,9 +1,9 @@
 #!/bin/bash
 # MFMA-pipe utilisation of the conv launches from PMC counters (one rocprofv3 pass, --kernel-trace only; one window in flight)
-R=$(pwd); TAG=${1:-r02}; WPL=${2:-4}
+R=$(pwd); TAG=${1:-r03}; WPL=${2:-4}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_mfma
-( cd /tmp && INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES \
+( cd /tmp && INSMOS_TWO_STREAMS=0 INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES \
     -d $R/gpurun_out/pmc_mfma/p -o p --output-format csv -- python $R/bench.py --timed-only --steps 1 --warmup 0 --windows-per-step $WPL ) > $R/gpurun_out/pmc_mfma/p.log 2>&1
 echo "rc=$?"
 python - <<PY
