@@ -287,6 +287,24 @@ int insmos_build_nbr_rank_sparse(const int32_t* out_coords, int64_t n_out, const
                                  const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
                                  const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
                                  /* (sparse stores, see insmos_nbr81_from_coarse_rows_sparse; mask16 required) */
+/* Row regrouping (no reference counterpart: spconv's rulebooks are pair lists, the row order of a level is an implementation
+ * detail there too -- spconv_unet.py:120-207 never looks at it).  The output-stationary kernels pay one 16-row MFMA pass per
+ * (16-row group, tap) slot any row of the group uses; rows are re-ordered inside blocks of block_rows (256 / 1024 / 4096)
+ * consecutive rows by their 27-bit submanifold tap signature so that a group's rows want the same taps.
+ *   insmos_regroup_rows3d: coords (n, 4) (b, z, y, x), bits = the level's rank-map bitmap -> new_coords (n, 4), new_of_old (n),
+ *   old_of_new (n).  The window index leads the sort key: window-major rows stay window-major.
+ *   insmos_regroup_apply_voxels: the voxeliser's level-1 arrays under that renaming (num_points copied to its new rows,
+ *   uperm and pc_voxel_id renamed in place; -1 entries stay). */
+size_t insmos_regroup_ws_bytes(int64_t n);   /* workspace of either form */
+int insmos_regroup_rows3d(const int32_t* coords, int64_t n, const uint64_t* bits, const int32_t* shape_host, int block_rows,
+                          int32_t* new_coords, int32_t* new_of_old, int32_t* old_of_new /* optional */, void* ws, size_t ws_bytes,
+                          void* stream);
+/* ... over whole windows: one stable sort of (window, signature), rows of equal signature in their old order */
+int insmos_regroup_rows3d_global(const int32_t* coords, int64_t n, const uint64_t* bits, const int32_t* shape_host,
+                                 int32_t* new_coords, int32_t* new_of_old, int32_t* old_of_new /* optional */, void* ws,
+                                 size_t ws_bytes, void* stream);
+int insmos_regroup_apply_voxels(const int32_t* new_of_old, int64_t n_rows, const int32_t* num_points_old, int32_t* num_points_new,
+                                int32_t* uperm, int64_t n_cells, int64_t* pc_voxel_id, int64_t n_points, void* stream);
 int insmos_dense_nbr2d_b(int H, int W, int B, int32_t* nbr, void* stream);            /* B images stacked along the rows */
 int insmos_sparse_to_bev_b(const float* feat, int ld_feat, int C, const int32_t* coords, int64_t n, int D, int H, int W, int B,
                            float* bev, void* stream);                                    /* bev (B, H, W, C*D) */
@@ -306,6 +324,12 @@ int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels
                              int B, const float* range_lo_host, const float* vsize_host, float stride, float mult,
                              const int32_t* coords, int64_t n, int ncls, int pad_to, int quirk_exact, float* out, int ld_out,
                              int32_t* scratch, void* stream);
+/* ... over rows re-ordered by insmos_regroup_rows3d: orig_of_row / row_of_orig (both or neither; null = reference order) keep the
+ * order-dependent part of Array_Index.cpp:40-56 -- the FIRST voxel inside a box -- in the reference's row order. */
+int insmos_boxes_to_onehot_rows(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev, int max_boxes,
+                                int B, const float* range_lo_host, const float* vsize_host, float stride, float mult,
+                                const int32_t* coords, const int32_t* orig_of_row, const int32_t* row_of_orig, int64_t n, int ncls,
+                                int pad_to, int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream);
 int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int B, int32_t* starts, void* stream);
 /* Dense BEV backbone convolution (base_bev_backbone.py:33-61: ZeroPad2d(1)+Conv2d(3x3) / Conv2d(3x3, padding 1), each with
  * BatchNorm2d + ReLU) as an LDS-tiled implicit GEMM: x (B, H, W, cin) NHWC with row pitch ld_x -> out (B, H, W, cout) with row
@@ -614,6 +638,10 @@ int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts,
  * (15); the environment variable INSMOS_TWO_STREAMS overrides both.  Single-window latency 3.8 -> 3.4 ms; with several launch
  * sets in flight the sets already overlap each other and the caller switches it off (insmos_amd/models.py). */
 int insmos_forward_streams(int mask);
+/* Row regrouping of the runner's 3D levels 1..4, one decimal digit per level (level 1 = units): 0 = off, 1 = blocks of 256 rows,
+ * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global); -1 = default (environment
+ * variable INSMOS_REGROUP_ROWS, else the built-in choice).  Process-wide.  The outputs do not depend on it. */
+int insmos_forward_regroup(int modes);
 int insmos_debug_table_limit(int64_t bytes); /* tests only: lower the table size at which a batch is refused (0 = default) */
 int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,
                            void* arena, size_t arena_bytes, void* stream, InsmosForwardOut* outs);

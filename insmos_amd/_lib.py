@@ -65,6 +65,8 @@ SIGNATURES = {
     "insmos_boxes_to_onehot_scratch_ints_b": (c_sz, [c_int, c_int, c_i64]),
     "insmos_boxes_to_onehot_b": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_int, c_int,
                                          c_int, c_vp, c_int, c_vp, c_vp]),
+    "insmos_boxes_to_onehot_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_i64, c_int,
+                                            c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_debug_table_limit": (c_int, [c_i64]),
     "insmos_forward_streams": (c_int, [c_int]),
     "insmos_rankmap_words": (c_sz, [c_vp, c_int]),
@@ -73,6 +75,11 @@ SIGNATURES = {
     "insmos_down_coords3d_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_build_nbr_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_build_nbr_rank_sparse": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_forward_regroup": (c_int, [c_int]),
+    "insmos_regroup_rows3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_regroup_ws_bytes": (c_sz, [c_i64]),
+    "insmos_regroup_rows3d_global": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_regroup_apply_voxels": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

@@ -1575,6 +1575,173 @@ static int build_nbr_rank_impl(const int32_t* out_coords, int64_t n_out, const u
     return INSMOS_OK;
 }
 
+// ---- row regrouping ------------------------------------------------------------------------------------------------------
+// The convolution kernels walk, per 16-row group, the UNION of the taps its rows have: a (group, tap) slot costs a full 16-row
+// MFMA pass whether one row or sixteen use it (~30-40 % of the executed passes multiply absent rows).
+// Which rows share a group is free: a level's row order is private to the runner (features, tables and rank lookups all go
+// through it).  Rows are therefore re-ordered inside blocks of NB consecutive rows (spatially close: the gathers keep their
+// locality) by their submanifold TAP SIGNATURE -- bit k = the row has the k-th of its 27 neighbours -- so that a group's rows want
+// the same taps (the window index leads the sort key: rows of different windows are never exchanged).  Measured on the S0 windows: executed (group, tap) slots of the submanifold maps -19...-24 %, of the strided
+// maps -21...-29 %, of the (cheap) inverse maps +12...+23 %.
+// Signatures from the level's rank-map bitmap (one thread per row), then one workgroup = one block: a bitonic sort of
+// (window, signature, local row) in LDS, the permuted coordinates and new_of_old / old_of_new.  Deterministic (the local row breaks
+// ties).
+// 27-bit submanifold tap signature of every row (bit k = the k-th neighbour, (dz, dy, dx) raster order, exists)
+__device__ __forceinline__ uint32_t tap_signature(const int4 c, const uint64_t* __restrict__ bits, int D, int H, int W) {
+    uint32_t sig = 0u;
+    int k = 0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx, ++k) {
+                const uint64_t q = key3b_encode(c.x, c.y + dz, c.z + dy, c.w + dx, D, H, W);
+                if (q != INSMOS_INVALID_KEY && ((bits[q >> 6] >> (q & 63)) & 1ull)) sig |= 1u << k;
+            }
+    return sig;
+}
+__global__ void k_regroup_sig(const int32_t* __restrict__ coords, int64_t n, const uint64_t* __restrict__ bits, int D, int H, int W,
+                              uint32_t* __restrict__ sig) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    sig[o] = tap_signature(*(const int4*)(coords + o * 4), bits, D, H, W);
+}
+template <int NB>
+__global__ void __launch_bounds__(1024) k_regroup_rows(const int32_t* __restrict__ coords, int64_t n, const uint32_t* __restrict__ sig,
+                                                       int32_t* __restrict__ new_coords, int32_t* __restrict__ new_of_old,
+                                                       int32_t* __restrict__ old_of_new) {
+    __shared__ uint64_t key[NB];
+    constexpr int NT = NB < 2048 ? NB / 2 : 1024;   // threads: one comparator each, or two (NB = 4096)
+    const int64_t base = (int64_t)blockIdx.x * NB;
+    for (int i = threadIdx.x; i < NB; i += NT) {
+        const int64_t o = base + i;
+        // window first: rows stay window-major.  Rows past the end sort last.
+        key[i] = o < n ? ((uint64_t)coords[o * 4] << 43) | ((uint64_t)sig[o] << 16) | (uint64_t)i : ~0ull;
+    }
+    __syncthreads();
+    for (int size = 2; size <= NB; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < NB / 2; t += NT) {
+                const int lo = 2 * t - (t & (stride - 1));   // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < NB; i += NT) {
+        const int64_t nw = base + i;
+        if (nw >= n) break;
+        const int64_t old = base + (int64_t)(key[i] & 0xFFFFull);
+        new_of_old[old] = (int32_t)nw;
+        if (old_of_new) old_of_new[nw] = (int32_t)old;
+        *(int4*)(new_coords + nw * 4) = *(const int4*)(coords + old * 4);
+    }
+}
+
+// coords (n, 4) int32 (b, z, y, x) of one level, bits = that level's rank-map bitmap (insmos_rankmap_from_keys /
+// insmos_down_coords3d_rank), shape = its (D, H, W).  block_rows in {256, 1024, 4096}.  Writes new_coords (n, 4) = the rows in
+// their new order, new_of_old (n): the new row of each old row, and (optional) old_of_new, its inverse.  Rows of different
+// windows (coords column 0) never change their relative order: window-major rows stay window-major.
+extern "C" size_t insmos_regroup_ws_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return pad256((size_t)n * 8) * 2 + sort_keys_u64_temp((size_t)n) + 1024;
+}
+extern "C" int insmos_regroup_rows3d(const int32_t* coords, int64_t n, const uint64_t* bits, const int32_t* shape_host, int block_rows,
+                                     int32_t* new_coords, int32_t* new_of_old, int32_t* old_of_new, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!coords || !bits || !shape_host || !new_coords || !new_of_old || !ws || n >= (1ll << 31)) return INSMOS_EINVAL;
+    if (block_rows != 256 && block_rows != 1024 && block_rows != 4096) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    uint32_t* sig = b.take<uint32_t>((size_t)n);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH(k_regroup_sig, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, coords, n, bits, shape_host[0], shape_host[1], shape_host[2], sig);
+    if (block_rows == 256)
+        INSMOS_LAUNCH(k_regroup_rows<256>, dim3(cdiv(n, 256)), dim3(128), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+    else if (block_rows == 1024)
+        INSMOS_LAUNCH(k_regroup_rows<1024>, dim3(cdiv(n, 1024)), dim3(512), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+    else
+        INSMOS_LAUNCH(k_regroup_rows<4096>, dim3(cdiv(n, 4096)), dim3(1024), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// The same over WHOLE WINDOWS (block_rows = 1): one stable radix sort of (window, signature) keys -- packed above the row index like
+// the 4D quantiser's keys -- instead of block-local sorts.  Longer runs of equal signatures: consecutive tiles walk the same tap
+// list at the same time, so the wide layers' weight fragments are re-used out of L1/L2 by neighbouring waves.
+__global__ void k_regroup_keys(const int32_t* __restrict__ coords, int64_t n, const uint64_t* __restrict__ bits, int D, int H, int W,
+                               uint64_t* __restrict__ keys) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const int4 c = *(const int4*)(coords + o * 4);
+    keys[o] = ((uint64_t)o << PK_KEY_BITS) | ((uint64_t)c.x << 27) | (uint64_t)tap_signature(c, bits, D, H, W);
+}
+__global__ void k_regroup_scatter(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ coords, int64_t n,
+                                  int32_t* __restrict__ new_coords, int32_t* __restrict__ new_of_old, int32_t* __restrict__ old_of_new) {
+    const int64_t nw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nw >= n) return;
+    const int64_t old = (int64_t)(keys_s[nw] >> PK_KEY_BITS);
+    new_of_old[old] = (int32_t)nw;
+    if (old_of_new) old_of_new[nw] = (int32_t)old;
+    *(int4*)(new_coords + nw * 4) = *(const int4*)(coords + old * 4);
+}
+extern "C" int insmos_regroup_rows3d_global(const int32_t* coords, int64_t n, const uint64_t* bits, const int32_t* shape_host,
+                                            int32_t* new_coords, int32_t* new_of_old, int32_t* old_of_new, void* ws, size_t ws_bytes,
+                                            void* stream) {
+    if (n <= 0) return INSMOS_OK;
+    if (!coords || !bits || !shape_host || !new_coords || !new_of_old || !ws || n >= (1ll << PK_IDX_BITS)) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    uint64_t* k_in = b.take<uint64_t>((size_t)n);
+    uint64_t* k_s = b.take<uint64_t>((size_t)n);
+    const size_t st = sort_keys_u64_temp((size_t)n);
+    char* tmp = b.take<char>(st);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH(k_regroup_keys, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, coords, n, bits, shape_host[0], shape_host[1], shape_host[2], k_in);
+    int rc = sort_keys_u64(tmp, st, k_in, k_s, (size_t)n, 0, 27 + 4, s);   // (window < 16: 4 bits above the 27 signature bits); stable
+    if (rc) return rc;
+    INSMOS_LAUNCH(k_regroup_scatter, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, k_s, coords, n, new_coords, new_of_old, old_of_new);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// the level-1 (voxeliser) arrays under a row re-ordering: num_points moves with its row, the cell -> row map (uperm, n_cells
+// entries, -1 = dropped cell) and the point -> row map (pc_voxel_id, n_points entries, -1 = no voxel) are renamed in place
+__global__ void k_regroup_apply(const int32_t* __restrict__ new_of_old, int64_t n_rows, const int32_t* __restrict__ num_old,
+                                int32_t* __restrict__ num_new, int32_t* __restrict__ uperm, int64_t n_cells,
+                                int64_t* __restrict__ pcid, int64_t n_points) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) num_new[new_of_old[i]] = num_old[i];
+    if (i < n_cells) {
+        const int v = uperm[i];
+        if (v >= 0) uperm[i] = new_of_old[v];
+    }
+    if (i < n_points) {
+        const int64_t v = pcid[i];
+        if (v >= 0) pcid[i] = (int64_t)new_of_old[v];
+    }
+}
+extern "C" int insmos_regroup_apply_voxels(const int32_t* new_of_old, int64_t n_rows, const int32_t* num_points_old,
+                                           int32_t* num_points_new, int32_t* uperm, int64_t n_cells, int64_t* pc_voxel_id,
+                                           int64_t n_points, void* stream) {
+    if (n_rows <= 0) return INSMOS_OK;
+    if (!new_of_old || !num_points_old || !num_points_new || !uperm || !pc_voxel_id || n_cells < 0 || n_points < 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t m = n_rows > n_cells ? n_rows : n_cells;
+    if (n_points > m) m = n_points;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH(k_regroup_apply, dim3(cdiv(m, TPB)), dim3(TPB), 0, s, new_of_old, n_rows, num_points_old, num_points_new, uperm,
+                  n_cells, pc_voxel_id, n_points);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
 extern "C" int insmos_down_coords3d(const int32_t* in_coords, int64_t n_in, const int32_t* ksize_host,
                                     const int32_t* stride_host, const int32_t* pad_host,
                                     const int32_t* out_shape_host, uint64_t* out_keys, int32_t* out_coords,

@@ -57,6 +57,14 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 }
 
 struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
+int g_regroup = -1;                 // row regrouping modes of the 3D levels (insmos_forward_regroup); -1 = not read yet
+constexpr int kRegroupDefault = 3333;   // every level: blocks of 4096 rows (measured against 1024-row blocks and whole windows)
+inline bool regroup_modes_ok(int v) {
+    if (v < 0 || v > 4444) return false;
+    for (int l = 0; l < 4; ++l, v /= 10)
+        if (v % 10 > 4) return false;
+    return true;
+}
 int64_t g_table_limit = 1ll << 31;  // bytes a neighbour table may span (32-bit offsets); lowered by tests (insmos_debug_table_limit)
 
 #define CK(expr)                                  \
@@ -427,12 +435,13 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     CK(read_counts(counts, hc, 5 + B, s));
     for (int b = 0; b < B; ++b) outs[b].unet_voxels[0] = hc[4 + b + 1] - hc[4 + b];
     int64_t nv[6] = {0}, nkeys[6] = {0};
-    const int32_t* co[6] = {nullptr};
+    const int32_t* co[6] = {nullptr};       // a level's coordinates in the row order its features are stored in ...
+    const int32_t* co_ref[6] = {nullptr};   // ... and in the order they were generated in (what the next level's bitmap is marked from)
     const uint64_t* ky[6] = {nullptr};
     const int32_t* pm[6] = {nullptr};
     nv[1] = hc[0];
     nkeys[1] = hc[1];
-    co[1] = coords1;
+    co[1] = co_ref[1] = coords1;
     ky[1] = ukeys;
     pm[1] = uperm;
     // rank maps (occupancy bitmap + block prefix counts) of the five levels: what the 13 kernel maps are read off instead of
@@ -453,6 +462,52 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         CK(insmos_rankmap_from_keys(ukeys, nkeys[1], g.shape[1], B, rbits[1], rincl[1], ws, wsb, s));
         A.off = mark;   // (stream-ordered: the next user of this scratch is enqueued behind it)
     }
+    // row regrouping (coords.hip: k_regroup_rows): every level's rows are re-ordered (inside blocks, or over whole windows) by tap
+    // signature, so that the 16 rows of a group want the same taps; the row order of a level is private to this function
+    // (features, kernel maps, rank lookups and the point -> voxel map all follow).  INSMOS_REGROUP_ROWS=0 keeps the plain order.
+    if (g_regroup < 0) {
+        const char* e = getenv("INSMOS_REGROUP_ROWS");
+        const int v = e ? atoi(e) : kRegroupDefault;
+        g_regroup = regroup_modes_ok(v) ? v : 0;
+    }
+    const int regroup = g_regroup;
+    // level l's mode = the l-th decimal digit (insmos_forward_regroup): 0 off, 1 / 2 / 3 = blocks of 256 / 1024 / 4096 rows, 4 = windows
+    auto regroup_level = [&](int lvl, const int32_t* c_old, int64_t nrows, const int32_t* shp, int32_t* c_new, int32_t* n2o,
+                             int32_t* o2n) -> int {
+        int m = regroup;
+        for (int l = 1; l < lvl; ++l) m /= 10;
+        m %= 10;
+        const size_t wsb = insmos_regroup_ws_bytes(nrows);
+        const size_t mark = A.off;
+        void* ws = A.take<char>(wsb);
+        NEED_ARENA();
+        if (m == 4) CK(insmos_regroup_rows3d_global(c_old, nrows, rbits[lvl], shp, c_new, n2o, o2n, ws, wsb, s));
+        else CK(insmos_regroup_rows3d(c_old, nrows, rbits[lvl], shp, m == 1 ? 256 : m == 2 ? 1024 : 4096, c_new, n2o, o2n, ws, wsb, s));
+        A.off = mark;
+        return INSMOS_OK;
+    };
+    auto regroup_on = [&](int lvl) {
+        int m = regroup;
+        for (int l = 1; l < lvl; ++l) m /= 10;
+        return m % 10 != 0;
+    };
+    const int32_t* row_new[6] = {nullptr};    // per level: reference row -> row here, and back (null: the reference's order)
+    const int32_t* row_orig[6] = {nullptr};
+    const int32_t* num_points_r = num_points;   // level-1 arrays in their final row order (what phase 2 of the voxeliser reads)
+    const int32_t* coords1_r = coords1;
+    if (rank_tables && regroup_on(1) && nv[1] > 0) {
+        int32_t* c1n = A.take<int32_t>(nv[1] * 4);
+        int32_t* np1n = A.take<int32_t>(nv[1]);
+        int32_t* n2o = A.take<int32_t>(nv[1]);
+        int32_t* o2n = A.take<int32_t>(nv[1]);
+        NEED_ARENA();
+        CK(regroup_level(1, coords1, nv[1], g.shape[1], c1n, n2o, o2n));
+        row_new[1] = n2o;
+        row_orig[1] = o2n;
+        CK(insmos_regroup_apply_voxels(n2o, nv[1], num_points, np1n, uperm, nkeys[1], pcid, ncur, s));
+        co[1] = coords1_r = c1n;
+        num_points_r = np1n;
+    }
     auto down_coords = [&](int lvl_in, const int32_t ks[3], const int32_t st[3], const int32_t pd[3], const int32_t* oshape,
                            int lvl_out) -> int {
         const int64_t n_in = nv[lvl_in];
@@ -461,7 +516,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         const int64_t cap = std::max<int64_t>(std::min(n_in * K, cells), 1);
         uint64_t* ok = A.take<uint64_t>(cap);
         int32_t* oc = A.take<int32_t>(cap * 4);
-        co[lvl_out] = oc;
+        co[lvl_out] = co_ref[lvl_out] = oc;
         ky[lvl_out] = ok;
         pm[lvl_out] = nullptr;
         if (n_in == 0) {
@@ -475,13 +530,24 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
         if (rank_tables)
-            CK(insmos_down_coords3d_rank(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, rbits[lvl_out], rincl[lvl_out], ws,
+            CK(insmos_down_coords3d_rank(co_ref[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, rbits[lvl_out], rincl[lvl_out], ws,
                                          wsb, s));
         else
-            CK(insmos_down_coords3d_b(co[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
+            CK(insmos_down_coords3d_b(co_ref[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
         CK(read_counts(counts, hc, 1, s));
         A.off = mark;
         nv[lvl_out] = nkeys[lvl_out] = hc[0];
+        if (rank_tables && lvl_out <= 4 && regroup_on(lvl_out) && hc[0] > 0) {   // (level 5 feeds the dense BEV scatter only)
+            int32_t* ocn = A.take<int32_t>((int64_t)hc[0] * 4);
+            int32_t* n2o = A.take<int32_t>(hc[0]);
+            int32_t* o2n = A.take<int32_t>(hc[0]);
+            NEED_ARENA();
+            CK(regroup_level(lvl_out, oc, hc[0], oshape, ocn, n2o, o2n));
+            co[lvl_out] = ocn;
+            pm[lvl_out] = n2o;   // (rows came out in ascending key order: sorted position == old row)
+            row_new[lvl_out] = n2o;
+            row_orig[lvl_out] = o2n;
+        }
         return INSMOS_OK;
     };
     {
@@ -524,7 +590,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     CK(insmos_build_current_points_part(pts_host, n_pts_host, B, ld, motion, 4, inverse, cur_index, ncur, cur, 8, 2, s));
     CK(link_streams(s2_coords, s));
     CK(insmos_voxelize_windows_phased(cur, ncur, 8, g.in_ch, cur_start_dev, B, key_cells1, g.range, g.vs, g.max_voxels, g.max_points,
-                                      feat, 8, coords1, num_points, pcid, ukeys, uperm, counts, vox_ws, vox_wsb, 2, s));
+                                      feat, 8, const_cast<int32_t*>(coords1_r), const_cast<int32_t*>(num_points_r), pcid, ukeys, uperm,
+                                      counts, vox_ws, vox_wsb, 2, s));
 
     // ---- encoder (spconv_unet.py:297-306)
     float* x0 = A.take<float>(V * 16);
@@ -633,8 +700,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     int32_t* scratch = A.take<int32_t>(insmos_boxes_to_onehot_scratch_ints_b(g.post_max, B, nvmax));
     auto onehot = [&](int level, float mult, float* o, int ldo, int col) -> int {
         if (nv[level] == 0) return INSMOS_OK;
-        return insmos_boxes_to_onehot_b(pb, pl, cnt_k, g.post_max, B, g.range, g.vs, 8.0f, mult, co[level], nv[level], ncls, 16,
-                                        g.quirk_exact, o + col, ldo, scratch, s);
+        // ("first voxel inside a box" is order-dependent in the reference: it is taken in the reference's row order)
+        return insmos_boxes_to_onehot_rows(pb, pl, cnt_k, g.post_max, B, g.range, g.vs, 8.0f, mult, co[level], row_orig[level],
+                                           row_new[level], nv[level], ncls, 16, g.quirk_exact, o + col, ldo, scratch, s);
     };
     // UR_block_forward up to (not including) conv_inv; catm[:, 0:C] already holds x_bottom
     auto ur_block = [&](int lvl, int Cc, const float* x_lat, int ld_lat, float* catm, float* m) -> int {
@@ -749,6 +817,15 @@ extern "C" int insmos_forward_window(void* ctx, const float* pts, int64_t N, int
 extern "C" int insmos_forward_streams(int mask) {
     if (mask < -1 || mask > 15) return INSMOS_EINVAL;
     tl_stream_mask = mask;
+    return INSMOS_OK;
+}
+
+// row regrouping of the 3D levels (coords.hip: insmos_regroup_rows3d[_global]), one decimal digit per level 4..1: 0 = off, 1 / 2 / 3 =
+// blocks of 256 / 1024 / 4096 rows, 4 = whole windows; -1 = back to the default (INSMOS_REGROUP_ROWS, else kRegroupDefault).
+// Process-wide; the outputs do not depend on it (tests/test_gpu_model.py).
+extern "C" int insmos_forward_regroup(int modes) {
+    if (modes != -1 && !regroup_modes_ok(modes)) return INSMOS_EINVAL;
+    g_regroup = modes;
     return INSMOS_OK;
 }
 

@@ -401,7 +401,11 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
                                                      const int32_t* __restrict__ coords, int64_t n,
                                                      int32_t* __restrict__ first, const BoxVox* __restrict__ bv, int ncls,
                                                      int quirk, uint32_t* __restrict__ vbits,
-                                                     unsigned long long* __restrict__ inside) {
+                                                     unsigned long long* __restrict__ inside,
+                                                     const int32_t* __restrict__ orig_of_row,
+                                                     const int32_t* __restrict__ row_of_orig) {
+    // orig_of_row / row_of_orig (both or neither): the rows were re-ordered (coords.hip: insmos_regroup_rows3d) -- "first hit"
+    // means first in the ORIGINAL row order, the one the reference walks (Array_Index.cpp:40-56)
     const int b0 = blockIdx.y * 64;
     __shared__ BoxVox sb[64];
     __shared__ int sfirst[64];
@@ -414,6 +418,7 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
     int4 q = make_int4(-1, 0, 0, 0);
     if (livej) q = *(const int4*)(coords + j * 4);  // [b,z,y,x]
     const int x = q.w, y = q.z, z = q.y;
+    const int jo = (livej && orig_of_row) ? orig_of_row[j] : (int)j;   // this voxel's place in the reference's walk
     // PASS 0 does the geometry once and leaves, per voxel and 64-box chunk, the bitmask of boxes containing it;
     // PASS 1 only walks those bits (typically none) and applies the order-dependent rule.
     unsigned long long* im = inside + (size_t)blockIdx.y * (size_t)n + (livej ? j : 0);
@@ -429,7 +434,7 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
                 const int f = first[g0 + threadIdx.x];
                 sfirst[threadIdx.x] = f;
                 if (f != 0x7fffffff) {
-                    int4 fq = *(const int4*)(coords + (int64_t)f * 4);
+                    int4 fq = *(const int4*)(coords + (int64_t)(row_of_orig ? row_of_orig[f] : f) * 4);
                     sfx[threadIdx.x] = fq.w; sfy[threadIdx.x] = fq.z; sfz[threadIdx.x] = fq.y;
                 }
             }
@@ -441,7 +446,7 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
             for (int i = 0; i < nb; ++i) {
                 if (inside_box(sb[i], x, y, z)) {
                     hit |= 1ull << i;
-                    atomicMin(&first[g0 + i], (int)j);
+                    atomicMin(&first[g0 + i], jo);
                 }
             }
             *im = hit;
@@ -453,7 +458,7 @@ __global__ void __launch_bounds__(256) k_onehot_scan(const int32_t* __restrict__
                 hit &= hit - 1;
                 const BoxVox& bb = sb[i];
                 const int f = sfirst[i];
-                if (quirk && j != f) {
+                if (quirk && jo != f) {
                     // Array_Index.cpp:48-51: once a first hit exists (rows after it), skip voxels farther than
                     // extend[d] from the first-hit voxel.  (f <= j here: f is the smallest inside row.)
                     if (x > (sfx[i] + bb.e[0]) || x < (sfx[i] - bb.e[0]) || y > (sfy[i] + bb.e[1]) || y < (sfy[i] - bb.e[1]) ||
@@ -712,13 +717,16 @@ extern "C" size_t insmos_boxes_to_onehot_scratch_ints(int max_boxes, int64_t n) 
 
 // B windows: pred arrays (B, max_boxes, .), n_boxes_dev (B, 4) int32 (slot 0), voxel rows window-major with the window in
 // coords[:, 0]; a voxel is tested against its own window's boxes only.
-extern "C" int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
-                                        int max_boxes, int B, const float* range_lo_host, const float* vsize_host, float stride,
-                                        float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
-                                        int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
+// insmos_boxes_to_onehot_b over RE-ORDERED rows (insmos_regroup_rows3d): orig_of_row[r] = the row's place in the reference's
+// order, row_of_orig = its inverse (both null: the rows are in the reference's order).  Rows must still be window-major.
+extern "C" int insmos_boxes_to_onehot_rows(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                                           int max_boxes, int B, const float* range_lo_host, const float* vsize_host, float stride,
+                                           float mult, const int32_t* coords, const int32_t* orig_of_row,
+                                           const int32_t* row_of_orig, int64_t n, int ncls, int pad_to, int quirk_exact,
+                                           float* out, int ld_out, int32_t* scratch, void* stream) {
     if (n <= 0) return INSMOS_OK;
     if (!pred_boxes || !pred_labels || !n_boxes_dev || max_boxes <= 0 || !coords || !out || !scratch || ncls <= 0 ||
-        ncls > 31 || pad_to < ncls || ld_out < pad_to || B < 1 || B > INSMOS_MAX_BATCH)
+        ncls > 31 || pad_to < ncls || ld_out < pad_to || B < 1 || B > INSMOS_MAX_BATCH || (!orig_of_row != !row_of_orig))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     OneHotP P;
@@ -739,12 +747,20 @@ extern "C" int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* 
                        max_boxes, B, P, first, bv);
     dim3 grid(cdiv(n, 256), cdiv(max_boxes, 64));
     INSMOS_LAUNCH(k_onehot_scan<0>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
-                       quirk_exact, vbits, inside);
+                       quirk_exact, vbits, inside, orig_of_row, row_of_orig);
     INSMOS_LAUNCH(k_onehot_scan<1>, grid, dim3(256), 0, s, n_boxes_dev, max_boxes, coords, n, first, bv, ncls,
-                       quirk_exact, vbits, inside);
+                       quirk_exact, vbits, inside, orig_of_row, row_of_orig);
     INSMOS_LAUNCH(k_onehot_write, dim3(cdiv(n * pad_to, 256)), dim3(256), 0, s, vbits, n, ncls, pad_to, out, ld_out);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_boxes_to_onehot_b(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,
+                                        int max_boxes, int B, const float* range_lo_host, const float* vsize_host, float stride,
+                                        float mult, const int32_t* coords, int64_t n, int ncls, int pad_to,
+                                        int quirk_exact, float* out, int ld_out, int32_t* scratch, void* stream) {
+    return insmos_boxes_to_onehot_rows(pred_boxes, pred_labels, n_boxes_dev, max_boxes, B, range_lo_host, vsize_host, stride, mult,
+                                       coords, nullptr, nullptr, n, ncls, pad_to, quirk_exact, out, ld_out, scratch, stream);
 }
 
 extern "C" int insmos_boxes_to_onehot(const float* pred_boxes, const int64_t* pred_labels, const int32_t* n_boxes_dev,

@@ -381,3 +381,93 @@ def test_packed_sort_keys_give_the_pair_sort_results(n_per, B):
                                        scratch[3].data_ptr(), counts.data_ptr(), w_.data_ptr(), w_.numel(), 2, stream()) == 0
     torch.cuda.synchronize()
     assert int(counts[3]) == 1
+
+
+@pytest.mark.parametrize("block", [256, 1024, 4096, 1 << 30])
+def test_regroup_rows_is_a_blockwise_signature_sort(block):
+    """insmos_regroup_rows3d: inside every block of `block` consecutive rows the rows come out sorted by (window, 27-bit
+    submanifold tap signature, old row); new_of_old is a permutation that never leaves its block; new_coords follows it.  And the point of it:
+    the submanifold map built on the new order has fewer active (16-row group, tap) slots than on the old one.
+    insmos_regroup_apply_voxels renames the voxeliser's arrays accordingly (-1 entries stay)."""
+    from gpu_util import dev, hp, i32, lib, stream, ws
+    L = lib()
+    rng = np.random.default_rng(5)
+    shape, B = (7, 64, 80), 2
+    cells = shape[0] * shape[1] * shape[2]
+    # surface-like occupancy: a few noisy sheets, so that neighbourhoods are neither empty nor full
+    per = []
+    for b in range(B):
+        zz, yy, xx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+        sheet = np.abs(zz - (2 + b + 2 * np.sin(yy / 9.0) + np.cos(xx / 7.0))) < 0.8
+        sheet &= rng.random(sheet.shape) < 0.8
+        per.append(np.flatnonzero(sheet.ravel()))
+    coords = np.concatenate([np.concatenate([np.full((len(c), 1), b), np.stack(np.unravel_index(c, shape), 1)], 1)
+                             for b, c in enumerate(per)], 0).astype(np.int32)
+    keys = np.concatenate([b * cells + c for b, c in enumerate(per)]).astype(np.uint64)
+    n = len(coords)
+    assert n > 2 * block or block >= 4096
+    shp = i32(shape)
+    nw = int(L.insmos_rankmap_words(hp(shp), B))
+    bits = torch.zeros(nw, dtype=torch.int64, device="cuda")
+    incl = torch.zeros(nw // 4, dtype=torch.int32, device="cuda")
+    w = ws(L.insmos_rankmap_ws_bytes(hp(shp), B))
+    assert L.insmos_rankmap_from_keys(dev(keys.view(np.int64)).data_ptr(), n, hp(shp), B, bits.data_ptr(), incl.data_ptr(), w.data_ptr(),
+                                      w.numel(), stream()) == 0
+    cd = dev(coords)
+    newc = torch.full((n, 4), -1, dtype=torch.int32, device="cuda")
+    n2o = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    o2n = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    w2 = ws(L.insmos_regroup_ws_bytes(n))
+    assert L.insmos_regroup_rows3d(cd.data_ptr(), n, bits.data_ptr(), hp(shp), 512, newc.data_ptr(), n2o.data_ptr(), None, w2.data_ptr(),
+                                   w2.numel(), stream()) != 0
+    if block == 1 << 30:   # whole windows: one stable sort
+        assert L.insmos_regroup_rows3d_global(cd.data_ptr(), n, bits.data_ptr(), hp(shp), newc.data_ptr(), n2o.data_ptr(), o2n.data_ptr(),
+                                              w2.data_ptr(), w2.numel(), stream()) == 0
+    else:
+        assert L.insmos_regroup_rows3d(cd.data_ptr(), n, bits.data_ptr(), hp(shp), block, newc.data_ptr(), n2o.data_ptr(), o2n.data_ptr(),
+                                       w2.data_ptr(), w2.numel(), stream()) == 0
+    torch.cuda.synchronize()
+    n2o_h, newc_h = n2o.cpu().numpy().astype(np.int64), newc.cpu().numpy()
+    np.testing.assert_array_equal(n2o_h[o2n.cpu().numpy()], np.arange(n))
+    assert np.all(np.diff(newc_h[:, 0]) >= 0)          # window-major rows stay window-major
+    np.testing.assert_array_equal(np.sort(n2o_h), np.arange(n))
+    np.testing.assert_array_equal(n2o_h // block, np.arange(n) // block)
+    np.testing.assert_array_equal(newc_h[n2o_h], coords)
+    occ = set(keys.tolist())
+    sig = np.zeros(n, np.int64)
+    k = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                q = coords[:, 1:].astype(np.int64) + np.array([dz, dy, dx])
+                ok = np.all((q >= 0) & (q < np.array(shape)), axis=1)
+                kk = coords[:, 0].astype(np.int64) * cells + (q[:, 0] * shape[1] + q[:, 1]) * shape[2] + q[:, 2]
+                hit = np.array([o and (int(v) in occ) for o, v in zip(ok, kk)])
+                sig |= hit.astype(np.int64) << k
+                k += 1
+    old_of_new = np.empty(n, np.int64)
+    old_of_new[n2o_h] = np.arange(n)
+    for s0 in range(0, n, block):
+        seg = old_of_new[s0:s0 + block]
+        want = s0 + np.lexsort((np.arange(len(seg)), sig[s0:s0 + block], coords[s0:s0 + block, 0]))   # window, signature, old row
+        np.testing.assert_array_equal(seg, want)
+
+    def active_slots(order):
+        pres = np.stack([(sig[order] >> t) & 1 for t in range(27)]).astype(bool)
+        pad = (-n) % 16
+        pres = np.concatenate([pres, np.zeros((27, pad), bool)], 1).reshape(27, -1, 16)
+        return int(pres.any(2).sum())
+    assert active_slots(old_of_new) < 0.97 * active_slots(np.arange(n))
+    # the voxeliser's arrays under the renaming
+    num = rng.integers(1, 6, n).astype(np.int32)
+    uperm = rng.permutation(n).astype(np.int32)
+    uperm[rng.choice(n, 17, replace=False)] = -1
+    pcid = rng.integers(-1, n, 3 * n).astype(np.int64)
+    num_new = torch.zeros(n, dtype=torch.int32, device="cuda")
+    up_d, pc_d = dev(uperm), dev(pcid)
+    assert L.insmos_regroup_apply_voxels(n2o.data_ptr(), n, dev(num).data_ptr(), num_new.data_ptr(), up_d.data_ptr(), n, pc_d.data_ptr(),
+                                         3 * n, stream()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(num_new.cpu().numpy()[n2o_h], num)
+    np.testing.assert_array_equal(up_d.cpu().numpy(), np.where(uperm >= 0, n2o_h[np.maximum(uperm, 0)], -1))
+    np.testing.assert_array_equal(pc_d.cpu().numpy(), np.where(pcid >= 0, n2o_h[np.maximum(pcid, 0)], -1))

@@ -132,6 +132,34 @@ def test_windows_in_flight_match_sequential(setup):
             assert torch.equal(p1[0][0][k], pr[k]), k
 
 
+def test_row_regrouping_does_not_change_the_outputs(setup):
+    """The runner re-orders the rows of its 3D levels by tap signature (insmos_regroup_rows3d / _global); every voxel's value is
+    a function of its own taps in tap order, and the one order-dependent rule downstream (the first voxel inside a box,
+    Array_Index.cpp:40-56) is evaluated in the reference's row order -- so logits and boxes are the same bits for every mode and
+    with the regrouping off, for one window and for a launch set of three."""
+    from insmos_amd.synth import make_window
+    model = setup["model"]
+    lib = model.model.engine.lib
+    wins = [torch.from_numpy(make_window(seed=40 + i, n_scans=5 + i, n_az=192 + 32 * i)).cuda() for i in range(3)]
+    got = {}
+    try:
+        for blk in (0, 1111, 2222, 3333, 4444, 4012):   # one digit per level 4..1: off / 256 / 1024 / 4096-row blocks / whole windows
+            assert lib.insmos_forward_regroup(blk) == 0
+            p1, _, l1 = model.forward([{"past_point_clouds": wins[0]}], "test")
+            p3, _, l3 = model.forward([{"past_point_clouds": w} for w in wins], "test")
+            torch.cuda.synchronize()
+            got[blk] = ([l.clone() for l in l1 + l3], [{k: v.clone() for k, v in p[0].items()} for p in p1 + p3])
+        assert lib.insmos_forward_regroup(7) != 0 and lib.insmos_forward_regroup(44444) != 0
+    finally:
+        lib.insmos_forward_regroup(-1)
+    for blk in (1111, 2222, 3333, 4444, 4012):
+        for a, b in zip(got[0][0], got[blk][0]):
+            assert torch.equal(a, b), blk
+        for a, b in zip(got[0][1], got[blk][1]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (blk, k)
+
+
 def test_eval_mode_is_test_mode_plus_the_two_losses(setup):
     """Model_mode 'eval' (models/models.py:347-353, 369-373): same predictions as 'test', MOSLoss of the point logits and of
     the motion features against past_labels[-1] (oracle: ref_ops.mos_loss on the oracle's own logits / current_point),
