@@ -292,7 +292,9 @@ int insmos_build_nbr_rank_sparse(const int32_t* out_coords, int64_t n_out, const
  * (16-row group, tap) slot any row of the group uses; rows are re-ordered inside blocks of block_rows (256 / 1024 / 4096)
  * consecutive rows by their 27-bit submanifold tap signature so that a group's rows want the same taps.
  *   insmos_regroup_rows3d: coords (n, 4) (b, z, y, x), bits = the level's rank-map bitmap -> new_coords (n, 4), new_of_old (n),
- *   old_of_new (n).  The window index leads the sort key: window-major rows stay window-major.
+ *   old_of_new (n).  Sort key inside a block: (window, signature, parity class of (z, y, x), old row) -- window-major rows stay
+ *   window-major; rows of equal signature are grouped by parity, which decides the valid taps of the strided / inverse maps.
+ *   block_rows < 0: (window, parity class, signature, old row) in blocks of -block_rows.
  *   insmos_regroup_apply_voxels: the voxeliser's level-1 arrays under that renaming (num_points copied to its new rows,
  *   uperm and pc_voxel_id renamed in place; -1 entries stay). */
 size_t insmos_regroup_ws_bytes(int64_t n);   /* workspace of either form */
@@ -639,7 +641,8 @@ int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts,
  * sets in flight the sets already overlap each other and the caller switches it off (insmos_amd/models.py). */
 int insmos_forward_streams(int mask);
 /* Row regrouping of the runner's 3D levels 1..4, one decimal digit per level (level 1 = units): 0 = off, 1 = blocks of 256 rows,
- * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global); -1 = default (environment
+ * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global), 5 = 4096-row blocks with the
+ * coordinate parity class above the signature (block_rows -4096); -1 = default (environment
  * variable INSMOS_REGROUP_ROWS, else the built-in choice).  Process-wide.  The outputs do not depend on it. */
 int insmos_forward_regroup(int modes);
 int insmos_debug_table_limit(int64_t bytes); /* tests only: lower the table size at which a batch is refused (0 = default) */

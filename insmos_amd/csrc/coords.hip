@@ -1607,17 +1607,27 @@ __global__ void k_regroup_sig(const int32_t* __restrict__ coords, int64_t n, con
     if (o >= n) return;
     sig[o] = tap_signature(*(const int4*)(coords + o * 4), bits, D, H, W);
 }
+// sort key of a row inside its block: window first (rows stay window-major), then the signature, then the coordinate PARITY class
+// -- rows of equal signature come out grouped by parity, which is what decides a row's valid taps in the strided / inverse maps
+// (tap k of an inverse 3^3 stride-2 map exists only where (coordinate + pad - k) is even: <= 8 of 27 taps per parity class); free
+// for the submanifold maps.  PARITY_FIRST: parity above the signature -- the inverse map of the level becomes near-dense (3-4
+// active taps per group instead of 9-14) at the price of ~11 % more active slots in its submanifold maps.
+__device__ __forceinline__ uint64_t regroup_key(const int4 c, uint32_t sig, bool parity_first) {
+    const uint64_t par = (uint64_t)(((c.y & 1) << 2) | ((c.z & 1) << 1) | (c.w & 1));
+    const uint64_t body = parity_first ? (par << 27) | (uint64_t)sig : ((uint64_t)sig << 3) | par;
+    return ((uint64_t)c.x << 30) | body;   // 4 + 30 bits
+}
 template <int NB>
 __global__ void __launch_bounds__(1024) k_regroup_rows(const int32_t* __restrict__ coords, int64_t n, const uint32_t* __restrict__ sig,
-                                                       int32_t* __restrict__ new_coords, int32_t* __restrict__ new_of_old,
-                                                       int32_t* __restrict__ old_of_new) {
+                                                       int parity_first, int32_t* __restrict__ new_coords,
+                                                       int32_t* __restrict__ new_of_old, int32_t* __restrict__ old_of_new) {
     __shared__ uint64_t key[NB];
     constexpr int NT = NB < 2048 ? NB / 2 : 1024;   // threads: one comparator each, or two (NB = 4096)
     const int64_t base = (int64_t)blockIdx.x * NB;
     for (int i = threadIdx.x; i < NB; i += NT) {
         const int64_t o = base + i;
-        // window first: rows stay window-major.  Rows past the end sort last.
-        key[i] = o < n ? ((uint64_t)coords[o * 4] << 43) | ((uint64_t)sig[o] << 16) | (uint64_t)i : ~0ull;
+        // (rows past the end sort last)
+        key[i] = o < n ? (regroup_key(*(const int4*)(coords + o * 4), sig[o], parity_first != 0) << 16) | (uint64_t)i : ~0ull;
     }
     __syncthreads();
     for (int size = 2; size <= NB; size <<= 1)
@@ -1654,6 +1664,8 @@ extern "C" int insmos_regroup_rows3d(const int32_t* coords, int64_t n, const uin
                                      void* stream) {
     if (n <= 0) return INSMOS_OK;
     if (!coords || !bits || !shape_host || !new_coords || !new_of_old || !ws || n >= (1ll << 31)) return INSMOS_EINVAL;
+    const int parity_first = block_rows < 0 ? 1 : 0;   // (negative block size: parity class above the signature)
+    if (block_rows < 0) block_rows = -block_rows;
     if (block_rows != 256 && block_rows != 1024 && block_rows != 4096) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     Bump b(ws, ws_bytes);
@@ -1662,11 +1674,14 @@ extern "C" int insmos_regroup_rows3d(const int32_t* coords, int64_t n, const uin
     ProfScope ps(KK_BUILD_NBR, s);
     INSMOS_LAUNCH(k_regroup_sig, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, coords, n, bits, shape_host[0], shape_host[1], shape_host[2], sig);
     if (block_rows == 256)
-        INSMOS_LAUNCH(k_regroup_rows<256>, dim3(cdiv(n, 256)), dim3(128), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+        INSMOS_LAUNCH(k_regroup_rows<256>, dim3(cdiv(n, 256)), dim3(128), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
+                      old_of_new);
     else if (block_rows == 1024)
-        INSMOS_LAUNCH(k_regroup_rows<1024>, dim3(cdiv(n, 1024)), dim3(512), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+        INSMOS_LAUNCH(k_regroup_rows<1024>, dim3(cdiv(n, 1024)), dim3(512), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
+                      old_of_new);
     else
-        INSMOS_LAUNCH(k_regroup_rows<4096>, dim3(cdiv(n, 4096)), dim3(1024), 0, s, coords, n, sig, new_coords, new_of_old, old_of_new);
+        INSMOS_LAUNCH(k_regroup_rows<4096>, dim3(cdiv(n, 4096)), dim3(1024), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
+                      old_of_new);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -1679,7 +1694,7 @@ __global__ void k_regroup_keys(const int32_t* __restrict__ coords, int64_t n, co
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n) return;
     const int4 c = *(const int4*)(coords + o * 4);
-    keys[o] = ((uint64_t)o << PK_KEY_BITS) | ((uint64_t)c.x << 27) | (uint64_t)tap_signature(c, bits, D, H, W);
+    keys[o] = ((uint64_t)o << PK_KEY_BITS) | regroup_key(c, tap_signature(c, bits, D, H, W), false);
 }
 __global__ void k_regroup_scatter(const uint64_t* __restrict__ keys_s, const int32_t* __restrict__ coords, int64_t n,
                                   int32_t* __restrict__ new_coords, int32_t* __restrict__ new_of_old, int32_t* __restrict__ old_of_new) {
@@ -1704,7 +1719,7 @@ extern "C" int insmos_regroup_rows3d_global(const int32_t* coords, int64_t n, co
     if (!b.ok) return INSMOS_EWORKSPACE;
     ProfScope ps(KK_BUILD_NBR, s);
     INSMOS_LAUNCH(k_regroup_keys, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, coords, n, bits, shape_host[0], shape_host[1], shape_host[2], k_in);
-    int rc = sort_keys_u64(tmp, st, k_in, k_s, (size_t)n, 0, 27 + 4, s);   // (window < 16: 4 bits above the 27 signature bits); stable
+    int rc = sort_keys_u64(tmp, st, k_in, k_s, (size_t)n, 0, 34, s);   // (regroup_key: window, signature, parity); stable
     if (rc) return rc;
     INSMOS_LAUNCH(k_regroup_scatter, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, k_s, coords, n, new_coords, new_of_old, old_of_new);
     HIP_TRY(hipGetLastError());

@@ -58,11 +58,11 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 
 struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
 int g_regroup = -1;                 // row regrouping modes of the 3D levels (insmos_forward_regroup); -1 = not read yet
-constexpr int kRegroupDefault = 3333;   // every level: blocks of 4096 rows (measured against 1024-row blocks and whole windows)
+constexpr int kRegroupDefault = 3553;   // 4096-row blocks; levels 2 and 3 with the parity class above the signature (their inverse maps feed 64- and 32-channel layers; measured)
 inline bool regroup_modes_ok(int v) {
-    if (v < 0 || v > 4444) return false;
+    if (v < 0 || v > 5555) return false;
     for (int l = 0; l < 4; ++l, v /= 10)
-        if (v % 10 > 4) return false;
+        if (v % 10 > 5) return false;
     return true;
 }
 int64_t g_table_limit = 1ll << 31;  // bytes a neighbour table may span (32-bit offsets); lowered by tests (insmos_debug_table_limit)
@@ -471,7 +471,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         g_regroup = regroup_modes_ok(v) ? v : 0;
     }
     const int regroup = g_regroup;
-    // level l's mode = the l-th decimal digit (insmos_forward_regroup): 0 off, 1 / 2 / 3 = blocks of 256 / 1024 / 4096 rows, 4 = windows
+    // level l's mode = the l-th decimal digit (insmos_forward_regroup): 0 off, 1 / 2 / 3 = blocks of 256 / 1024 / 4096 rows, 4 = windows,
+    // 5 = blocks of 4096 rows with the parity class above the signature
     auto regroup_level = [&](int lvl, const int32_t* c_old, int64_t nrows, const int32_t* shp, int32_t* c_new, int32_t* n2o,
                              int32_t* o2n) -> int {
         int m = regroup;
@@ -482,7 +483,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         void* ws = A.take<char>(wsb);
         NEED_ARENA();
         if (m == 4) CK(insmos_regroup_rows3d_global(c_old, nrows, rbits[lvl], shp, c_new, n2o, o2n, ws, wsb, s));
-        else CK(insmos_regroup_rows3d(c_old, nrows, rbits[lvl], shp, m == 1 ? 256 : m == 2 ? 1024 : 4096, c_new, n2o, o2n, ws, wsb, s));
+        else CK(insmos_regroup_rows3d(c_old, nrows, rbits[lvl], shp, m == 1 ? 256 : m == 2 ? 1024 : m == 3 ? 4096 : -4096, c_new, n2o, o2n,
+                                      ws, wsb, s));
         A.off = mark;
         return INSMOS_OK;
     };
@@ -821,7 +823,8 @@ extern "C" int insmos_forward_streams(int mask) {
 }
 
 // row regrouping of the 3D levels (coords.hip: insmos_regroup_rows3d[_global]), one decimal digit per level 4..1: 0 = off, 1 / 2 / 3 =
-// blocks of 256 / 1024 / 4096 rows, 4 = whole windows; -1 = back to the default (INSMOS_REGROUP_ROWS, else kRegroupDefault).
+// blocks of 256 / 1024 / 4096 rows, 4 = whole windows, 5 = 4096-row blocks sorted by parity class first; -1 = back to the default
+// (INSMOS_REGROUP_ROWS, else kRegroupDefault).
 // Process-wide; the outputs do not depend on it (tests/test_gpu_model.py).
 extern "C" int insmos_forward_regroup(int modes) {
     if (modes != -1 && !regroup_modes_ok(modes)) return INSMOS_EINVAL;

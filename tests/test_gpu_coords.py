@@ -386,7 +386,7 @@ def test_packed_sort_keys_give_the_pair_sort_results(n_per, B):
 @pytest.mark.parametrize("block", [256, 1024, 4096, 1 << 30])
 def test_regroup_rows_is_a_blockwise_signature_sort(block):
     """insmos_regroup_rows3d: inside every block of `block` consecutive rows the rows come out sorted by (window, 27-bit
-    submanifold tap signature, old row); new_of_old is a permutation that never leaves its block; new_coords follows it.  And the point of it:
+    submanifold tap signature, coordinate parity class, old row); new_of_old is a permutation that never leaves its block; new_coords follows it.  And the point of it:
     the submanifold map built on the new order has fewer active (16-row group, tap) slots than on the old one.
     insmos_regroup_apply_voxels renames the voxeliser's arrays accordingly (-1 entries stay)."""
     from gpu_util import dev, hp, i32, lib, stream, ws
@@ -449,8 +449,22 @@ def test_regroup_rows_is_a_blockwise_signature_sort(block):
     old_of_new[n2o_h] = np.arange(n)
     for s0 in range(0, n, block):
         seg = old_of_new[s0:s0 + block]
-        want = s0 + np.lexsort((np.arange(len(seg)), sig[s0:s0 + block], coords[s0:s0 + block, 0]))   # window, signature, old row
+        cb = coords[s0:s0 + block]
+        par = (cb[:, 1] & 1) * 4 + (cb[:, 2] & 1) * 2 + (cb[:, 3] & 1)
+        want = s0 + np.lexsort((np.arange(len(seg)), par, sig[s0:s0 + block], cb[:, 0]))   # window, signature, parity, old row
         np.testing.assert_array_equal(seg, want)
+
+    if block == 4096:   # parity class above the signature (block_rows < 0)
+        n2o_p = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        assert L.insmos_regroup_rows3d(cd.data_ptr(), n, bits.data_ptr(), hp(shp), -4096, newc.data_ptr(), n2o_p.data_ptr(), None,
+                                       w2.data_ptr(), w2.numel(), stream()) == 0
+        torch.cuda.synchronize()
+        oon = np.empty(n, np.int64)
+        oon[n2o_p.cpu().numpy().astype(np.int64)] = np.arange(n)
+        for s0 in range(0, n, block):
+            cb = coords[s0:s0 + block]
+            par = (cb[:, 1] & 1) * 4 + (cb[:, 2] & 1) * 2 + (cb[:, 3] & 1)
+            np.testing.assert_array_equal(oon[s0:s0 + block], s0 + np.lexsort((np.arange(len(cb)), sig[s0:s0 + block], par, cb[:, 0])))
 
     def active_slots(order):
         pres = np.stack([(sig[order] >> t) & 1 for t in range(27)]).astype(bool)

@@ -143,16 +143,16 @@ def test_row_regrouping_does_not_change_the_outputs(setup):
     wins = [torch.from_numpy(make_window(seed=40 + i, n_scans=5 + i, n_az=192 + 32 * i)).cuda() for i in range(3)]
     got = {}
     try:
-        for blk in (0, 1111, 2222, 3333, 4444, 4012):   # one digit per level 4..1: off / 256 / 1024 / 4096-row blocks / whole windows
+        for blk in (0, 1111, 2222, 3333, 4444, 5555, 4012):   # one digit per level 4..1: off / 256 / 1024 / 4096-row blocks / whole windows / parity first
             assert lib.insmos_forward_regroup(blk) == 0
             p1, _, l1 = model.forward([{"past_point_clouds": wins[0]}], "test")
             p3, _, l3 = model.forward([{"past_point_clouds": w} for w in wins], "test")
             torch.cuda.synchronize()
             got[blk] = ([l.clone() for l in l1 + l3], [{k: v.clone() for k, v in p[0].items()} for p in p1 + p3])
-        assert lib.insmos_forward_regroup(7) != 0 and lib.insmos_forward_regroup(44444) != 0
+        assert lib.insmos_forward_regroup(7) != 0 and lib.insmos_forward_regroup(55555) != 0
     finally:
         lib.insmos_forward_regroup(-1)
-    for blk in (1111, 2222, 3333, 4444, 4012):
+    for blk in (1111, 2222, 3333, 4444, 5555, 4012):
         for a, b in zip(got[0][0], got[blk][0]):
             assert torch.equal(a, b), blk
         for a, b in zip(got[0][1], got[blk][1]):
