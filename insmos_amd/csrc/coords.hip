@@ -996,6 +996,87 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// The constant-input first layer (MODE 1 above) on an OCCUPANCY CUBE instead of per-tap table arithmetic.  The 5^3 taps of a voxel
+// with parities (px, py, pz) inside its parent are cells [p, p + 4] per axis of the 6^3 fine cells covered by the parent's 3^3
+// coarse neighbourhood; the 27 neighbours' 8-bit child masks are spread into six z-planes of 6 x 6 occupancy bits (static
+// shifts), the plane of tap offset dz is picked by pz and shifted by 6 * py + px once -- after which tap (dz, dy, dx) is bit
+// 6 * (dy + 2) + (dx + 2) of word T[dz + 2]: a compile-time bit.  A wave-wide OR of the five words tells, in scalar registers,
+// which taps any of the wave's 64 voxels has; the others are skipped without a vector instruction.  Same sums, same order
+// (k ascending, fmaf(sel, w[k], acc), bias last): the same bits as k_resolve_taps<2, 1, 1>.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_const_conv125(const int32_t* __restrict__ coords, int64_t n_f,
+                                                       const int32_t* __restrict__ parent, int L,
+                                                       const int32_t* __restrict__ cnbr, int64_t n_c,
+                                                       const uint32_t* __restrict__ child_mask, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int ld_out,
+                                                       int relu) {
+    const int64_t o_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = o_raw < n_f;
+    const int64_t o = live ? o_raw : n_f - 1;
+    const int4 c = *(const int4*)(coords + o * 4);
+    const int px = (c.x >> L) & 1, py = (c.y >> L) & 1, pz = (c.z >> L) & 1;
+    const int p = parent[o];
+    // plane z' (0..5): rows y' = 0..2 in lo[z'] (6 bits each), rows 3..5 in hi[z']
+    uint32_t lo[6] = {0u, 0u, 0u, 0u, 0u, 0u}, hi[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ibz = 0; ibz < 3; ++ibz)
+#pragma unroll
+        for (int iby = 0; iby < 3; ++iby)
+#pragma unroll
+            for (int ibx = 0; ibx < 3; ++ibx) {
+                const int ctap = ibx + 3 * iby + 9 * ibz + 27;   // (dt = 0 slab of the coarse 81-tap table)
+                const int q = cnbr[(int64_t)ctap * n_c + p];
+                const uint32_t m = q >= 0 ? (child_mask[q] & 0xFFu) : 0u;   // bit (x | y << 1 | z << 2)
+#pragma unroll
+                for (int oz = 0; oz < 2; ++oz)
+#pragma unroll
+                    for (int oy = 0; oy < 2; ++oy) {
+                        const uint32_t two = (m >> (oz * 4 + oy * 2)) & 3u;
+                        const int zz = 2 * ibz + oz, yy = 2 * iby + oy;
+                        if (yy < 3) lo[zz] |= two << (6 * yy + 2 * ibx);
+                        else hi[zz] |= two << (6 * (yy - 3) + 2 * ibx);
+                    }
+            }
+    uint32_t T[5], U[5];
+    const int sh = 6 * py + px;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {   // tap offset dz = d - 2 reads plane pz + d
+        const uint32_t l = pz ? lo[d + 1] : lo[d], h = pz ? hi[d + 1] : hi[d];
+        const uint64_t plane = (uint64_t)l | ((uint64_t)h << 18);
+        T[d] = (uint32_t)(plane >> sh);
+        uint32_t u = T[d];
+#pragma unroll
+        for (int x = 1; x < 64; x <<= 1) u |= (uint32_t)__shfl_xor((int)u, x);
+        U[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+    }
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    int k = 0;
+#pragma unroll
+    for (int d = 0; d < 5; ++d)
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx, ++k) {
+                const int b = 6 * dy + dx;
+                if ((U[d] >> b) & 1u) {   // (wave-uniform: a scalar branch)
+                    const float sel = ((T[d] >> b) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(sel, w[k * 8 + i], acc[i]);
+                }
+            }
+    if (live) {
+        float* op = out + o * ld_out;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = acc[i] + bias[i];
+            op[i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
 // first row of each trailing time slice of a sorted 4D key array: starts[d] = first row with t >= t_last - d
 __global__ void k_tslice_starts(const uint64_t* __restrict__ keys, int64_t n, int max_d, int32_t* __restrict__ starts) {
     const int d = threadIdx.x;
@@ -1859,9 +1940,14 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 125; ps.meta[1] = 1; ps.meta[2] = 8; ps.meta[3] = n_f;
-    INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
-                       fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
-                       w125x8, bias8, out, ld_out, relu, (int64_t)0);
+    static const bool cube = [] { const char* e = getenv("INSMOS_CONV0_CUBE"); return !(e && e[0] == '0'); }();
+    if (cube)
+        INSMOS_LAUNCH(k_const_conv125, dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, coarse_nbr81, n_c,
+                      child_mask, w125x8, bias8, out, ld_out, relu);
+    else   // (the per-tap resolver, kept as the A/B reference: same bits)
+        INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
+                           fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
+                           w125x8, bias8, out, ld_out, relu, (int64_t)0);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
