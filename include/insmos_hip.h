@@ -122,6 +122,12 @@ int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, co
                                      const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
                                      const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
                                      int ld_out, int relu, void* stream);
+/* ... on occupancy cubes (coords.hip: k_parent_cubes / k_const_conv125): cubes_ws = 48 bytes of scratch per COARSE voxel, 16-byte
+ * aligned (null = the per-tap resolver above); same bits, 1.5x faster on the S0 windows. */
+int insmos_const_conv125_cubes(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                               const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
+                               const float* w125x8, const float* bias8, float* out, int ld_out, int relu, void* cubes_ws,
+                               void* stream);
 int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift, int64_t n_c,
                        const int32_t* child_start, const uint32_t* child_mask, int32_t* dn, uint32_t* dn_mask16,
                        int32_t* up, uint32_t* up_mask16, void* stream);

@@ -1001,23 +1001,17 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
 // with parities (px, py, pz) inside its parent are cells [p, p + 4] per axis of the 6^3 fine cells covered by the parent's 3^3
 // coarse neighbourhood; the 27 neighbours' 8-bit child masks are spread into six z-planes of 6 x 6 occupancy bits (static
 // shifts), the plane of tap offset dz is picked by pz and shifted by 6 * py + px once -- after which tap (dz, dy, dx) is bit
-// 6 * (dy + 2) + (dx + 2) of word T[dz + 2]: a compile-time bit.  A wave-wide OR of the five words tells, in scalar registers,
+// 6 * (dy + 2) + (dx + 2) of word T[dz + 2]: a compile-time bit.  The planes are built once per COARSE voxel (k_parent_cubes: all
+// children of a parent see the same cube).  A wave-wide OR of the five words tells, in scalar registers,
 // which taps any of the wave's 64 voxels has; the others are skipped without a vector instruction.  Same sums, same order
 // (k ascending, fmaf(sel, w[k], acc), bias last): the same bits as k_resolve_taps<2, 1, 1>.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_const_conv125(const int32_t* __restrict__ coords, int64_t n_f,
-                                                       const int32_t* __restrict__ parent, int L,
-                                                       const int32_t* __restrict__ cnbr, int64_t n_c,
-                                                       const uint32_t* __restrict__ child_mask, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ out, int ld_out,
-                                                       int relu) {
-    const int64_t o_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = o_raw < n_f;
-    const int64_t o = live ? o_raw : n_f - 1;
-    const int4 c = *(const int4*)(coords + o * 4);
-    const int px = (c.x >> L) & 1, py = (c.y >> L) & 1, pz = (c.z >> L) & 1;
-    const int p = parent[o];
-    // plane z' (0..5): rows y' = 0..2 in lo[z'] (6 bits each), rows 3..5 in hi[z']
+// Part 1, one thread per COARSE voxel: its 27 neighbours' child masks spread into the six occupancy planes (rows y' 0..2 in lo,
+// 3..5 in hi: 18 bits each), 12 words per coarse voxel.  The cube is the same for all of a parent's children.
+__global__ void __launch_bounds__(256) k_parent_cubes(const int32_t* __restrict__ cnbr, int64_t n_c,
+                                                      const uint32_t* __restrict__ child_mask, uint32_t* __restrict__ cubes) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_c) return;
     uint32_t lo[6] = {0u, 0u, 0u, 0u, 0u, 0u}, hi[6] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int ibz = 0; ibz < 3; ++ibz)
@@ -1038,6 +1032,26 @@ __global__ void __launch_bounds__(256) k_const_conv125(const int32_t* __restrict
                         else hi[zz] |= two << (6 * (yy - 3) + 2 * ibx);
                     }
             }
+    uint4* cp = (uint4*)(cubes + p * 12);
+    cp[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    cp[1] = make_uint4(lo[4], lo[5], hi[0], hi[1]);
+    cp[2] = make_uint4(hi[2], hi[3], hi[4], hi[5]);
+}
+// Part 2, one thread per fine voxel: its parent's cube (48 contiguous bytes, shared by the siblings), planes picked by pz and
+// shifted by 6 * py + px, taps as compile-time bits.
+__global__ void __launch_bounds__(256) k_const_conv125(const int32_t* __restrict__ coords, int64_t n_f,
+                                                       const int32_t* __restrict__ parent, int L,
+                                                       const uint32_t* __restrict__ cubes, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int ld_out,
+                                                       int relu) {
+    const int64_t o_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = o_raw < n_f;
+    const int64_t o = live ? o_raw : n_f - 1;
+    const int4 c = *(const int4*)(coords + o * 4);
+    const int px = (c.x >> L) & 1, py = (c.y >> L) & 1, pz = (c.z >> L) & 1;
+    const uint4* cp = (const uint4*)(cubes + (int64_t)parent[o] * 12);
+    const uint4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+    const uint32_t lo[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y}, hi[6] = {c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
     uint32_t T[5], U[5];
     const int sh = 6 * py + px;
 #pragma unroll
@@ -1053,20 +1067,22 @@ __global__ void __launch_bounds__(256) k_const_conv125(const int32_t* __restrict
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    int k = 0;
+    // (one scalar branch per x-ROW of five taps, not per tap: the row's 40 weights arrive with one batch of scalar loads; a tap the
+    //  wave does not have inside a live row adds exact zeros)
 #pragma unroll
     for (int d = 0; d < 5; ++d)
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy)
+        for (int dy = 0; dy < 5; ++dy) {
+            if ((U[d] >> (6 * dy)) & 31u) {   // (wave-uniform)
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx, ++k) {
-                const int b = 6 * dy + dx;
-                if ((U[d] >> b) & 1u) {   // (wave-uniform: a scalar branch)
-                    const float sel = ((T[d] >> b) & 1u) ? 1.0f : 0.0f;
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int k = (d * 5 + dy) * 5 + dx;
+                    const float sel = ((T[d] >> (6 * dy + dx)) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) acc[i] = fmaf(sel, w[k * 8 + i], acc[i]);
                 }
             }
+        }
     if (live) {
         float* op = out + o * ld_out;
 #pragma unroll
@@ -1934,17 +1950,25 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
                                                 const int32_t* child_start, const uint32_t* child_mask,
                                                 const float* w125x8, const float* bias8, float* out, int ld_out, int relu,
                                                 void* stream) {
+    return insmos_const_conv125_cubes(fine_coords, n_f, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, w125x8, bias8,
+                                      out, ld_out, relu, nullptr, stream);
+}
+// the same with 48 bytes of scratch per COARSE voxel (cubes_ws, 16-byte aligned; null = the per-tap resolver): occupancy cubes
+extern "C" int insmos_const_conv125_cubes(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
+                                          const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
+                                          const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
+                                          int ld_out, int relu, void* cubes_ws, void* stream) {
     if (n_f <= 0 || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start || !child_mask || !w125x8 ||
-        !bias8 || !out || ld_out < 8 || fine_shift < 0 || fine_shift > 14)
+        !bias8 || !out || ld_out < 8 || fine_shift < 0 || fine_shift > 14 || ((uintptr_t)cubes_ws & 15))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 125; ps.meta[1] = 1; ps.meta[2] = 8; ps.meta[3] = n_f;
-    static const bool cube = [] { const char* e = getenv("INSMOS_CONV0_CUBE"); return !(e && e[0] == '0'); }();
-    if (cube)
-        INSMOS_LAUNCH(k_const_conv125, dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift, coarse_nbr81, n_c,
-                      child_mask, w125x8, bias8, out, ld_out, relu);
-    else   // (the per-tap resolver, kept as the A/B reference: same bits)
+    if (cubes_ws) {
+        INSMOS_LAUNCH(k_parent_cubes, dim3(cdiv(n_c, TPB)), dim3(TPB), 0, s, coarse_nbr81, n_c, child_mask, (uint32_t*)cubes_ws);
+        INSMOS_LAUNCH(k_const_conv125, dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift,
+                      (const uint32_t*)cubes_ws, w125x8, bias8, out, ld_out, relu);
+    } else   // (the per-tap resolver: same bits)
         INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                            fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
                            w125x8, bias8, out, ld_out, relu, (int64_t)0);

@@ -378,8 +378,15 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     CK(insmos_fill_cols(cat7, n[1], 32, 24, 8, 0.0f, s));
     if (!g.w0_const || !g.b0_const) return INSMOS_EINVAL;
     // motionnet.py:29-32: every point carries the feature 0.5 -> conv0 needs no table and no gathers
-    CK(insmos_const_conv125_from_coarse(coords[0], n[0], parent[0], 0, nbr81[1].nbr, n[1], cstart[0], cmask[0], g.w0_const,
-                                        g.b0_const, cat8 + 8, 16, 1, s));
+    {
+        // (occupancy cubes, 48 B per level-1 voxel; INSMOS_CONV0_CUBE=0 keeps the per-tap resolver for A/B runs: same bits)
+        static const bool cube = [] { const char* e = getenv("INSMOS_CONV0_CUBE"); return !(e && e[0] == '0'); }();
+        // (not handed back: what is allocated next is written on the SECOND stream, which is not ordered behind these kernels)
+        void* cubes = cube ? (void*)A.take<uint4>((size_t)n[1] * 3) : nullptr;
+        NEED_ARENA();
+        CK(insmos_const_conv125_cubes(coords[0], n[0], parent[0], 0, nbr81[1].nbr, n[1], cstart[0], cmask[0], g.w0_const, g.b0_const,
+                                      cat8 + 8, 16, 1, cubes, s));
+    }
     CK(conv("conv1p1s2", cat8, n[0], 16, 8, &dn[0], n[1], x1, 8, 0, nullptr, 0, 0, 0, 0, 1));
     // BasicBlock (minkunet.py:63-124): conv1-bn-relu, conv2-bn, (+ downsample(x) | x), relu
     // (output needed `depth` scans back: conv2 / downsample on those rows, conv1 one scan further; depth 99 = all rows)

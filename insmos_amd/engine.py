@@ -498,11 +498,13 @@ class Engine:
         cat6 = E((n[2], 48))  # [convtr5 (32) | out_b2p4 (16)]
         if self.const_input:
             # motionnet.py:29-32: every point carries the feature 0.5 -> conv0 needs no table and no gathers
-            _lib.check(lib.insmos_const_conv125_from_coarse(coords[0].data_ptr(), n[0], parent[0].data_ptr(), 0,
-                                                            nbr81[1].nbr.data_ptr(), n[1], child_start[0].data_ptr(),
-                                                            child_mask[0].data_ptr(), self.w0_const.data_ptr(),
-                                                            self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1, st),
-                       "insmos_const_conv125_from_coarse")
+            cubes = torch.empty(max(n[1], 1) * 12, dtype=torch.int32, device=self.device)   # occupancy cubes, 48 B per coarse voxel
+            _lib.check(lib.insmos_const_conv125_cubes(coords[0].data_ptr(), n[0], parent[0].data_ptr(), 0,
+                                                      nbr81[1].nbr.data_ptr(), n[1], child_start[0].data_ptr(),
+                                                      child_mask[0].data_ptr(), self.w0_const.data_ptr(),
+                                                      self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1,
+                                                      cubes.data_ptr(), st),
+                       "insmos_const_conv125_cubes")
             self._conv_log.append((None, n[0], L["conv0p1s1"], 0))
             self._conv_nin.append(0)   # constant input: nothing is read
         else:
