@@ -75,7 +75,8 @@ int insmos_quantize4d(const float* points, int64_t n, int ld_pts, const float* q
  * Because keys are Morton-in-space this is a prefix de-duplication of the sorted key array.
  *   shift = log2 of the OUTPUT tensor stride (1,2,3).  parent (n) i32 = fine row -> coarse row.
  *   child_start (cap n) i32 = first fine row of each coarse voxel, child_mask (cap n) u32 = which of its
- *   8 octants (x | y<<1 | z<<2) are occupied (both optional).  counts[0] = #coarse voxels.
+ *   8 octants (x | y<<1 | z<<2) are occupied, in its LOW BYTE; bits 8..31 repeat child_start when n < 2^24 (0 otherwise), so
+ *   that the table kernels fetch one word per coarse neighbour (both arrays optional).  counts[0] = #coarse voxels.
  * ---------------------------------------------------------------------------------------------- */
 size_t insmos_level_down4d_ws_bytes(int64_t n);
 int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,

@@ -302,7 +302,9 @@ __global__ void k_level_down_scatter(const uint64_t* __restrict__ keys, const in
                 if ((kj >> shift_bits) != (k >> shift_bits)) break;
                 m |= 1u << (unsigned)((kj >> (shift_bits - 3)) & 7ull);
             }
-            child_mask[vid] = m;
+            // bits 8..31: the first child row again, whenever it fits (n < 2^24) -- the table kernels then fetch ONE word per
+            // coarse neighbour instead of two (k_resolve_taps); readers of the mask alone take the low byte
+            child_mask[vid] = n < (1ll << 24) ? (m | ((uint32_t)i << 8)) : m;
         }
     }
     parent[i] = vid;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(256) k_nbr_from_coarse(const int32_t* __restri
         const int q = cnbr[(int64_t)ctap * n_c + parent[o]];
         if (q >= 0) {
             const unsigned oct = ((nx >> L) & 1) | (((ny >> L) & 1) << 1) | (((nz >> L) & 1) << 2);
-            const uint32_t m = child_mask[q];
+            const uint32_t m = child_mask[q] & 0xFFu;   // (bits 8..31 may carry child_start, see k_level_down_scatter)
             if ((m >> oct) & 1u) r = child_start[q] + __popc(m & ((1u << oct) - 1u));
         }
     }
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(256) k_nbr_down(int64_t n_c, const int32_t* __
                                                   uint32_t* __restrict__ mask16) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = p < n_c;
-    const uint32_t m = ok ? child_mask[p] : 0u;
+    const uint32_t m = ok ? (child_mask[p] & 0xFFu) : 0u;
     const int32_t cs = ok ? child_start[p] : 0;
     int32_t r[8];
 #pragma unroll
@@ -927,7 +929,8 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
         const int ctap = (bx + 1) + 3 * (by + 1) + 9 * (bz + 1) + 27 * (dt + 1);
         const int q = cnbr[(int64_t)ctap * n_c + p];
         uint32_t v = 0u;
-        if (q >= 0) v = ((uint32_t)child_start[q] << 8) | (child_mask[q] & 0xFFu);
+        // (fewer than 2^24 fine rows: the mask word carries child_start above its low byte -- one gather, not two)
+        if (q >= 0) v = n_f < (1ll << 24) ? child_mask[q] : (((uint32_t)child_start[q] << 8) | (child_mask[q] & 0xFFu));
         sl[e][tid] = v;
     }
     // (each thread reads back only its own column: no barrier needed)
@@ -1748,6 +1751,81 @@ __global__ void __launch_bounds__(1024) k_regroup_rows(const int32_t* __restrict
     }
 }
 
+// The 4096-row block on 1024 threads with four keys per thread in REGISTERS (element e = q * 1024 + thread): of the 78
+// compare-exchange steps of the bitonic network only the 18 whose partner sits in another wave (strides 64..512) go through LDS;
+// strides 1..32 are lane exchanges (57 steps, no barrier), strides 1024 / 2048 stay inside the thread.  Keys are distinct (the
+// local row is part of the key), so compare-exchange is min / max.  Same result as k_regroup_rows<4096>; 47 -> 42 us per
+// launch on the S0 sets: lane exchanges of 64-bit keys are ds_bpermute pairs, i.e. the LDS pipe again (one block per CU).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+__global__ void __launch_bounds__(1024) k_regroup_rows4096(const int32_t* __restrict__ coords, int64_t n, const uint32_t* __restrict__ sig,
+                                                           int parity_first, int32_t* __restrict__ new_coords,
+                                                           int32_t* __restrict__ new_of_old, int32_t* __restrict__ old_of_new) {
+    __shared__ uint64_t key[4096];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    uint64_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * 1024 + t;
+        const int64_t o = base + e;
+        v[q] = o < n ? (regroup_key(*(const int4*)(coords + o * 4), sig[o], parity_first != 0) << 16) | (uint64_t)e : ~0ull;
+    }
+    for (int size = 2; size <= 4096; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 1024) {           // partner = another register of this thread
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sq = stride >> 10;   // 1 or 2
+                    if (q & sq) continue;
+                    const bool up = ((q * 1024 + t) & size) == 0;
+                    // (static register indices: both candidate partners are named, the stride picks)
+                    const int qp = q | sq;
+                    uint64_t a = v[q], b = qp == 1 ? v[1] : qp == 2 ? v[2] : v[3];
+                    const bool sw = (a > b) == up;
+                    const uint64_t na = sw ? b : a, nb = sw ? a : b;
+                    v[q] = na;
+                    if (qp == 1) v[1] = nb; else if (qp == 2) v[2] = nb; else v[3] = nb;
+                }
+            } else if (stride < 64) {       // partner = another lane of this wave
+                const bool lower = (t & stride) == 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool up = ((q * 1024 + t) & size) == 0;
+                    const uint64_t p = shfl_xor_u64(v[q], stride);
+                    const uint64_t mn = v[q] < p ? v[q] : p, mx = v[q] < p ? p : v[q];
+                    v[q] = (lower == up) ? mn : mx;
+                }
+            } else {                        // partner = another wave: through LDS
+#pragma unroll
+                for (int q = 0; q < 4; ++q) key[q * 1024 + t] = v[q];
+                __syncthreads();
+                const bool lower = (t & stride) == 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = q * 1024 + t;
+                    const bool up = (e & size) == 0;
+                    const uint64_t p = key[e ^ stride];
+                    const uint64_t mn = v[q] < p ? v[q] : p, mx = v[q] < p ? p : v[q];
+                    v[q] = (lower == up) ? mn : mx;
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t nw = base + q * 1024 + t;
+        if (nw < n) {
+            const int64_t old = base + (int64_t)(v[q] & 0xFFFFull);
+            new_of_old[old] = (int32_t)nw;
+            if (old_of_new) old_of_new[nw] = (int32_t)old;
+            *(int4*)(new_coords + nw * 4) = *(const int4*)(coords + old * 4);
+        }
+    }
+}
+
 // coords (n, 4) int32 (b, z, y, x) of one level, bits = that level's rank-map bitmap (insmos_rankmap_from_keys /
 // insmos_down_coords3d_rank), shape = its (D, H, W).  block_rows in {256, 1024, 4096}.  Writes new_coords (n, 4) = the rows in
 // their new order, new_of_old (n): the new row of each old row, and (optional) old_of_new, its inverse.  Rows of different
@@ -1777,7 +1855,7 @@ extern "C" int insmos_regroup_rows3d(const int32_t* coords, int64_t n, const uin
         INSMOS_LAUNCH(k_regroup_rows<1024>, dim3(cdiv(n, 1024)), dim3(512), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
                       old_of_new);
     else
-        INSMOS_LAUNCH(k_regroup_rows<4096>, dim3(cdiv(n, 4096)), dim3(1024), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
+        INSMOS_LAUNCH(k_regroup_rows4096, dim3(cdiv(n, 4096)), dim3(1024), 0, s, coords, n, sig, parity_first, new_coords, new_of_old,
                       old_of_new);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
