@@ -650,7 +650,8 @@ int insmos_forward_streams(int mask);
 /* Row regrouping of the runner's 3D levels 1..4, one decimal digit per level (level 1 = units): 0 = off, 1 = blocks of 256 rows,
  * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global), 5 = 4096-row blocks with the
  * coordinate parity class above the signature (block_rows -4096); -1 = default (environment
- * variable INSMOS_REGROUP_ROWS, else the built-in choice).  Process-wide.  The outputs do not depend on it. */
+ * variable INSMOS_REGROUP_ROWS, else 3553 for launch sets of two or more windows and off for a single window, whose latency
+ * the block sorts would cost more than the convolutions gain).  Process-wide.  The outputs do not depend on it. */
 int insmos_forward_regroup(int modes);
 int insmos_debug_table_limit(int64_t bytes); /* tests only: lower the table size at which a batch is refused (0 = default) */
 int insmos_forward_windows(void* ctx, const float* const* points_host, const int64_t* n_points_host, int B, int ld_pts,

@@ -57,7 +57,7 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 }
 
 struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
-int g_regroup = -1;                 // row regrouping modes of the 3D levels (insmos_forward_regroup); -1 = not read yet
+int g_regroup = -1;                 // row regrouping modes of the 3D levels set by insmos_forward_regroup; -1 = the default
 constexpr int kRegroupDefault = 3553;   // 4096-row blocks; levels 2 and 3 with the parity class above the signature (their inverse maps feed 64- and 32-channel layers; measured)
 inline bool regroup_modes_ok(int v) {
     if (v < 0 || v > 5555) return false;
@@ -472,12 +472,13 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // row regrouping (coords.hip: k_regroup_rows): every level's rows are re-ordered (inside blocks, or over whole windows) by tap
     // signature, so that the 16 rows of a group want the same taps; the row order of a level is private to this function
     // (features, kernel maps, rank lookups and the point -> voxel map all follow).  INSMOS_REGROUP_ROWS=0 keeps the plain order.
-    if (g_regroup < 0) {
+    // (default: launch sets only -- for ONE window the four block sorts cost more latency, ~0.16 ms, than the convolutions save)
+    static const int regroup_env = [] {
         const char* e = getenv("INSMOS_REGROUP_ROWS");
-        const int v = e ? atoi(e) : kRegroupDefault;
-        g_regroup = regroup_modes_ok(v) ? v : 0;
-    }
-    const int regroup = g_regroup;
+        const int v = e ? atoi(e) : -1;
+        return (e && regroup_modes_ok(v)) ? v : -1;
+    }();
+    const int regroup = g_regroup >= 0 ? g_regroup : regroup_env >= 0 ? regroup_env : (B == 1 ? 0 : kRegroupDefault);
     // level l's mode = the l-th decimal digit (insmos_forward_regroup): 0 off, 1 / 2 / 3 = blocks of 256 / 1024 / 4096 rows, 4 = windows,
     // 5 = blocks of 4096 rows with the parity class above the signature
     auto regroup_level = [&](int lvl, const int32_t* c_old, int64_t nrows, const int32_t* shp, int32_t* c_new, int32_t* n2o,
@@ -831,7 +832,7 @@ extern "C" int insmos_forward_streams(int mask) {
 
 // row regrouping of the 3D levels (coords.hip: insmos_regroup_rows3d[_global]), one decimal digit per level 4..1: 0 = off, 1 / 2 / 3 =
 // blocks of 256 / 1024 / 4096 rows, 4 = whole windows, 5 = 4096-row blocks sorted by parity class first; -1 = back to the default
-// (INSMOS_REGROUP_ROWS, else kRegroupDefault).
+// (INSMOS_REGROUP_ROWS, else kRegroupDefault for launch sets of two windows or more and off for a single window).
 // Process-wide; the outputs do not depend on it (tests/test_gpu_model.py).
 extern "C" int insmos_forward_regroup(int modes) {
     if (modes != -1 && !regroup_modes_ok(modes)) return INSMOS_EINVAL;
