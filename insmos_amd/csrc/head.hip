@@ -215,10 +215,14 @@ __global__ void k_iou3d(const float* __restrict__ a, int na, const float* __rest
     out[t] = ov3 / fmaxf(vol_a + vol_b - ov3, 1e-6f);
 }
 
-// 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed).
-// 256 threads: wave w owns rows rb*64 + 16w .. +15, lane = column; the 64-bit mask word of a row is the
-// wave ballot.  Pairs whose circumscribed circles (grown by the corner MARGIN of check_in_box2d) are
-// disjoint cannot overlap: the reference's clipping yields exactly 0 for them, so they are skipped.
+// 64 x 64 block of the suppression bitmask (only col block >= row block is ever consumed), 256 threads, two phases:
+//   1. every (row, column) pair of the block gets the cheap test -- pairs whose circumscribed circles (grown by the corner MARGIN
+//      of check_in_box2d) are disjoint cannot overlap: the reference's clipping yields exactly 0 for them -- and the pairs that
+//      pass (~0.7 % on LiDAR scenes) are COMPACTED into a list in LDS (wave ballots, one LDS counter);
+//   2. the list is walked with every lane busy: one rotated-IoU evaluation (polygon clipping, ~2000 instructions) per lane, the
+//      result OR-ed into the row's 64-bit word in LDS (order-independent).
+// Before (one phase: a wave ballot per row right after the test) a wave ran the clipping code whenever ANY of its 64 columns was
+// near, i.e. for a third of all (row, 64-column) slots with one or two lanes active.  Same pairs, same function: same words.
 __global__ void __launch_bounds__(256) k_nms_mask(const float* __restrict__ boxes, const int32_t* __restrict__ n_dev,
                                                   int max_n, float thresh, uint64_t* __restrict__ mask) {
     const int win = blockIdx.z;                    // one suppression matrix per window of the batch
@@ -228,34 +232,53 @@ __global__ void __launch_bounds__(256) k_nms_mask(const float* __restrict__ boxe
     const int cbs = (max_n + 63) / 64;
     boxes += (int64_t)win * max_n * 7;
     mask += (int64_t)win * max_n * cbs;
-    __shared__ float rowb[64 * 8];
+    __shared__ float rowb[64 * 8], colb[64 * 8];   // [box][x, y, z, dx, dy, dz, yaw, circle radius]
+    __shared__ unsigned long long words[64];
+    __shared__ uint16_t pairs[64 * 64];            // (row << 6) | column of the block's near pairs
+    __shared__ int n_pairs;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < 64) {
-        const int i = rb * 64 + threadIdx.x;
-        for (int d = 0; d < 7; ++d) rowb[threadIdx.x * 8 + d] = i < n ? boxes[(int64_t)i * 7 + d] : 0.f;
-        rowb[threadIdx.x * 8 + 7] = i < n ? 0.5f * sqrtf(rowb[threadIdx.x * 8 + 3] * rowb[threadIdx.x * 8 + 3] +
-                                                          rowb[threadIdx.x * 8 + 4] * rowb[threadIdx.x * 8 + 4]) + 0.05f
-                                          : 0.f;
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x & 63;
+        float* dst = (threadIdx.x < 64 ? rowb : colb) + t * 8;
+        const int i = (threadIdx.x < 64 ? rb : cb) * 64 + t;
+        for (int d = 0; d < 7; ++d) dst[d] = i < n ? boxes[(int64_t)i * 7 + d] : (d >= 3 && d < 6 ? 1.f : 0.f);
+        dst[7] = i < n ? 0.5f * sqrtf(dst[3] * dst[3] + dst[4] * dst[4]) + 0.05f : 0.f;
+        if (threadIdx.x < 64) words[t] = 0ull;
+        if (threadIdx.x == 0) n_pairs = 0;
     }
     __syncthreads();
     const int j = cb * 64 + lane;
-    float B[7] = {0, 0, 0, 1, 1, 1, 0};
-    float rj = 0.f;
-    if (j < n) {
-        for (int d = 0; d < 7; ++d) B[d] = boxes[(int64_t)j * 7 + d];
-        rj = 0.5f * sqrtf(B[3] * B[3] + B[4] * B[4]) + 0.05f;
-    }
+    const float bx = colb[lane * 8 + 0], by = colb[lane * 8 + 1], rj = colb[lane * 8 + 7];
     for (int r = 0; r < 16; ++r) {
         const int il = w * 16 + r, i = rb * 64 + il;
         if (i >= n) break;  // wave-uniform
         const float* A = rowb + il * 8;
-        bool hit = false;
+        bool near = false;
         if (j < n && j > i) {
-            const float dx = A[0] - B[0], dy = A[1] - B[1], rr = A[7] + rj;
-            if (dx * dx + dy * dy <= rr * rr) hit = iou_bev_dev(A, B) > thresh;
+            const float dx = A[0] - bx, dy = A[1] - by, rr = A[7] + rj;
+            near = dx * dx + dy * dy <= rr * rr;
         }
-        const unsigned long long word = __ballot(hit);
-        if (lane == 0) mask[(int64_t)i * cbs + cb] = word;
+        const unsigned long long bal = __ballot(near);
+        if (bal) {   // (wave-uniform)
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_pairs, __popcll(bal));
+            base = __shfl(base, 0);
+            if (near) pairs[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((il << 6) | lane);
+        }
+    }
+    __syncthreads();
+    const int np = n_pairs;
+    for (int t = threadIdx.x; t < np; t += 256) {
+        const int il = pairs[t] >> 6, cl = pairs[t] & 63;
+        float A[7], B[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { A[d] = rowb[il * 8 + d]; B[d] = colb[cl * 8 + d]; }
+        if (iou_bev_dev(A, B) > thresh) atomicOr(&words[il], 1ull << cl);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = rb * 64 + threadIdx.x;
+        if (i < n) mask[(int64_t)i * cbs + cb] = words[threadIdx.x];
     }
 }
 
