@@ -126,9 +126,16 @@ int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int64_t n_f, co
 /* ... on occupancy cubes (coords.hip: k_parent_cubes / k_const_conv125): cubes_ws = 48 bytes of scratch per COARSE voxel, 16-byte
  * aligned (null = the per-tap resolver above); same bits, 1.5x faster on the S0 windows. */
 int insmos_const_conv125_cubes(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
-                               const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
-                               const float* w125x8, const float* bias8, float* out, int ld_out, int relu, void* cubes_ws,
-                               void* stream);
+                               const int32_t* coarse_nbr81, const uint32_t* coarse_mask16 /* null = fully written table */,
+                               int64_t n_c, const int32_t* child_start, const uint32_t* child_mask, const float* w125x8,
+                               const float* bias8, float* out, int ld_out, int relu, void* cubes_ws, void* stream);
+/* insmos_nbr81_from_coarse_rows from a coarse table that was itself written with SPARSE stores: coarse_mask16 = that table's
+ * mask array (its entries outside a group's mask are unwritten memory and count as "no neighbour"; null = fully written);
+ * sparse_stores != 0 writes this table sparsely too (mask16 required).  Same tables wherever they are defined. */
+int insmos_nbr81_from_coarse_rows_masked(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                         int fine_shift, const int32_t* coarse_nbr81, const uint32_t* coarse_mask16, int64_t n_c,
+                                         const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16,
+                                         int sparse_stores, void* stream);
 int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift, int64_t n_c,
                        const int32_t* child_start, const uint32_t* child_mask, int32_t* dn, uint32_t* dn_mask16,
                        int32_t* up, uint32_t* up_mask16, void* stream);

@@ -32,8 +32,10 @@ SIGNATURES = {
     "insmos_nbr81_from_coarse_rows_sparse": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_const_conv125_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_int, c_int, c_vp]),
-    "insmos_const_conv125_cubes": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+    "insmos_const_conv125_cubes": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_int, c_int, c_vp, c_vp]),
+    "insmos_nbr81_from_coarse_rows_masked": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                                     c_int, c_vp]),
     "insmos_nbr_down_up": (c_int, [c_vp, c_i64, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_build_nbr": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_voxelize_mean_ws_bytes": (c_sz, [c_i64]),

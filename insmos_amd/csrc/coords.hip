@@ -907,7 +907,10 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
                                                       const uint32_t* __restrict__ child_mask,
                                                       int32_t* __restrict__ nbr, uint32_t* __restrict__ mask16,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int ld_out, int relu, int64_t row0) {
+                                                      float* __restrict__ out, int ld_out, int relu, int64_t row0,
+                                                      const uint32_t* __restrict__ cmask16) {
+    // cmask16: the COARSE table's active-tap masks when that table was written with sparse stores (its entries outside a group's
+    // mask are unwritten memory: they are "no neighbour" and must not be read); null = a fully written table
     constexpr int NB = RANGE == 1 ? 2 : 3;       // candidate coarse blocks per axis
     constexpr int E = NB * NB * NB * NDT;        // cached coarse entries per voxel
     constexpr int W1 = 2 * RANGE + 1;
@@ -927,7 +930,8 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
         const int bz = RANGE == 1 ? pz - 1 + ibz : ibz - 1;
         const int dt = NDT == 3 ? idt - 1 : 0;
         const int ctap = (bx + 1) + 3 * (by + 1) + 9 * (bz + 1) + 27 * (dt + 1);
-        const int q = cnbr[(int64_t)ctap * n_c + p];
+        int q = -1;
+        if (!cmask16 || ((cmask16[(int64_t)(p >> 4) * 4 + (ctap >> 5)] >> (ctap & 31)) & 1u)) q = cnbr[(int64_t)ctap * n_c + p];
         uint32_t v = 0u;
         // (fewer than 2^24 fine rows: the mask word carries child_start above its low byte -- one gather, not two)
         if (q >= 0) v = n_f < (1ll << 24) ? child_mask[q] : (((uint32_t)child_start[q] << 8) | (child_mask[q] & 0xFFu));
@@ -1012,9 +1016,13 @@ __global__ void __launch_bounds__(256) k_resolve_taps(const int32_t* __restrict_
 // Part 1, one thread per COARSE voxel: its 27 neighbours' child masks spread into the six occupancy planes (rows y' 0..2 in lo,
 // 3..5 in hi: 18 bits each), 12 words per coarse voxel.  The cube is the same for all of a parent's children.
 __global__ void __launch_bounds__(256) k_parent_cubes(const int32_t* __restrict__ cnbr, int64_t n_c,
-                                                      const uint32_t* __restrict__ child_mask, uint32_t* __restrict__ cubes) {
+                                                      const uint32_t* __restrict__ child_mask, uint32_t* __restrict__ cubes,
+                                                      const uint32_t* __restrict__ cmask16) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_c) return;
+    // (cmask16 as in k_resolve_taps: taps 27..53, the dt = 0 slab, are bits 27..31 of word 0 and 0..21 of word 1)
+    uint32_t mw0 = ~0u, mw1 = ~0u;
+    if (cmask16) { mw0 = cmask16[(p >> 4) * 4 + 0]; mw1 = cmask16[(p >> 4) * 4 + 1]; }
     uint32_t lo[6] = {0u, 0u, 0u, 0u, 0u, 0u}, hi[6] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int ibz = 0; ibz < 3; ++ibz)
@@ -1023,7 +1031,8 @@ __global__ void __launch_bounds__(256) k_parent_cubes(const int32_t* __restrict_
 #pragma unroll
             for (int ibx = 0; ibx < 3; ++ibx) {
                 const int ctap = ibx + 3 * iby + 9 * ibz + 27;   // (dt = 0 slab of the coarse 81-tap table)
-                const int q = cnbr[(int64_t)ctap * n_c + p];
+                const bool written = ((ctap < 32 ? mw0 >> ctap : mw1 >> (ctap - 32)) & 1u) != 0u;
+                const int q = written ? cnbr[(int64_t)ctap * n_c + p] : -1;
                 const uint32_t m = q >= 0 ? (child_mask[q] & 0xFFu) : 0u;   // bit (x | y << 1 | z << 2)
 #pragma unroll
                 for (int oz = 0; oz < 2; ++oz)
@@ -1975,14 +1984,14 @@ extern "C" int insmos_nbr_down_up(const int32_t* fine_coords, int64_t n_f, const
 }
 
 static int nbr81_rows_impl(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent, int fine_shift,
-                           const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
-                           int32_t* nbr, uint32_t* mask16, bool sparse, void* stream);
+                           const int32_t* coarse_nbr81, const uint32_t* coarse_mask16, int64_t n_c, const int32_t* child_start,
+                           const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, bool sparse, void* stream);
 extern "C" int insmos_nbr81_from_coarse_rows(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
                                              int fine_shift, const int32_t* coarse_nbr81, int64_t n_c,
                                              const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr,
                                              uint32_t* mask16, void* stream) {
-    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, false,
-                           stream);
+    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, nullptr, n_c, child_start, child_mask, nbr, mask16,
+                           false, stream);
 }
 // The same table with the entries of inactive (16-row group, tap) pairs left UNWRITTEN (mask16 is required and complete): for
 // consumers that walk a group's taps through its mask only -- insmos_sparse_conv with 16-row tiles -- half the table's bytes.
@@ -1991,12 +2000,22 @@ extern "C" int insmos_nbr81_from_coarse_rows_sparse(const int32_t* fine_coords, 
                                                     const int32_t* child_start, const uint32_t* child_mask, int32_t* nbr,
                                                     uint32_t* mask16, void* stream) {
     if (!mask16) return INSMOS_EINVAL;
-    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, true,
-                           stream);
+    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, nullptr, n_c, child_start, child_mask, nbr, mask16,
+                           true, stream);
+}
+// the same from a coarse table that was itself written with sparse stores: coarse_mask16 = ITS mask array (entries outside a
+// group's mask are unwritten memory and count as "no neighbour"); sparse_stores: write this table sparsely too (mask16 required)
+extern "C" int insmos_nbr81_from_coarse_rows_masked(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent,
+                                                    int fine_shift, const int32_t* coarse_nbr81, const uint32_t* coarse_mask16,
+                                                    int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
+                                                    int32_t* nbr, uint32_t* mask16, int sparse_stores, void* stream) {
+    if (sparse_stores && !mask16) return INSMOS_EINVAL;
+    return nbr81_rows_impl(fine_coords, n_f, row0, parent, fine_shift, coarse_nbr81, coarse_mask16, n_c, child_start, child_mask, nbr,
+                           mask16, sparse_stores != 0, stream);
 }
 static int nbr81_rows_impl(const int32_t* fine_coords, int64_t n_f, int64_t row0, const int32_t* parent, int fine_shift,
-                           const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start, const uint32_t* child_mask,
-                           int32_t* nbr, uint32_t* mask16, bool sparse, void* stream) {
+                           const int32_t* coarse_nbr81, const uint32_t* coarse_mask16, int64_t n_c, const int32_t* child_start,
+                           const uint32_t* child_mask, int32_t* nbr, uint32_t* mask16, bool sparse, void* stream) {
     if (n_f <= 0 || n_f >= (1 << 24) || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start ||
         !child_mask || !nbr || fine_shift < 0 || fine_shift > 14 || row0 < 0)
         return INSMOS_EINVAL;
@@ -2007,11 +2026,11 @@ static int nbr81_rows_impl(const int32_t* fine_coords, int64_t n_f, int64_t row0
     if (sparse)
         INSMOS_LAUNCH((k_resolve_taps<1, 3, 2>), dim3(cdiv(n_f - row0, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift,
                       coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr, (const float*)nullptr,
-                      (float*)nullptr, 0, 0, row0);
+                      (float*)nullptr, 0, 0, row0, coarse_mask16);
     else
     INSMOS_LAUNCH((k_resolve_taps<1, 3, 0>), dim3(cdiv(n_f - row0, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                        fine_shift, coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, 0, 0, row0);
+                       (const float*)nullptr, (float*)nullptr, 0, 0, row0, coarse_mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -2028,14 +2047,14 @@ extern "C" int insmos_const_conv125_from_coarse(const int32_t* fine_coords, int6
                                                 const int32_t* child_start, const uint32_t* child_mask,
                                                 const float* w125x8, const float* bias8, float* out, int ld_out, int relu,
                                                 void* stream) {
-    return insmos_const_conv125_cubes(fine_coords, n_f, parent, fine_shift, coarse_nbr81, n_c, child_start, child_mask, w125x8, bias8,
-                                      out, ld_out, relu, nullptr, stream);
+    return insmos_const_conv125_cubes(fine_coords, n_f, parent, fine_shift, coarse_nbr81, nullptr, n_c, child_start, child_mask, w125x8,
+                                      bias8, out, ld_out, relu, nullptr, stream);
 }
 // the same with 48 bytes of scratch per COARSE voxel (cubes_ws, 16-byte aligned; null = the per-tap resolver): occupancy cubes
 extern "C" int insmos_const_conv125_cubes(const int32_t* fine_coords, int64_t n_f, const int32_t* parent, int fine_shift,
-                                          const int32_t* coarse_nbr81, int64_t n_c, const int32_t* child_start,
-                                          const uint32_t* child_mask, const float* w125x8, const float* bias8, float* out,
-                                          int ld_out, int relu, void* cubes_ws, void* stream) {
+                                          const int32_t* coarse_nbr81, const uint32_t* coarse_mask16, int64_t n_c,
+                                          const int32_t* child_start, const uint32_t* child_mask, const float* w125x8,
+                                          const float* bias8, float* out, int ld_out, int relu, void* cubes_ws, void* stream) {
     if (n_f <= 0 || n_c <= 0 || !fine_coords || !parent || !coarse_nbr81 || !child_start || !child_mask || !w125x8 ||
         !bias8 || !out || ld_out < 8 || fine_shift < 0 || fine_shift > 14 || ((uintptr_t)cubes_ws & 15))
         return INSMOS_EINVAL;
@@ -2043,13 +2062,14 @@ extern "C" int insmos_const_conv125_cubes(const int32_t* fine_coords, int64_t n_
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 125; ps.meta[1] = 1; ps.meta[2] = 8; ps.meta[3] = n_f;
     if (cubes_ws) {
-        INSMOS_LAUNCH(k_parent_cubes, dim3(cdiv(n_c, TPB)), dim3(TPB), 0, s, coarse_nbr81, n_c, child_mask, (uint32_t*)cubes_ws);
+        INSMOS_LAUNCH(k_parent_cubes, dim3(cdiv(n_c, TPB)), dim3(TPB), 0, s, coarse_nbr81, n_c, child_mask, (uint32_t*)cubes_ws,
+                      coarse_mask16);
         INSMOS_LAUNCH(k_const_conv125, dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift,
                       (const uint32_t*)cubes_ws, w125x8, bias8, out, ld_out, relu);
     } else   // (the per-tap resolver: same bits)
         INSMOS_LAUNCH((k_resolve_taps<2, 1, 1>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent,
                            fine_shift, coarse_nbr81, n_c, child_start, child_mask, (int32_t*)nullptr, (uint32_t*)nullptr,
-                           w125x8, bias8, out, ld_out, relu, (int64_t)0);
+                           w125x8, bias8, out, ld_out, relu, (int64_t)0, coarse_mask16);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

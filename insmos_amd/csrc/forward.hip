@@ -309,6 +309,18 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // ones) and deriving the stride-8 table from it costs a third of searching stride 8; a single window gains nothing (one more
     // count read-back), so it searches stride 8 directly.
     static const bool deep_tables = [] { const char* e = getenv("INSMOS_TABLES_LEVEL4"); return !(e && e[0] == '0'); }();
+    // Sparse stores for the FINEST table (read by the convolutions only): an entry of a (16-row group, tap) slot outside the
+    // group's active-tap mask is never read by the 16-row-tile kernels, so it is not written.  The coarser tables are written in
+    // full -- measured: with sparse stores at every level (the derivations then read the coarse table through its mask array,
+    // insmos_nbr81_from_coarse_rows_masked, tests/test_gpu_coords.py) the resolver's per-tap ballots and the mask loads in front of
+    // every coarse entry cost more than the stores they save (2.39 -> 2.61 ms per 7 launch sets; masks on fully written tables:
+    // 2.95).  The first layer's cubes do take the mask array of the level-1 table (a slot outside the mask is "no neighbour" for
+    // all 16 rows, known without loading the entry: 118 -> 106 us).  INSMOS_TABLES_DENSE=1 writes everything.
+    static const bool sparse_tab = [] {
+        const char* e = getenv("INSMOS_TABLES_DENSE");
+        const char* jt = getenv("INSMOS_CK_JT");
+        return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
+    }();
     if (deep_tables && B >= 2) {
         const int64_t np = n[3];
         uint64_t* keys4 = A.take<uint64_t>(np);
@@ -335,14 +347,6 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (the level-0 table is read by block8 only -- rows of the last two scans, at the very end of the branch: it is built on
         //  the second stream, off the convolution chain)
         if (l == 0) CK(link_streams(s, s2_tab0));
-        // (sparse stores for the FINEST table only: entries outside a 16-row group's active-tap mask are never read by the 16-row-tile
-        //  convolution kernels -- but a coarser table is also the input of the next finer one's derivation and of the first layer's
-        //  tap resolver, which read every entry)
-        static const bool sparse_tab = [] {
-            const char* e = getenv("INSMOS_TABLES_DENSE");
-            const char* jt = getenv("INSMOS_CK_JT");
-            return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
-        }();
         CK(((sparse_tab && l == 0) ? insmos_nbr81_from_coarse_rows_sparse : insmos_nbr81_from_coarse_rows)(
             coords[l], n[l], l == 0 ? row_from(0, 1) : 0, parent[l], l, nbr81[l + 1].nbr, n[l + 1], cstart[l], cmask[l], nbr81[l].nbr,
             nbr81[l].mask, l == 0 ? s2_tab0 : s));
@@ -384,8 +388,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (not handed back: what is allocated next is written on the SECOND stream, which is not ordered behind these kernels)
         void* cubes = cube ? (void*)A.take<uint4>((size_t)n[1] * 3) : nullptr;
         NEED_ARENA();
-        CK(insmos_const_conv125_cubes(coords[0], n[0], parent[0], 0, nbr81[1].nbr, n[1], cstart[0], cmask[0], g.w0_const, g.b0_const,
-                                      cat8 + 8, 16, 1, cubes, s));
+        CK(insmos_const_conv125_cubes(coords[0], n[0], parent[0], 0, nbr81[1].nbr, nbr81[1].mask, n[1], cstart[0], cmask[0], g.w0_const,
+                                      g.b0_const, cat8 + 8, 16, 1, cubes, s));
     }
     CK(conv("conv1p1s2", cat8, n[0], 16, 8, &dn[0], n[1], x1, 8, 0, nullptr, 0, 0, 0, 0, 1));
     // BasicBlock (minkunet.py:63-124): conv1-bn-relu, conv2-bn, (+ downsample(x) | x), relu

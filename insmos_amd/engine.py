@@ -482,7 +482,8 @@ class Engine:
                        "insmos_nbr_down_up")
             dn.append(NbrTable(d_nb, d_mk))
             up.append(NbrTable(u_nb, u_mk))
-        self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse)
+        self._me_tables = dict(nbr125=nbr125, nbr81=nbr81, dn=dn, up=up, coords=coords, keys=keys, inverse=inverse,
+                               parent=parent, child_start=child_start, child_mask=child_mask)
         if self.tables_only:
             return None
 
@@ -500,7 +501,7 @@ class Engine:
             # motionnet.py:29-32: every point carries the feature 0.5 -> conv0 needs no table and no gathers
             cubes = torch.empty(max(n[1], 1) * 12, dtype=torch.int32, device=self.device)   # occupancy cubes, 48 B per coarse voxel
             _lib.check(lib.insmos_const_conv125_cubes(coords[0].data_ptr(), n[0], parent[0].data_ptr(), 0,
-                                                      nbr81[1].nbr.data_ptr(), n[1], child_start[0].data_ptr(),
+                                                      nbr81[1].nbr.data_ptr(), None, n[1], child_start[0].data_ptr(),
                                                       child_mask[0].data_ptr(), self.w0_const.data_ptr(),
                                                       self.b0_const.data_ptr(), cat8.data_ptr() + 4 * 8, 16, 1,
                                                       cubes.data_ptr(), st),

@@ -485,3 +485,60 @@ def test_regroup_rows_is_a_blockwise_signature_sort(block):
     np.testing.assert_array_equal(num_new.cpu().numpy()[n2o_h], num)
     np.testing.assert_array_equal(up_d.cpu().numpy(), np.where(uperm >= 0, n2o_h[np.maximum(uperm, 0)], -1))
     np.testing.assert_array_equal(pc_d.cpu().numpy(), np.where(pcid >= 0, n2o_h[np.maximum(pcid, 0)], -1))
+
+
+def test_tables_derived_from_sparsely_stored_coarse_tables(window, engine):
+    """A 4D table written with sparse stores (entries outside a 16-row group's active-tap mask stay unwritten) is a valid INPUT of
+    the next finer level's derivation and of the first layer's occupancy cubes when the readers get its mask array
+    (insmos_nbr81_from_coarse_rows_masked, insmos_const_conv125_cubes): same fine table / same masks / same first-layer output as
+    from the fully written table.  The unwritten entries are prefilled with garbage row numbers here."""
+    from gpu_util import dev, lib, stream
+    L = lib()
+    engine.const_input = True
+    engine.prune_dead_rows = False
+    try:
+        engine.motionnet(dev(window))
+    finally:
+        engine.prune_dead_rows = True
+    torch.cuda.synchronize()
+    T = engine._me_tables
+    n = [int(c.shape[0]) for c in T["coords"]]
+    garbage = 0x3FFFFFF0
+    for lv in (2, 1, 0):   # derive level lv from level lv + 1
+        dense_c = T["nbr81"][lv + 1]
+        nc, nf = n[lv + 1], n[lv]
+        # the coarse table again, sparsely stored over garbage, from ITS coarse level (or as a masked copy at the top)
+        cs = torch.full((81, nc), garbage, dtype=torch.int32, device="cuda")
+        grp_mask = dense_c.mask16.view(torch.int32)   # (groups, 4)
+        tap = torch.arange(81, device="cuda")
+        bit = (grp_mask[:, (tap // 32).long()] >> (tap % 32).int()) & 1       # (groups, 81)
+        live = bit.bool().repeat_interleave(16, dim=0)[:nc].t()               # (81, nc)
+        cs[live] = dense_c.nbr[live]
+        fine = torch.full((81, nf), -9, dtype=torch.int32, device="cuda")
+        fmask = torch.zeros(((nf + 15) // 16, 4), dtype=torch.int32, device="cuda")
+        args = (T["coords"][lv].data_ptr(), nf, 0, T["parent"][lv].data_ptr(), lv, cs.data_ptr(), dense_c.mask16.data_ptr(), nc,
+                T["child_start"][lv].data_ptr(), T["child_mask"][lv].data_ptr(), fine.data_ptr(), fmask.data_ptr())
+        assert L.insmos_nbr81_from_coarse_rows_masked(*args, 0, stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(fine, T["nbr81"][lv].nbr)
+        assert torch.equal(fmask, T["nbr81"][lv].mask16.view(torch.int32))
+        # ... and written sparsely itself: the same wherever its own mask has the tap, untouched elsewhere
+        fine_s = torch.full((81, nf), -9, dtype=torch.int32, device="cuda")
+        fmask_s = torch.zeros_like(fmask)
+        args_s = args[:10] + (fine_s.data_ptr(), fmask_s.data_ptr())
+        assert L.insmos_nbr81_from_coarse_rows_masked(*args_s, 1, stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(fmask_s, fmask)
+        bit_f = (fmask[:, (tap // 32).long()] >> (tap % 32).int()) & 1
+        live_f = bit_f.bool().repeat_interleave(16, dim=0)[:nf].t()
+        assert torch.equal(fine_s[live_f], fine[live_f]) and bool((fine_s[~live_f] == -9).all())
+        if lv == 0:   # the first layer from the sparsely stored level-1 table
+            out_ref = engine._me_debug["cat8"][:, 8:16]
+            out = torch.zeros((nf, 16), dtype=torch.float32, device="cuda")
+            cubes = torch.empty(nc * 12, dtype=torch.int32, device="cuda")
+            assert L.insmos_const_conv125_cubes(T["coords"][0].data_ptr(), nf, T["parent"][0].data_ptr(), 0, cs.data_ptr(),
+                                                dense_c.mask16.data_ptr(), nc, T["child_start"][0].data_ptr(),
+                                                T["child_mask"][0].data_ptr(), engine.w0_const.data_ptr(), engine.b0_const.data_ptr(),
+                                                out.data_ptr() + 32, 16, 1, cubes.data_ptr(), stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(out[:, 8:16], out_ref)
