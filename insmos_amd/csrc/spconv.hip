@@ -804,6 +804,8 @@ ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
     if (ck == 0 && split == 1 && cot == 2 && jt == 1) return k_sparse_conv<2, 1, 0, false, 3, 1, false, DBG>;
     if (ck == 0 && split == 1 && cot == 4 && jt == 1) return k_sparse_conv<4, 1, 0, false, 2, 1, false, DBG>;
     if (ck == 0 && split == 4 && cot == 8 && by_chunk) return k_sparse_conv<8, 1, 0, false, 2, 4, true, DBG>;
+    if (ck == 0 && split == 4 && cot == 4 && by_chunk) return k_sparse_conv<4, 1, 0, false, 2, 4, true, DBG>;    // C = 64 layers
+    if (ck == 0 && split == 4 && cot == 2 && !by_chunk) return k_sparse_conv<2, 1, 0, false, 3, 4, false, DBG>;  // C = 32, tap split
     return nullptr;
 }
 ConvKernel pick_forced(int cot, int jt, int ring) {
