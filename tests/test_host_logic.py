@@ -429,6 +429,32 @@ def test_precision_modes_are_refused_unless_known():
     assert lib.insmos_debug_dw_kernel(2) == 0
 
 
+def test_runner_scheduling_knobs_are_validated_on_the_host():
+    """insmos_forward_regroup takes one decimal digit per 3D level (0 off, 1 / 2 / 3 = blocks of 256 / 1024 / 4096 rows, 4 = whole
+    windows, 5 = parity class first; -1 = default) and insmos_forward_streams a 4-bit mask (-1 = default); anything else is
+    refused.  Workspace sizes of the regrouping entry points are pure host arithmetic."""
+    from insmos_amd import _lib
+    lib = _lib.load()
+    try:
+        for ok in (0, 5, 3553, 4444, 1000, 5555, -1):
+            assert lib.insmos_forward_regroup(ok) == 0, ok
+        for bad in (6, 16, 3563, 9000, 55555, -2):
+            assert lib.insmos_forward_regroup(bad) != 0, bad
+        for ok in (0, 15, 2, -1):
+            assert lib.insmos_forward_streams(ok) == 0, ok
+        for bad in (16, -2, 99):
+            assert lib.insmos_forward_streams(bad) != 0, bad
+    finally:
+        lib.insmos_forward_regroup(-1)
+        lib.insmos_forward_streams(-1)
+    assert lib.insmos_regroup_ws_bytes(0) == 0
+    small, big = lib.insmos_regroup_ws_bytes(1000), lib.insmos_regroup_ws_bytes(300000)
+    assert 16 * 1000 <= small < big and big >= 16 * 300000        # two key arrays + the sort's scratch
+    # null / unsupported arguments never reach a launch
+    assert lib.insmos_regroup_rows3d(None, 10, None, None, 4096, None, None, None, None, 0, None) != 0
+    assert lib.insmos_regroup_rows3d(None, 0, None, None, 4096, None, None, None, None, 0, None) == 0      # nothing to do
+
+
 def test_overlapped_reducer_contract_one_backward_per_reduce_and_close():
     """overlap=True: a second backward before reduce() would write into a bucket whose all-reduce is in flight -> it raises;
     close() removes the hooks (a second reducer over the same parameters then sees every gradient exactly once)."""
