@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- scans/sec of the InsMOS inference hot path on MI355X.
 
-A "step" is one forward() over a batch of `--windows-per-step` different windows (each N=10 pose-aligned
+A "step" is one forward() over a batch of `--windows-per-step` windows (each N=10 pose-aligned
 scans, ~1.2 M points in, per-point MOS logits + boxes out) with the inputs already resident in HBM:
 BASELINE.json configs[1] (synthetic S0); the model runs them as launch sets of
 INSMOS_WINDOWS_PER_LAUNCH windows (one set of kernel launches per group), INSMOS_WINDOWS_IN_FLIGHT sets at a time.
-One process per GPU; ranks hold different windows (seeds rank*W ..) and there is no data-path collective -- the only exchange is the all_gather of the 3x3 confusion counters at the
+One process per GPU; rank r holds the S0-style window of seed r and there is no data-path collective -- the only exchange is the all_gather of the 3x3 confusion counters at the
 end of the timed region.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3     # no launcher around it: starts the 8 ranks itself (maybe_spawn_ranks)
+    python bench.py --gpus 2 --backend gloo --device-index 0   # dry run of the multi-rank line on a one-GPU box
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -161,6 +163,35 @@ def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync):
     return dt, value, cm_all
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(n, argv, port=None):
+    """`python bench.py --gpus N ...` outside a launcher: the command that starts N ranks of this script on this node
+    (one process per GPU, rendezvous on 127.0.0.1), exactly the form the bench contract names."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_spawn_ranks(args, argv):
+    """--gpus N > 1 without a launcher's environment: start the N ranks here and pass their output through.  Inside a launcher
+    (WORLD_SIZE set) --gpus must agree with it: an 8-GPU line must never be a 1-GPU measurement in disguise."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus > 1:
+            import subprocess
+            sys.stdout.flush()
+            raise SystemExit(subprocess.call(spawn_command(args.gpus, argv)))
+        return
+    if int(world_env) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks; pass --gpus {world_env} "
+                         "(or run `python bench.py --gpus N` without a launcher: it starts the N ranks itself)")
+
+
 def read_profile(lib):
     ids = (ctypes.c_int * 64)()
     ms = (ctypes.c_double * 64)()
@@ -191,6 +222,10 @@ def main():
                          "warm-up and the timed steps and nothing else -- every kernel launch in the trace belongs to a step")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="extra sustained loop after the timed steps")
     ap.add_argument("--layer-times", type=str, default=None, help="write per-conv-launch timings (CSV) here")
+    ap.add_argument("--mixed-seeds", action="store_true",
+                    help="the step's slots hold DIFFERENT windows (seeds rank*W .. rank*W+W-1: ~10 % less executed work on average "
+                         "than S0) instead of W device copies of the rank's own S0-style window; reported as value_mixed_seeds by "
+                         "the default run")
     ap.add_argument("--windows-per-step", type=int, default=None, help="batch items of one forward() = one step (default 32 = four launch sets of 8 in flight; cfg4: 4)")
     ap.add_argument("--conv-precision", type=int, default=0, choices=[0, 3],
                     help="EXPERIMENT ONLY (the line is then labelled as such and is not the benchmark): 3 = split-bf16 x 3 "
@@ -199,7 +234,11 @@ def main():
                                                                "dry run of this script on a one-GPU box)")
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; the dry run puts "
                                                                     "every rank on GPU 0)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check (no GPU needed with --backend gloo): start / join the ranks, all-reduce a counter, print the "
+                         "world the backend saw and exit -- what tests/test_host_logic.py runs through `bench.py --gpus 2` here")
     args = ap.parse_args()
+    maybe_spawn_ranks(args, sys.argv[1:])
     cfg4 = args.config == "cfg4"
     if args.n_az is None:
         args.n_az = 4710 if cfg4 else 1886
@@ -217,11 +256,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     gpu = local_rank if args.device_index is None else args.device_index
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        seen = 1
+        if world > 1:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            one = torch.ones(1, dtype=torch.int64)
+            if args.backend != "gloo":
+                torch.cuda.set_device(gpu)
+                one = one.cuda(gpu)
+            dist.all_reduce(one)
+            seen = int(one.item())
+            assert seen == dist.get_world_size() == args.gpus, (seen, dist.get_world_size(), args.gpus)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": seen, "backend": args.backend if world > 1 else None}), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(gpu)
         dist.init_process_group(args.backend, rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     dev = f"cuda:{gpu}"
     torch.cuda.set_device(gpu)
     host_cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
@@ -244,12 +303,17 @@ def main():
         cfg["MODEL"]["MAP_TO_BEV"]["NUM_BEV_FEATURES"] = 640
         cfg["MODEL"]["DENSE_HEAD"]["TARGET_ASSIGNER_CONFIG"]["VOXEL_SIZE"] = [0.05, 0.05, 0.05]
     sd = P.random_state_dict(cfg, seed=4 if cfg4 else 0)
-    # one step = one forward() over a batch of `windows_per_step` DIFFERENT windows (seeds rank*W .. rank*W+W-1);
-    # InsMOS_Model keeps up to INSMOS_WINDOWS_IN_FLIGHT of them in flight (threads + streams, same device weights)
+    # one step = one forward() over a batch of W slots.  Headline workload: every slot holds the rank's S0-style
+    # window -- seed = rank, so N = 1 is the survey's scene S0 itself (cfg-2) and N ranks hold seeds 0 .. N-1 (cfg-3) -- as W
+    # SEPARATE device buffers (nothing is shared between slots; the model runs each like any other window).  --mixed-seeds: slots
+    # hold different windows.  InsMOS_Model keeps up to INSMOS_WINDOWS_IN_FLIGHT launch sets in flight (threads + streams).
     W = max(1, args.windows_per_step)
-    windows = load_windows([rank * W + i for i in range(W)], args.n_az)
+    seeds = [rank * W + i for i in range(W)] if args.mixed_seeds else [rank] * W
+    uniq = load_windows(sorted(set(seeds)), args.n_az)
+    by_seed = dict(zip(sorted(set(seeds)), uniq))
+    windows = [by_seed[sd_] for sd_ in seeds]
     window = windows[0]
-    pts_list = [torch.from_numpy(w).to(dev) for w in windows]
+    pts_list = [torch.from_numpy(w).to(dev).clone() for w in windows]
     pts = pts_list[0]
     model = InsMOSNet(cfg, state_dict=sd).cuda(gpu).eval()
     if world > 1 and args.calibration:   # one cache file per rank: ranks calibrate on their own first window, concurrently
@@ -263,7 +327,7 @@ def main():
     in_flight = min((W + wpl - 1) // wpl, model.model.windows_in_flight)
     batch = [{"past_point_clouds": p} for p in pts_list]
     ncur = int((window[:, 4] == 0).sum())
-    gts = [torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=rank * W + i)).to(dev) for i, w in enumerate(windows)]
+    gts = [torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=sd_)).to(dev) for sd_, w in zip(seeds, windows)]
     metrics = ClassificationMetrics(3, [0])
 
     dt, value, cm_all = timed_steps(model.forward, batch, gts, metrics, args.steps, args.warmup, world, dev,
@@ -297,23 +361,30 @@ def main():
 
     out = {
         "metric": "scans_per_sec", "value": round(value, 3), "unit": "scans/s (windows of N=10 scans, ~120k pts/scan)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+        "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not args.conv_precision else "EXPERIMENT split-bf16x3 (NOT the product path, NOT a benchmark line)",
         "data": "synthetic",
         "config": {"workload": ("cfg-4 (BASELINE.json configs[3], NOT the headline): dense stress scene, 300k pts/scan, N=10 scans, voxel "
                                 "0.05 m, the 100 000-voxel cap hit, BEV 250 x 300 x 640, full InsMOS forward" if cfg4 else
-                                "cfg-2: synthetic S0 windows, N=10 scans, voxel 0.1 m, full InsMOS forward "
-                                "(MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)"),
+                                ("cfg-2: synthetic windows (seeds rank*W..), N=10 scans, voxel 0.1 m, full InsMOS forward; MIXED seeds, not the "
+                                 "headline workload" if args.mixed_seeds else
+                                 "cfg-2 (SURVEY.md 8d): every slot of the step holds the synthetic scene S0 (seed = rank: seed 0 at N=1; "
+                                 "cfg-3 = seeds 0..N-1, one per rank) in its own device buffer, N=10 scans, voxel 0.1 m, full InsMOS "
+                                 "forward (MotionNet 4D UNet + voxelise + UNetV2 + BEV CenterHead + NMS + instance fusion)")),
+                   "window_seeds": sorted(set(seeds)),
                    "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
                    "n_az": args.n_az, "points_per_window": int(len(window)), "current_points": ncur,
                    "host_cores_per_rank": host_cores, "torch_threads": torch.get_num_threads(),
                    "weights": "seeded random (He-normal, occupancy-corrected), head bias calibrated to "
-                              f"~{args.candidates} candidates", "parallelism": f"dp{world} (windows sharded by rank)"},
+                              f"~{args.candidates} candidates", "parallelism": f"dp{world} (windows sharded by rank)",
+                   "backend": (dist.get_backend() if world > 1 else None)},
         "ms_per_window": round(1000.0 * dt / (args.steps * W), 3),
         "timed_region_s": round(dt, 3),
         "sustained_scans_per_sec": round(sustained, 3) if sustained is not None else None,
+        # (random weights against synthetic labels: the number only shows that the counters of every rank went through the gather)
         "mos_iou_moving_vs_pseudo_gt": float(iou[2]),
+        "confusion_points": int(cm_all.sum().item()),
     }
 
     if rank == 0:
@@ -339,16 +410,19 @@ def main():
             model.forward(one, "test")
         torch.cuda.synchronize()
         out["value_b1"] = round(nb1 / (time.perf_counter() - t1), 3)
-        # the step with every slot holding the S0 window itself (seed 0: ~9 % more executed work than the mean of seeds 0..W-1)
-        s0_batch = [batch[0]] * W
-        model.forward(s0_batch, "test")
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ns0 = max(3, min(args.steps, 10))
-        for _ in range(ns0):
-            model.forward(s0_batch, "test")
-        torch.cuda.synchronize()
-        out["value_s0_only"] = round(ns0 * W / (time.perf_counter() - t1), 3)
+        # the same step with DIFFERENT windows in the slots (seeds 0 .. W-1: ~10 % less executed work on average than S0) -- an
+        # extra, un-bracketed; the headline `value` is the S0 workload of SURVEY.md 8d
+        if world == 1 and not args.mixed_seeds and not cfg4:
+            mixed = [{"past_point_clouds": torch.from_numpy(w).to(dev)} for w in load_windows(list(range(W)), args.n_az)]
+            model.forward(mixed, "test")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nmx = max(3, min(args.steps, 10))
+            for _ in range(nmx):
+                model.forward(mixed, "test")
+            torch.cuda.synchronize()
+            out["value_mixed_seeds"] = round(nmx * W / (time.perf_counter() - t1), 3)
+            del mixed
         # ---- roofline of the dominant kernel (k_sparse_conv), HIP events on the launch stream, same workload, ONE launch
         # set at a time (nothing else on the GPU): plain per-launch durations -- what `rocprofv3 --kernel-trace --stats` of
         # `INSMOS_WINDOWS_IN_FLIGHT=1 bench.py --timed-only` shows (profiles/, tools/roofline_from_rocprof.py)
@@ -356,10 +430,19 @@ def main():
         lib.insmos_forward_streams(0)   # per-kernel durations: ONE stream (the second stream would overlap the spans it measures)
         flops = flops_ref = gather = launches = comp = 0
         counts0 = None
-        for p in pts_list:                      # algorithmic work of every window of the step (step path, per window)
+        seen_work = {}
+        for sd_, p in zip(seeds, pts_list):     # algorithmic work of every window of the step (step path, once per distinct window)
+            if sd_ in seen_work:
+                f_ref, wk = seen_work[sd_]
+                flops_ref += f_ref
+                flops += wk["flops"]
+                gather += wk["gather_bytes"]
+                comp += wk["compulsory_bytes"]
+                continue
             eng.prune_dead_rows = False
             eng.forward_window(p, native=False)  # every row of every layer, as the reference computes them
-            flops_ref += eng.algorithmic_work()["flops"]
+            f_ref = eng.algorithmic_work()["flops"]
+            flops_ref += f_ref
             eng.prune_dead_rows = True
             eng.forward_window(p, native=False)  # fills the launch log the EXECUTED work is counted from
             wk = eng.algorithmic_work()
@@ -367,6 +450,7 @@ def main():
             gather += wk["gather_bytes"]
             comp += wk["compulsory_bytes"]
             launches = wk["launches"]
+            seen_work[sd_] = (f_ref, wk)
             if counts0 is None:
                 counts0 = dict(eng.last_counts)
                 eng.forward_window(p)

@@ -408,6 +408,28 @@ def test_bench_timed_region_shard_and_aggregate_gloo_world2(tmp_path):
         assert p.returncode == 0 and "OK" in o, o
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks (round-3 review: the flag was parsed and ignored, an
+    8-GPU call would have measured one GPU); inside a launcher a --gpus that disagrees with WORLD_SIZE is refused.  The
+    rendezvous-only mode runs the real spawn + process group over gloo without touching a GPU."""
+    import json
+    bench_py = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--backend", "gloo", "--rendezvous-only"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:]
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["backend"] == "gloo", out[-2000:]   # ONE line, from rank 0
+    r = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--rendezvous-only"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stdout.decode()
+    import bench
+    cmd = bench.spawn_command(8, ["--gpus", "8", "--steps", "5"], port=1234)
+    assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                        "--master-port", "1234"] and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+
+
 def test_precision_modes_are_refused_unless_known():
     """The reduced-precision switches are opt-in and validated on the host: the library refuses unknown modes (and stays in
     exact fp32), the training switch accepts only 0 / 1, and the d/dW kernel selector only its three kernels."""

@@ -121,3 +121,23 @@ def test_two_ranks_on_one_gpu_timed_region_and_overlapped_grad_exchange(tmp_path
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o[-3000:]
     print("\n".join(o.strip().splitlines()[-1] for o in outs))
+
+
+def test_bench_gpus_2_dry_run_on_one_gpu():
+    """The command the driver uses, with --gpus 2: bench.py starts both ranks itself (gloo, both on GPU 0), rank 0 prints ONE line
+    with n_gpus = 2, the whole-job rate of both ranks' windows, and a confusion sum that holds both ranks' points."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", INSMOS_WINDOWS_PER_LAUNCH="2", INSMOS_WINDOWS_IN_FLIGHT="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-index", "0",
+                        "--steps", "2", "--warmup", "1", "--n-az", "320", "--windows-per-step", "4", "--sustain-seconds", "0",
+                        "--no-cpu-baseline", "--candidates", "200"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("dp2") and j["config"]["backend"] == "gloo"
+    assert j["confusion_points"] == 2 * 2 * 4 * j["config"]["current_points"] or j["confusion_points"] > 2 * 4 * j["config"]["current_points"]
+    assert abs(j["value"] - 2 * 2 * 4 / j["timed_region_s"]) / j["value"] < 2e-2
