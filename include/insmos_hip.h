@@ -383,6 +383,12 @@ int insmos_debug_conv_force(int cot, int jt, int ring);
 /* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
  * both produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_quad(int on);
+/* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
+ * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =
+ * Cin x Cout <= 128 with K >= 16, bit 1 = the same widths with K < 16, bit 2 = the 16 x 16 layers; 0 = off (MFMA tiles),
+ * -1 = default (INSMOS_CONV_ROWLANE, else 1).  rows_per_lane 1 or 2 (0 = INSMOS_CONV_ROWLANE_RPL, else 1).  Same bits as the
+ * MFMA kernels whatever the mode (tests/test_gpu_conv.py). */
+int insmos_debug_conv_rowlane(int mode, int rows_per_lane);
 /* test / tuning hook: the 81-tap single-chunk layers (Cin 8 / 16, contiguous rows, masked table) on the LDS-staged kernel (1;
  * csrc/spconv_lds.hip; also INSMOS_CONV_LDS=1) or on the generic kernels (0, the default: the staged kernel is bit-identical but
  * slower in its first form); same bits as the unsplit generic kernels (tests/test_gpu_conv.py). */
@@ -654,6 +660,10 @@ int insmos_forward_window(void* ctx, const float* points, int64_t n, int ld_pts,
  * (15); the environment variable INSMOS_TWO_STREAMS overrides both.  Single-window latency 3.8 -> 3.4 ms; with several launch
  * sets in flight the sets already overlap each other and the caller switches it off (insmos_amd/models.py). */
 int insmos_forward_streams(int mask);
+/* Releases the calling host thread's second stream and events (created on first use by insmos_forward_windows, on the device
+ * current at that time; a thread that later runs on another device gets new ones automatically).  Worker threads call it
+ * before they end. */
+int insmos_forward_thread_release(void);
 /* Row regrouping of the runner's 3D levels 1..4, one decimal digit per level (level 1 = units): 0 = off, 1 = blocks of 256 rows,
  * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global), 5 = 4096-row blocks with the
  * coordinate parity class above the signature (block_rows -4096); -1 = default (environment

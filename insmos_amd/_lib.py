@@ -73,6 +73,7 @@ SIGNATURES = {
                                             c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "insmos_debug_table_limit": (c_int, [c_i64]),
     "insmos_forward_streams": (c_int, [c_int]),
+    "insmos_forward_thread_release": (c_int, []),
     "insmos_rankmap_words": (c_sz, [c_vp, c_int]),
     "insmos_rankmap_ws_bytes": (c_sz, [c_vp, c_int]),
     "insmos_rankmap_from_keys": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
+    "insmos_debug_conv_rowlane": (c_int, [c_int, c_int]),
     "insmos_debug_conv_lds": (c_int, [c_int]),
     "insmos_debug_conv_lds_stats": (c_int, [c_vp, c_int]),
     "insmos_debug_dw_kernel": (c_int, [c_int]),

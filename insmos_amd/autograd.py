@@ -75,16 +75,16 @@ def current_train_conv_precision():
 
 def _conv(lib, x, n_in, cin_pad, nbr, K, n_out, packed, bias_pad, cout, st, mask=None, mode=0):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-    if mode:
-        _lib.check(lib.insmos_conv_precision_thread(mode), "insmos_conv_precision_thread")
+    # ALWAYS pinned for this host thread, mode 0 included: a node recorded as exact fp32 must not inherit a process-wide
+    # insmos_conv_precision(1 / 3) an inference engine may have set meanwhile
+    _lib.check(lib.insmos_conv_precision_thread(int(mode)), "insmos_conv_precision_thread")
     try:
         _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n_in, x.stride(0), cin_pad, nbr.data_ptr() if nbr is not None else None,
                                           mask.data_ptr() if (mask is not None and nbr is not None) else None, K, n_out,
                                           packed.data_ptr(), bias_pad.data_ptr(), out.data_ptr(), cout, cout, None,
                                           0, 0, 0, 0, st), "insmos_sparse_conv")
     finally:
-        if mode:
-            lib.insmos_conv_precision_thread(-1)
+        lib.insmos_conv_precision_thread(-1)
     return out
 
 

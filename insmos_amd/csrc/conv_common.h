@@ -13,6 +13,7 @@ struct ConvP {
     const int32_t* nbr;
     const uint32_t* mask16;  // [ceil(n_out/16)][4] active-tap bits per 16-row group, or null (all active)
     const float* w;
+    const float* w_rl;  // the layer's row-lane weight tail ([tap][p][co], spconv_rowlane.hip) behind the packed fragments, or null
     const float* bias;
     float* out;
     const float* res;
@@ -31,5 +32,12 @@ struct ConvP {
 // generic kernels), true = launched (rc holds the status)
 bool conv_lds_ok(const ConvP& P, int ck, int cot);   // applicable (and not switched off)?
 bool conv_lds_try(const ConvP& P, int ck, int cot, long n_rows, hipStream_t s, int* rc);
+
+// spconv_rowlane.hip: the row-per-lane VALU kernel of the small-channel layers.  Floats of the row-lane tail a layer's packed
+// weights carry behind the MFMA fragments (0 = the layer does not qualify); try = launch if applicable and enabled.
+size_t rowlane_tail_floats(int K, int cin, int cout);
+bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc);
+// [tap][p][co] position -> (ci, co) of the layer: p = 4 s + g walks the input channels in the MFMA kernels' chain order
+__host__ __device__ inline int rowlane_ci(int cin, int p) { return (cin / 4) * (p & 3) + (p >> 2); }
 
 }  // namespace insmos

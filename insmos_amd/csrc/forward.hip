@@ -11,6 +11,7 @@
 // insmos_amd/engine.py carries the same graph in inspectable form and tests/test_gpu_model.py asserts that both
 // produce identical bits.  All device memory comes from a caller-provided arena (bump-allocated per window).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -26,6 +27,10 @@ struct Ctx {
     std::map<std::string, InsmosConvW> L;
     std::vector<int32_t> off81[4];
     std::vector<int32_t> d_subm, d_inv, d_down5, d_inv5;
+    // launch sets whose points left the packed-key box (+-2048 voxels in x / y, +-256 in z: coords.hip k_quant_keys_p) pay a second
+    // quantise + sort + read-back through the fallback; a context that has seen one starts at the pair sort from then on (far
+    // returns are a property of the sensor / voxel size, not of one window).  Re-armed every 256 sets.
+    mutable std::atomic<int> packed_overflow{0};
 };
 
 struct Arena {
@@ -85,8 +90,26 @@ struct Aux {
     hipStream_t s2 = nullptr;
     std::vector<hipEvent_t> ev;
     size_t used = 0;
+    int dev = -1;   // the device s2 and the events belong to: a host thread that moves to another GPU gets new ones
+    void release() {
+        if (s2) (void)hipStreamDestroy(s2);
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        s2 = nullptr;
+        ev.clear();
+        used = 0;
+        dev = -1;
+    }
     int init() {
-        if (!s2) HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if (s2 && cur != dev) {   // (resources of the previous device are released from here: destroy calls take any current device)
+            (void)hipStreamSynchronize(s2);
+            release();
+        }
+        if (!s2) {
+            HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            dev = cur;
+        }
         used = 0;
         return INSMOS_OK;
     }
@@ -235,11 +258,14 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // packed 40-bit sort keys with the point index in the low bits first (sets of <= 8 windows, < 2^24 points, z within
         // +-256 voxels), then the 40(+)-bit pair sort, then the full-width sort (windows wider than +-2048 voxels / 16 time steps)
         static const bool packed_keys = [] { const char* e = getenv("INSMOS_PACKED_KEYS"); return !(e && e[0] == '0'); }();
-        for (int mode = (packed_keys && B <= 8 && N < (1ll << 24)) ? 2 : 1; mode >= 0; --mode) {
+        int skip_packed = C.packed_overflow.load(std::memory_order_relaxed);
+        if (skip_packed > 0) C.packed_overflow.store(skip_packed - 1, std::memory_order_relaxed);
+        for (int mode = (packed_keys && !skip_packed && B <= 8 && N < (1ll << 24)) ? 2 : 1; mode >= 0; --mode) {
             CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb,
                                          mode, s));
             CK(read_counts(counts, hc, 5 + B, s));
             if (hc[3] == 0) break;
+            if (mode == 2) C.packed_overflow.store(256, std::memory_order_relaxed);
         }
         A.off = mark;  // the sort workspace is dead once the counts are back
     }
@@ -838,6 +864,15 @@ extern "C" int insmos_forward_streams(int mask) {
 // blocks of 256 / 1024 / 4096 rows, 4 = whole windows, 5 = 4096-row blocks sorted by parity class first; -1 = back to the default
 // (INSMOS_REGROUP_ROWS, else kRegroupDefault for launch sets of two windows or more and off for a single window).
 // Process-wide; the outputs do not depend on it (tests/test_gpu_model.py).
+// The calling host thread's second stream and its events are released (a worker thread calls this before it ends; a thread that
+// moves to another device gets new ones on its own, see Aux::init).  Not done from a thread_local destructor: at process exit that
+// would run after the HIP runtime's own teardown.
+extern "C" int insmos_forward_thread_release(void) {
+    if (tl_aux.s2) (void)hipStreamSynchronize(tl_aux.s2);
+    tl_aux.release();
+    return INSMOS_OK;
+}
+
 extern "C" int insmos_forward_regroup(int modes) {
     if (modes != -1 && !regroup_modes_ok(modes)) return INSMOS_EINVAL;
     g_regroup = modes;

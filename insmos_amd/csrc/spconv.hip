@@ -702,7 +702,11 @@ extern "C" size_t insmos_packed_weight_floats(int K, int cin, int cout) {
     int n16, h8, h4;
     chunking(cin, n16, h8, h4);
     int ntile = (cout + 15) / 16;
-    return (size_t)K * (size_t)(n16 + h8 + h4) * (size_t)ntile * 64 * (size_t)frag_lane_floats(cin);
+    return (size_t)K * (size_t)(n16 + h8 + h4) * (size_t)ntile * 64 * (size_t)frag_lane_floats(cin) + rowlane_tail_floats(K, cin, cout);
+}
+// floats of the MFMA fragment part alone (the row-lane tail of the small-channel layers starts here)
+static size_t packed_fragment_floats(int K, int cin, int cout) {
+    return (size_t)insmos_packed_weight_floats(K, cin, cout) - rowlane_tail_floats(K, cin, cout);
 }
 
 extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, int cout_real, int cin, int cout,
@@ -730,6 +734,12 @@ extern "C" int insmos_pack_weights_host(const float* taps, int K, int cin_real, 
         int c0 = n16 * 16;
         if (h8) { emit(c0, 2); c0 += 8; }
         if (h4) emit(c0, 1);
+    }
+    if (rowlane_tail_floats(K, cin, cout)) {   // [tap][p][co], spconv_rowlane.hip
+        float* tail = packed + packed_fragment_floats(K, cin, cout);
+        for (int k = 0; k < K; ++k)
+            for (int p = 0; p < cin; ++p)
+                for (int co = 0; co < cout; ++co) tail[((size_t)k * cin + p) * cout + co] = W(k, rowlane_ci(cin, p), co);
     }
     return INSMOS_OK;
 }
@@ -849,6 +859,7 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     hipStream_t s = (hipStream_t)stream;
     ConvP P;
     P.in = in; P.nbr = nbr; P.mask16 = mask16; P.w = wpacked; P.bias = bias; P.out = out; P.res = res;
+    P.w_rl = rowlane_tail_floats(K, cin, cout) ? wpacked + packed_fragment_floats(K, cin, cout) : nullptr;
     P.n_out = (uint32_t)n_out;
     P.row0 = (uint32_t)row0;
     P.in_bytes = (uint32_t)((n_in - 1) * (int64_t)ld_in * 4 + (int64_t)cin * 4);
@@ -869,6 +880,13 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         ProfScope ps(KK_SPARSE_CONV, s);
         ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
         if (conv_lds_try(P, ck, P.ntile_co, (long)n_rows, s, &rc_lds)) return rc_lds;
+    }
+    // the small-channel layers (Cin, Cout in {8, 16}): one lane per output row on the vector ALUs (spconv_rowlane.hip)
+    if (!g_force_cot && !g_dbg && nbr) {
+        int rc_rl = INSMOS_OK;
+        ProfScope ps(KK_SPARSE_CONV, s);
+        ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
+        if (conv_rowlane_try(P, (long)n_rows, s, &rc_rl)) return rc_rl;
     }
     // tile shape, from tools/conv_tune.py sweeps on MI355X: a 16-row gather is ~8x the cost of a coalesced
     // weight fragment, so generic layers always use 16-row tiles (JT = 1) and widen in channels instead:

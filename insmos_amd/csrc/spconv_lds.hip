@@ -158,9 +158,16 @@ __global__ void __launch_bounds__(256, CK == 8 ? 3 : 2) k_conv_ldsw(ConvP P) {
             idx[k] = -1;
             if ((ug >> k) & 1u) idx[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff, (uint32_t)(dg * 27 + k) * n4, 0);
         }
-        if (!row_ok) {
+        {
+            // tables written with sparse stores (k_resolve_taps<.., 2>, insmos_build_nbr_rank_sparse) hold NOTHING in the slots of a
+            // 16-row group that lacks the tap: a lane keeps only the entries of its OWN tile's taps (garbage there would steer the
+            // window placement, the miss list and the raw fallback -- correct results through the MFMA gating, but a random path)
+            const uint64_t mlo = g == 0 ? tlo[0] : g == 1 ? tlo[1] : g == 2 ? tlo[2] : tlo[3];
+            const uint64_t mhi = g == 0 ? thi[0] : g == 1 ? thi[1] : g == 2 ? thi[2] : thi[3];
+            const uint32_t mg = row_ok ? group_bits(mlo, mhi, dg) : 0u;
 #pragma unroll
-            for (int k = 0; k < 27; ++k) idx[k] = -1;
+            for (int k = 0; k < 27; ++k)
+                if (!((mg >> k) & 1u)) idx[k] = -1;
         }
         // ---- B. window placement: centred on the centre tap's neighbours; a workgroup none of whose voxels exists at t + dt
         // centres on its smallest neighbour index.  (The barrier also closes the previous group: every wave is done with s_rows.)

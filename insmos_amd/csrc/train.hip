@@ -14,6 +14,7 @@
 //             class-weighted NLL; k_mos_loss writes the per-point terms and d loss / d logits, reduced in fixed order.
 #include <cstdlib>
 #include "common.h"
+#include "conv_common.h"
 
 namespace insmos {
 
@@ -49,6 +50,23 @@ __global__ void k_pack_weights(const float* __restrict__ taps, int K, int cin_re
         }
     }
     packed[(t >> 2) * lf + s] = v;
+}
+
+// the row-lane tail of the small-channel layers ([tap][p][co], spconv_rowlane.hip), same transpose / mirror rules as above
+__global__ void k_pack_rowlane_tail(const float* __restrict__ taps, int K, int cin_real, int cout_real, int cin, int cout,
+                                    int transpose, int mirror, float* __restrict__ tail) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= K * cin * cout) return;
+    const int co = t % cout, p = (t / cout) % cin, k = t / (cout * cin);
+    const int ci = rowlane_ci(cin, p);
+    const int ks = mirror ? K - 1 - k : k;
+    float v = 0.f;
+    if (!transpose) {
+        if (ci < cin_real && co < cout_real) v = taps[((int64_t)ks * cin_real + ci) * cout_real + co];
+    } else if (ci < cout_real && co < cin_real) {
+        v = taps[((int64_t)ks * cin_real + co) * cout_real + ci];
+    }
+    tail[t] = v;
 }
 
 // ---- dW: block = 256 threads = 16 x 16 (ci, co) pairs of a 16 x 16 channel tile, one tap, one chunk of rows ----
@@ -655,6 +673,11 @@ extern "C" int insmos_pack_weights_device(const float* taps, int K, int cin_real
     hipStream_t s = (hipStream_t)stream;
     INSMOS_LAUNCH(k_pack_weights, dim3(cdiv(total, 256)), dim3(256), 0, s, taps, K, cin_real, cout_real, cin, cout, nblk, ntile,
                   n16, h8, transpose, mirror_taps, packed);
+    if (const size_t tail = rowlane_tail_floats(K, cin, cout)) {
+        float* tp = packed + (insmos_packed_weight_floats(K, cin, cout) - tail);
+        INSMOS_LAUNCH(k_pack_rowlane_tail, dim3(cdiv((int64_t)tail, 256)), dim3(256), 0, s, taps, K, cin_real, cout_real, cin, cout,
+                      transpose, mirror_taps, tp);
+    }
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -104,7 +104,8 @@ class BucketedGradReducer:
             # the bucket's all-reduce is already in flight (or this gradient was already packed): a second backward before
             # reduce() -- gradient accumulation / retain_graph -- would write into a buffer RCCL is reading
             raise RuntimeError("BucketedGradReducer(overlap=True): a gradient arrived twice between two reduce() calls "
-                               "(one backward per reduce(); use overlap=False to accumulate gradients over several)")
+                               "(one backward per reduce(); use overlap=False to accumulate gradients over several; after a "
+                               "backward that was aborted midway call reset() before the next one)")
         flat, members = self.buckets[bi]
         p, off, n = members[mi]
         flat[off:off + n].copy_(p.grad.reshape(-1))
@@ -112,6 +113,13 @@ class BucketedGradReducer:
         while self._launched < len(self.buckets) and len(self._seen[self._launched]) == len(self.buckets[self._launched][1]):
             self._launch(self._launched)      # strictly in bucket order
             self._launched += 1
+
+    def reset(self):
+        """Forget a backward that did not reach reduce() (an exception or OOM midway): wait for the collectives already in
+        flight (every rank must call this: they are collectives), drop what the hooks packed, start again at bucket 0."""
+        for w in self._works:
+            w.wait()
+        self._works, self._launched, self._seen = [], 0, [set() for _ in self.buckets]
 
     def reduce(self, average=True):
         """All-reduce every parameter's .grad (missing grads count as zero) in place; returns the number of collectives.

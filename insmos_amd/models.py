@@ -90,7 +90,22 @@ class InsMOS_Model:
 
     def _drop_workers(self):
         if self._workers is not None:
-            self._workers[2].shutdown(wait=True)
+            engines, _, pool = self._workers[:3]
+            # every worker thread hands back its second stream and events (csrc/forward.hip keeps them per host thread); the
+            # barrier makes each of the pool's threads take exactly one of the tasks
+            import threading
+            bar = threading.Barrier(len(engines))
+
+            def release():
+                try:
+                    bar.wait(timeout=5.0)
+                except threading.BrokenBarrierError:
+                    pass
+                engines[0].lib.insmos_forward_thread_release()
+
+            for f in [pool.submit(release) for _ in engines]:
+                f.result()
+            pool.shutdown(wait=True)
             self._workers = None
 
     def _get_workers(self, w):

@@ -240,6 +240,7 @@ def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_m
 
     def run(quad, masked, row0=0):
         lib().insmos_debug_conv_quad(quad)
+        lib().insmos_debug_conv_rowlane(0, 0)   # (these shapes would otherwise take the row-per-lane kernel: tested below)
         try:
             out = torch.full((n_out, cout), -7.0, device="cuda:0")
             _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr() if masked else None,
@@ -250,6 +251,7 @@ def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_m
             return out
         finally:
             lib().insmos_debug_conv_quad(1)
+            lib().insmos_debug_conv_rowlane(-1, 0)
 
     ref = R.sparse_conv(x, nbr, taps) + bias
     if res_mode == 2:
@@ -263,6 +265,68 @@ def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_m
         np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
     r0 = 16 * (n_out // 48)
     assert torch.equal(run(1, True, r0)[r0:], run(0, True, r0)[r0:])
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
+    (8, 8, 81, 40003, 1), (8, 16, 81, 5000, 0), (16, 16, 81, 33333, 1), (16, 8, 81, 2049, 0), (16, 16, 27, 40000, 2),
+    (8, 16, 27, 777, 0), (8, 8, 8, 33000, 0), (16, 8, 8, 1000, 0), (16, 16, 3, 17, 0), (8, 8, 81, 63, 2), (8, 8, 125, 1300, 0)])
+def test_rowlane_kernel_is_bitwise_the_mfma_one(cin, cout, K, n_out, res_mode):
+    """The small-channel layers on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip: one lane per output row, the tap's
+    weights from SGPRs, v_pk_fma_f32) against the MFMA tiles: the SAME bits -- per row and channel both are one fmaf chain over
+    (tap, MFMA step, lane group) -- for one and two rows per lane, with and without active-tap masks, every epilogue, a row
+    suffix, tap lists of every length (the pipeline's clamped tail) and a table whose slots outside the group masks hold
+    garbage (sparse table stores: insmos_build_nbr_rank_sparse, k_resolve_taps<.., 2>)."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(K * 100 + cin + cout + 7)
+    n_in = max(n_out // 2, 40)
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    ngrp = (n_out + 15) // 16
+    n_act = rng.integers(0, K + 1, size=ngrp)
+    grp = np.zeros((K, ngrp), bool)
+    for gi in range(ngrp):
+        grp[rng.permutation(K)[:n_act[gi]], gi] = True
+    slot_on = np.repeat(grp, 16, axis=1)[:, :n_out]
+    nbr[~(slot_on & (rng.uniform(size=(K, n_out)) < 0.7))] = -1
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.3)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    masks = tap_masks(nbr).view(np.int32)
+    garbage = nbr.copy()                                   # what a sparsely stored table looks like outside its masks
+    off = ~slot_on
+    garbage[off] = rng.integers(-5, n_in + 5, size=int(off.sum())).astype(np.int32)
+    xd, nd, gd, md = dev(x), dev(nbr), dev(garbage), dev(masks)
+
+    def run(mode, rpl, table, masked, row0=0):
+        assert lib().insmos_debug_conv_rowlane(mode, rpl) == 0
+        try:
+            out = torch.full((n_out, cout), -7.0, device="cuda:0")
+            _lib.check(lib().insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, table.data_ptr(), md.data_ptr() if masked else None,
+                                                     K, n_out, row0, layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout,
+                                                     layer.cout, res.data_ptr() if res is not None else None, ld_res if res_mode else 0,
+                                                     res_mode, 1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib().insmos_debug_conv_rowlane(-1, 0)
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    base = {m: run(0, 0, nd, m) for m in (True, False)}    # the MFMA tiles
+    np.testing.assert_allclose(base[True].cpu().numpy(), ref, **TOL)
+    for rpl in (1, 2):
+        for masked in (True, False):
+            assert torch.equal(run(7, rpl, nd, masked), base[masked]), (rpl, masked)
+        assert torch.equal(run(7, rpl, gd, True), base[True]), ("garbage outside the masks", rpl)
+        r0 = 16 * (n_out // 48)
+        assert torch.equal(run(7, rpl, nd, True, r0)[r0:], base[True][r0:])
 
 
 def _with_precision(mode, layers, fn):

@@ -45,7 +45,7 @@ def _emulate_conv(packed, K, cin, cout, x, nbr):
         blocks.append((c0, 1))
     ntile = (cout + 15) // 16
     lf = 2 if cin == 8 else 1 if cin == 4 else 4   # floats per lane: the single-chunk layers (Cin = 8 / 4) are stored compactly
-    pk = packed.reshape(K, len(blocks), ntile, 64, lf)
+    pk = packed[:K * len(blocks) * ntile * 64 * lf].reshape(K, len(blocks), ntile, 64, lf)   # (a row-lane tail may follow)
     n_out = nbr.shape[1]
     out = np.zeros((n_out, ntile * 16), np.float64)
     for k in range(K):
@@ -62,7 +62,8 @@ def _emulate_conv(packed, K, cin, cout, x, nbr):
 
 
 @pytest.mark.parametrize("cin_real,cout_real,K", [(8, 8, 5), (1, 8, 3), (7, 16, 4), (19, 16, 3), (35, 32, 2), (48, 32, 2),
-                                                  (24, 16, 3), (131, 24, 2), (16, 3, 1), (128, 11, 1)])
+                                                  (24, 16, 3), (131, 24, 2), (16, 3, 1), (128, 11, 1), (16, 16, 3), (13, 8, 2),
+                                                  (8, 16, 1)])
 def test_weight_packing_matches_fragment_convention(lib, cin_real, cout_real, K):
     from oracle import ref_ops as R
     rng = np.random.default_rng(cin_real * 7 + cout_real)
@@ -82,6 +83,20 @@ def test_weight_packing_matches_fragment_convention(lib, cin_real, cout_real, K)
     ref = R.sparse_conv(x[:, :cin_real], nbr, taps)
     np.testing.assert_allclose(got[:, :cout_real], ref, rtol=1e-4, atol=1e-4)
     assert np.all(got[:, cout_real:] == 0)
+    # the row-lane tail of the small-channel layers (csrc/spconv_rowlane.hip): [tap][p][co] behind the fragments, p = 4 s + g
+    # walking the input channels in the MFMA chain order ci = (cin / 4) g + s; no tail for K = 1 or other widths
+    frag = K * ((cin // 16) + (1 if cin % 16 >= 8 else 0) + (1 if cin % 8 >= 4 else 0)) * ((cout + 15) // 16) * 64 * (2 if cin == 8 else 1 if cin == 4 else 4)
+    if cin in (8, 16) and cout in (8, 16) and K >= 2:
+        assert n == frag + K * cin * cout
+        tail = packed[frag:].reshape(K, cin, cout)
+        for p in range(cin):
+            ci = (cin // 4) * (p & 3) + (p >> 2)
+            want = np.zeros((K, cout), np.float32)
+            if ci < cin_real:
+                want[:, :cout_real] = taps[:, ci, :]
+            np.testing.assert_array_equal(tail[:, p, :], want)
+    else:
+        assert n == frag
     assert lib.insmos_pack_weights_host(taps.ctypes.data, K, cin_real, cout_real, cin + 1, cout, packed.ctypes.data) == -1
 
 
@@ -490,6 +505,12 @@ def test_overlapped_reducer_contract_one_backward_per_reduce_and_close():
     assert red._launched == 2
     with pytest.raises(RuntimeError, match="arrived twice"):
         loss().backward()
+    red.reset()                          # an aborted backward: without reset() every later backward would raise
+    assert red._launched == 0 and not red._works
+    for p in params.values():
+        p.grad = None
+    loss().backward()
+    assert red._launched == 2
     red.reduce()
     g = params["a"].grad.clone()
     red.close()
