@@ -385,9 +385,10 @@ int insmos_debug_conv_force(int cot, int jt, int ring);
 int insmos_debug_conv_quad(int on);
 /* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
  * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =
- * Cin x Cout <= 128 with K >= 16, bit 1 = the same widths with K < 16, bit 2 = the 16 x 16 layers; 0 = off (MFMA tiles),
- * -1 = default (INSMOS_CONV_ROWLANE, else 1).  rows_per_lane 1 or 2 (0 = INSMOS_CONV_ROWLANE_RPL, else 1).  Same bits as the
- * MFMA kernels whatever the mode (tests/test_gpu_conv.py). */
+ * 8 x 8 layers with K >= 16, bit 1 = K < 16 (Cin x Cout <= 128), bit 2 = 8 x 16 / 16 x 8 with K >= 16, bit 3 = 16 x 16; 0 = off
+ * (MFMA tiles), -1 = default (INSMOS_CONV_ROWLANE, else 3).  rows_per_lane 1 or 2 (0 = INSMOS_CONV_ROWLANE_RPL, else 1).  Same
+ * bits as the MFMA kernels whatever the mode (tests/test_gpu_conv.py).  mode | dbg << 4 (dbg > 0) selects a probe build of
+ * the kernel (tools/batch_layers.py; results are wrong by construction). */
 int insmos_debug_conv_rowlane(int mode, int rows_per_lane);
 /* test / tuning hook: the 81-tap single-chunk layers (Cin 8 / 16, contiguous rows, masked table) on the LDS-staged kernel (1;
  * csrc/spconv_lds.hip; also INSMOS_CONV_LDS=1) or on the generic kernels (0, the default: the staged kernel is bit-identical but

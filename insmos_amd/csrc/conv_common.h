@@ -36,6 +36,7 @@ bool conv_lds_try(const ConvP& P, int ck, int cot, long n_rows, hipStream_t s, i
 // spconv_rowlane.hip: the row-per-lane VALU kernel of the small-channel layers.  Floats of the row-lane tail a layer's packed
 // weights carry behind the MFMA fragments (0 = the layer does not qualify); try = launch if applicable and enabled.
 size_t rowlane_tail_floats(int K, int cin, int cout);
+bool conv_rowlane_ok(const ConvP& P);
 bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc);
 // [tap][p][co] position -> (ci, co) of the layer: p = 4 s + g walks the input channels in the MFMA kernels' chain order
 __host__ __device__ inline int rowlane_ci(int cin, int p) { return (cin / 4) * (p & 3) + (p >> 2); }

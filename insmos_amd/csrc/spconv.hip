@@ -882,7 +882,7 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         if (conv_lds_try(P, ck, P.ntile_co, (long)n_rows, s, &rc_lds)) return rc_lds;
     }
     // the small-channel layers (Cin, Cout in {8, 16}): one lane per output row on the vector ALUs (spconv_rowlane.hip)
-    if (!g_force_cot && !g_dbg && nbr) {
+    if (!g_force_cot && !g_dbg && nbr && conv_rowlane_ok(P)) {
         int rc_rl = INSMOS_OK;
         ProfScope ps(KK_SPARSE_CONV, s);
         ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;

@@ -53,7 +53,9 @@ __device__ __forceinline__ void pk_fma_bcast(f32x2& acc, const f32x2 xp, const f
 }
 
 // CIN in {8, 16}; CO in {8, 16} (== the layer's cout); RPL rows per lane
-template <int CIN, int CO, int RPL>
+// DBG (probe builds, insmos_debug_conv_rowlane(mode | dbg << 4, .)): bit 0 = no FMAs, bit 1 = no gathers, bit 2 = gathers of the
+// lane's OWN row (same instructions and bytes, consecutive lines), bit 3 = no weight loads
+template <int CIN, int CO, int RPL, int DBG = 0>
 __global__ void __launch_bounds__(64) k_conv_rowlane(ConvP P) {
     constexpr int NX = CIN / 4;   // b128 loads per gathered row
     constexpr int NC2 = CO / 2;   // accumulator pairs per row
@@ -105,7 +107,13 @@ __global__ void __launch_bounds__(64) k_conv_rowlane(ConvP P) {
     // my row's neighbour under tap k; -1 where my group lacks the tap (the entry may be unwritten there)
     auto load_idx = [&](int k, uint32_t (&idx)[RPL]) {
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) idx[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff[q], (uint32_t)k * n4, 0);
+        for (int q = 0; q < RPL; ++q) {
+            if constexpr (DBG & 16)   // probe: the address pattern of a TILE-major table ([tile][tap][64 rows]); values are garbage
+                idx[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, (uint32_t)lane * 4u,
+                                                                        ((blockIdx.x * RPL + q) * (uint32_t)P.K + (uint32_t)k) * 256u, 0);
+            else
+                idx[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rowoff[q], (uint32_t)k * n4, 0);
+        }
     };
     // `live` (wave-uniform): false for the clamped taps past the end of the tile's list -- every lane gathers zeros
     auto gather = [&](int k, bool live, const uint32_t (&idx)[RPL], f32x4 (&x)[RPL][NX]) {
@@ -113,14 +121,28 @@ __global__ void __launch_bounds__(64) k_conv_rowlane(ConvP P) {
         for (int q = 0; q < RPL; ++q) {
             const uint32_t wsel = k < 64 ? (k < 32 ? own[q][0] : own[q][1]) : (k < 96 ? own[q][2] : own[q][3]);
             const bool has = ((wsel >> (k & 31)) & 1u) && live;
-            const uint32_t off = (has ? idx[q] : 0xFFFFFFFFu) * ld4;   // -1 wraps past the end of the buffer: the loads return 0
+            uint32_t off = (has ? idx[q] : 0xFFFFFFFFu) * ld4;   // -1 wraps past the end of the buffer: the loads return 0
+            if constexpr (DBG & 4) off = has ? (rowoff[q] >> 2) % (P.in_bytes / ld4) * ld4 : 0xFFFFFFF0u;
 #pragma unroll
-            for (int c = 0; c < NX; ++c)
-                x[q][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (uint32_t)c * 16u, 0));
+            for (int c = 0; c < NX; ++c) {
+                if constexpr (DBG & 2) {
+                    if (k == 1000) x[q][c] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                    asm volatile("" ::"v"(off));
+                } else {
+                    x[q][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (uint32_t)c * 16u, 0));
+                }
+            }
         }
     };
     auto fma_tap = [&](int k, const f32x4 (&x)[RPL][NX]) {
-        const CONSTAS f32x2* wk = wc + (size_t)k * (CIN * NC2);
+        if constexpr (DBG & 1) {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) asm volatile("" ::"v"(x[q][c]));
+            return;
+        }
+        const CONSTAS f32x2* wk = wc + ((DBG & 8) ? (size_t)0 : (size_t)k * (CIN * NC2));
 #pragma unroll
         for (int p = 0; p < CIN; ++p) {
             const int ci = WIDTH * (p & 3) + (p >> 2);   // MFMA step s = p >> 2, lane group g = p & 3
@@ -150,6 +172,12 @@ __global__ void __launch_bounds__(64) k_conv_rowlane(ConvP P) {
         for (int i = 1; i < 5; ++i) kq[i] = rl_pop_or_keep(tlo, thi, kq[i - 1]);
         uint32_t ia[RPL], ib[RPL], ic[RPL];
         f32x4 x0[RPL][NX], x1[RPL][NX], x2[RPL][NX];
+        if constexpr (DBG & 2) {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) x0[q][c] = x1[q][c] = x2[q][c] = (f32x4){0.5f, 0.5f, 0.5f, 0.5f};
+        }
         load_idx(kq[0], ia);
         load_idx(kq[1], ib);
         load_idx(kq[2], ic);
@@ -223,15 +251,33 @@ __global__ void __launch_bounds__(64) k_conv_rowlane(ConvP P) {
 }
 
 typedef void (*RlKernel)(ConvP);
+int g_rowlane_dbg = 0;
 RlKernel pick_rowlane(int cin, int co, int rpl) {
+    if (g_rowlane_dbg && rpl == 1) {
+#define PROBE(CI, C)                                                              \
+    if (cin == CI && co == C) switch (g_rowlane_dbg) {                            \
+        case 1: return k_conv_rowlane<CI, C, 1, 1>;                               \
+        case 2: return k_conv_rowlane<CI, C, 1, 2>;                               \
+        case 3: return k_conv_rowlane<CI, C, 1, 3>;                               \
+        case 4: return k_conv_rowlane<CI, C, 1, 4>;                               \
+        case 8: return k_conv_rowlane<CI, C, 1, 8>;                               \
+        case 5: return k_conv_rowlane<CI, C, 1, 5>;                               \
+        case 21: return k_conv_rowlane<CI, C, 1, 21>;                             \
+        case 20: return k_conv_rowlane<CI, C, 1, 20>;                             \
+    }
+        PROBE(8, 8) PROBE(16, 8) PROBE(8, 16)
+#undef PROBE
+    }
 #define CASE(CI, C, R) if (cin == CI && co == C && rpl == R) return k_conv_rowlane<CI, C, R>;
     CASE(8, 8, 1) CASE(8, 8, 2) CASE(8, 16, 1) CASE(8, 16, 2) CASE(16, 8, 1) CASE(16, 8, 2) CASE(16, 16, 1) CASE(16, 16, 2)
 #undef CASE
     return nullptr;
 }
 
-// which layers take the row-per-lane kernel: bit 0 = Cin x Cout <= 128 with K >= 16 (the 81-tap 8 / 16-channel layers), bit 1 =
-// the same widths with K < 16 (the k2s2 maps), bit 2 = 16 x 16 layers; -1 = read INSMOS_CONV_ROWLANE
+// which layers take the row-per-lane kernel: bit 0 = 8 x 8 layers with K >= 16 (block1, block8.conv2), bit 1 = K < 16 with
+// Cin x Cout <= 128 (the k2s2 maps), bit 2 = 8 x 16 / 16 x 8 with K >= 16, bit 3 = 16 x 16; -1 = read INSMOS_CONV_ROWLANE (default 3:
+// measured per layer on a launch set of 8 windows, profiles/r04_layers_rowlane_variants.csv -- 8 x 8 x 81 taps 1.35-1.45x faster
+// than the MFMA tiles, the 8-tap maps 1.1-1.2x, 8 x 16 / 16 x 8 slower (0.8-0.9x), 16 x 16 much slower (0.5-0.6x))
 int g_rowlane = -1;
 int g_rowlane_rpl = 0;   // rows per lane: 0 = read INSMOS_CONV_ROWLANE_RPL (default 1)
 
@@ -242,24 +288,34 @@ size_t rowlane_tail_floats(int K, int cin, int cout) {
     return (size_t)K * (size_t)cin * (size_t)cout;
 }
 
-bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc) {
+static void rowlane_env() {
     if (g_rowlane < 0) {
         const char* e = getenv("INSMOS_CONV_ROWLANE");
-        g_rowlane = e ? atoi(e) : 1;
+        g_rowlane = e ? atoi(e) : 3;
     }
     if (!g_rowlane_rpl) {
         const char* e = getenv("INSMOS_CONV_ROWLANE_RPL");
         g_rowlane_rpl = (e && atoi(e) == 2) ? 2 : 1;
     }
+}
+
+bool conv_rowlane_ok(const ConvP& P) {
+    rowlane_env();
     if (!g_rowlane || !P.nbr || !P.w_rl || !rowlane_tail_floats(P.K, P.cin, P.cout)) return false;
-    const bool wide = P.cin * P.cout > 128;
-    const int need = wide ? 4 : (P.K >= 16 ? 1 : 2);
-    if (!(g_rowlane & need)) return false;
-    // (row-lane stores and residual reads are per-lane whole rows: vector forms need 16-byte row pitches)
+    const int cc = P.cin * P.cout;
+    const int need = cc > 128 ? 8 : P.K < 16 ? 2 : cc > 64 ? 4 : 1;
+    return (g_rowlane & need) != 0 && pick_rowlane(P.cin, P.cout, g_rowlane_rpl) != nullptr;
+}
+
+bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc) {
+    if (!conv_rowlane_ok(P)) return false;
     RlKernel kern = pick_rowlane(P.cin, P.cout, g_rowlane_rpl);
-    if (!kern) return false;
     const long tiles = (n_rows + 64 * g_rowlane_rpl - 1) / (64 * g_rowlane_rpl);
-    INSMOS_LAUNCH(kern, dim3((unsigned)tiles), dim3(64), 0, s, P);
+    // probe only (INSMOS_ROWLANE_PROBE=1): INSMOS_ROWLANE_LDS bytes of dynamic LDS per one-wave workgroup cap the waves resident per CU
+    static const bool probe_env = getenv("INSMOS_ROWLANE_PROBE") != nullptr;
+    size_t lds = 0;
+    if (probe_env) { const char* e = getenv("INSMOS_ROWLANE_LDS"); lds = e ? (size_t)atoi(e) : 0; }
+    INSMOS_LAUNCH(kern, dim3((unsigned)tiles), dim3(64), lds, s, P);
     *rc = hipGetLastError() == hipSuccess ? INSMOS_OK : INSMOS_EHIP;
     return true;
 }
@@ -267,7 +323,9 @@ bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc) {
 }  // namespace insmos
 
 extern "C" int insmos_debug_conv_rowlane(int mode, int rows_per_lane) {
-    if (mode < -1 || mode > 7 || (rows_per_lane != 0 && rows_per_lane != 1 && rows_per_lane != 2)) return INSMOS_EINVAL;
+    if (mode < -1 || mode > 1023 || (rows_per_lane != 0 && rows_per_lane != 1 && rows_per_lane != 2)) return INSMOS_EINVAL;
+    insmos::g_rowlane_dbg = mode >= 0 ? mode >> 4 : 0;   // (probe builds: results are wrong by construction)
+    if (mode >= 0) mode &= 15;
     insmos::g_rowlane = mode;
     insmos::g_rowlane_rpl = rows_per_lane;
     return INSMOS_OK;

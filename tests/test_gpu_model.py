@@ -315,3 +315,61 @@ def test_dense_stress_config_voxel_005():
     logits_n, pred_n = eng.forward_window(torch.from_numpy(w).cuda(), native=True)  # same bits through the native runner
     assert torch.equal(logits_n, logits) and torch.equal(pred_n["pred_boxes"], pred["pred_boxes"])
     assert eng.last_counts["unet_voxels"][0] == cap
+
+
+def test_native_runner_launch_list_equals_the_step_path(setup):
+    """The roofline numerator (bench.py: roofline.algorithmic_gflop_per_window) is counted on the step path's launch log
+    (Engine._conv_log) and divided by the NATIVE runner's kernel time: the two graphs must issue the same convolution launches.
+    The native runner's launch sites attach (K, Cin, Cout, rows computed) to their profiler spans (insmos_prof_read_spans);
+    here they are lined up with the step path's log, launch by launch, for one window and for a launch set of three."""
+    import ctypes
+    model, window = setup["model"], setup["window"]
+    eng = model.model.engine
+    lib = eng.lib
+    pts = torch.from_numpy(window).cuda()
+    kk = next(k for k in range(64) if lib.insmos_prof_name(k) == b"sparse_conv_mfma")
+
+    def step_list(p):
+        eng.forward_window(p, native=False)
+        out = []
+        for nbr, n_out, layer, row0 in eng._conv_log:
+            if layer.name == "head" and out and out[-1][0] == "deconv":     # one fused launch (k_deconv_head)
+                nm, K, ci, co, rows = out[-1]
+                out[-1] = ("deconv+head", K, ci, 4 * eng.up_ch, rows)
+                continue
+            out.append((layer.name, layer.K, layer.cin, layer.cout, int(n_out) - (int(row0) & ~15)))
+        return out
+
+    def native_list(ps):
+        lib.insmos_forward_streams(0)
+        lib.insmos_prof_reset()
+        lib.insmos_prof_enable(1)
+        try:
+            eng.forward_windows(ps)
+            cap = 1024
+            ms = (ctypes.c_double * cap)()
+            meta = (ctypes.c_int64 * (4 * cap))()
+            n = lib.insmos_prof_read_spans(kk, cap, ms, meta)
+        finally:
+            lib.insmos_prof_enable(0)
+            lib.insmos_prof_reset()
+            lib.insmos_forward_streams(-1)
+        return [tuple(int(meta[4 * i + j]) for j in range(4)) for i in range(n)]
+
+    want = step_list(pts)
+    got = native_list([pts])
+    assert len(got) == len(want), (len(got), len(want))
+    for (name, K, ci, co, rows), (gK, gci, gco, grows) in zip(want, got):
+        assert (K, co) == (gK, gco) and (name == "conv0p1s1" or ci == gci), (name, (K, ci, co, rows), (gK, gci, gco, grows))
+        assert rows == grows, (name, rows, grows)
+    # a launch set of three: the same launches, rows summed over the windows (window 2 is a shorter one)
+    w2 = torch.from_numpy(np.ascontiguousarray(window[::2])).cuda()
+    wants = [step_list(p) for p in (pts, w2, pts)]
+    got3 = native_list([pts, w2, pts])
+    assert len(got3) == len(want)
+    for i, (gK, gci, gco, grows) in enumerate(got3):
+        name, K, ci, co, _ = want[i]
+        assert (K, co) == (gK, gco), (name, gK, gco)
+        tot = sum(w[i][4] for w in wants)
+        # (row0 of a set is rounded down to a 16-row group once, not once per window)
+        assert abs(grows - tot) <= 16 * 3, (name, grows, tot)

@@ -59,21 +59,54 @@ def main():
         per_win.append(layer_work(eng))
     n_layers = len(per_win[0])
     kk = next(k for k in range(64) if lib.insmos_prof_name(k) == b"sparse_conv_mfma")
-    eng.forward_windows(wins)
-    reps = 3
-    lib.insmos_prof_reset()
-    lib.insmos_prof_enable(1)
-    for _ in range(reps):
+
+    def measure(reps=3):
         eng.forward_windows(wins)
-    cap = 4096
-    ms = (ctypes.c_double * cap)()
-    meta = (ctypes.c_int64 * (4 * cap))()
-    n = lib.insmos_prof_read_spans(kk, cap, ms, meta)
-    lib.insmos_prof_enable(0)
-    lib.insmos_prof_reset()
-    assert n == reps * n_layers, (n, reps, n_layers)
-    t = np.array(ms[:n]).reshape(reps, n_layers).mean(0) * 1e3  # us
-    m = np.array(meta[:4 * n]).reshape(reps, n_layers, 4)[0]
+        lib.insmos_prof_reset()
+        lib.insmos_prof_enable(1)
+        for _ in range(reps):
+            eng.forward_windows(wins)
+        cap = 4096
+        ms = (ctypes.c_double * cap)()
+        meta = (ctypes.c_int64 * (4 * cap))()
+        n = lib.insmos_prof_read_spans(kk, cap, ms, meta)
+        lib.insmos_prof_enable(0)
+        lib.insmos_prof_reset()
+        assert n == reps * n_layers, (n, reps, n_layers)
+        t = np.array(ms[:n]).reshape(reps, n_layers).mean(0) * 1e3  # us
+        m = np.array(meta[:4 * n]).reshape(reps, n_layers, 4)[0]
+        return t, m
+
+    # BATCH_LAYERS_ROWLANE="0:1,1:1,3:1,7:2": the same launch set under several settings of the row-per-lane kernel
+    # (insmos_debug_conv_rowlane(mode, rows_per_lane)) in ONE process, interleaved twice -- one column per setting
+    variants = os.environ.get("BATCH_LAYERS_ROWLANE")
+    if variants:
+        # (mode | dbg << 4 selects a probe build; an optional third field = INSMOS_ROWLANE_LDS bytes under INSMOS_ROWLANE_PROBE=1)
+        vs = [tuple(int(v) for v in item.split(":")) for item in variants.split(",")]
+        cols = {v: [] for v in vs}
+        for _ in range(2):
+            for v in vs:
+                assert lib.insmos_debug_conv_rowlane(v[0], v[1]) == 0
+                os.environ["INSMOS_ROWLANE_LDS"] = str(v[2]) if len(v) > 2 else "0"
+                cols[v].append(measure(2)[0])
+        lib.insmos_debug_conv_rowlane(-1, 0)
+        tv = {v: np.minimum(*cols[v]) for v in vs}
+        hdr = "layer,K,cin,cout,rows," + ",".join("us_mode%d_dbg%d_rpl%d%s" % (v[0] & 15, v[0] >> 4, v[1], "_lds%d" % v[2] if len(v) > 2 else "")
+                                                   for v in vs)
+        lines = [hdr]
+        for i in range(n_layers):
+            name, K, cin, cout, _, _ = per_win[0][i]
+            rows = sum(pw[i][4] for pw in per_win)
+            lines.append("%s,%d,%d,%d,%d," % (name, K, cin, cout, rows) + ",".join("%.1f" % tv[v][i] for v in vs))
+        lines.append("TOTAL,,,,," + ",".join("%.1f" % float(tv[v].sum()) for v in vs))
+        txt = "\n".join(lines)
+        print(txt)
+        if out_csv:
+            with open(out_csv, "w") as f:
+                f.write(txt + "\n")
+        return
+
+    t, m = measure()
     lines = ["layer,K,cin,cout,rows,us,gflop,tflops,pct_time"]
     tot_us = float(t.sum())
     tot_fl = 0
