@@ -226,6 +226,7 @@ class InsMOSNet:
     def load_from_checkpoint(cls, checkpoint_path, hparams=None, map_location="cpu", **kw):
         ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
         cfg = hparams if hparams is not None else ckpt["hyper_parameters"]
+        _check_checkpoint_layouts(ckpt, cfg, checkpoint_path)
         return cls(cfg, state_dict=ckpt["state_dict"])
 
     def state_dict(self):
@@ -252,7 +253,32 @@ class InsMOSNet:
     __call__ = forward
 
 
+def _check_checkpoint_layouts(ckpt, cfg, path):
+    """Shapes of every tensor of the inference path against params.param_spec (a wrong LAYOUT of the right size -- spconv 1.x's
+    (kz, ky, kx, Cin, Cout), a torch Conv3d export -- must fail here, not produce silently permuted taps), and, for a checkpoint
+    this package did not write itself, one loud warning: the MinkowskiEngine tap order and the spconv 2.3.6 weight layout that
+    insmos_amd/params.py converts from are pinned to the reference's module definitions and to dependency knowledge only -- no
+    published checkpoint was available to verify them (tools/ckpt_probe.py prints the details)."""
+    import warnings
+    spec = P.param_spec(cfg)
+    sd = ckpt["state_dict"]
+    bad = [(k, tuple(int(d) for d in sd[k].shape), tuple(shape)) for k, (shape, _) in spec.items()
+           if k in sd and tuple(int(d) for d in sd[k].shape) != tuple(shape)]
+    if bad:
+        k, got, want = bad[0]
+        raise ValueError(f"{path}: {len(bad)} tensors have another shape than the reference's modules define, e.g. {k}: checkpoint "
+                         f"{got}, expected {want} -- run `python tools/ckpt_probe.py {path}` (it names known foreign layouts)")
+    if not ckpt.get("insmos_amd_synthetic", False):
+        warnings.warn(f"{path}: first-contact warning -- this looks like a REAL InsMOS checkpoint.  Shapes match, but the order of "
+                      "MinkowskiEngine's kernel-volume axis (x-fastest region enumeration, even kernels at offsets {0, 1}) and the "
+                      "spconv 2.3.6 (Cout, kz, ky, kx, Cin) layout assumed by insmos_amd/params.py have never been checked against "
+                      "published weights (none were available when this was built): compare a few scans' labels with the "
+                      "reference's own output before trusting the result; `python tools/ckpt_probe.py <ckpt>` prints what can "
+                      "be checked offline.", RuntimeWarning, stacklevel=3)
+
+
 def save_checkpoint(path, cfg, state_dict):
-    """Write a Lightning-shaped checkpoint ({'hyper_parameters', 'state_dict'}) for tests/tools."""
-    torch.save({"hyper_parameters": cfg,
+    """Write a Lightning-shaped checkpoint ({'hyper_parameters', 'state_dict'}) for tests/tools; marked as written by this
+    package (load_from_checkpoint warns about checkpoints that are not: their layout conversions are unverified)."""
+    torch.save({"hyper_parameters": cfg, "insmos_amd_synthetic": True,
                 "state_dict": {k: torch.as_tensor(v) for k, v in state_dict.items()}}, path)

@@ -28,7 +28,10 @@ two libraries the image lacks (they pin wiring and parameter names, not the libr
                     checkpoint loaded by name (all 329 tensors), default and voxel-0.05 configurations
   train_wiring.npz  the training forward of models/models.py:313-345 + torch autograd: losses, every parameter gradient
   driver.npz        scripts/predict_mos.py main() on a six-scan sequence (every file it wrote) + forward(list, 'eval')
-Flags: --poses-only --instance-only --refine-only --recall-only --mosloss-only --centerloss-only --wiring-only
+  nms_threshold.npz  the NMS predicate `iou > 0.01` (iou3d_nms_kernel.cu:298-307) AT its threshold: pairs of axis-aligned boxes
+                    (yaw 0: sin / cos exact on every platform) whose IoU, as the compiled reference computes it, is the float
+                    0.01 itself and the floats one ulp above and below it; the reference's keep list for them
+Flags: --nms-threshold-only --poses-only --instance-only --refine-only --recall-only --mosloss-only --centerloss-only --wiring-only
        --train-wiring-only --driver-only
 """
 import ctypes
@@ -109,6 +112,54 @@ def rand_boxes(rng, n, spread=20.0, big=False):
     b[:, 5] = rng.uniform(1.0, 2.0, n)
     b[:, 6] = rng.uniform(-np.pi, np.pi, n)
     return b
+
+
+def nms_threshold_golden():
+    """Box pairs whose reference IoU sits exactly on / one ulp around the float threshold 0.01.  Pair p = (A_p, B_p), A_p first
+    (higher score): B_p is suppressed iff iou > 0.01f.  Axis-aligned (yaw 0), pairs 40 m apart so that nothing else overlaps."""
+    th = np.float32(0.01)
+    want = {"equal": th, "above": np.nextafter(th, np.float32(1)), "below": np.nextafter(th, np.float32(0))}
+    rng = np.random.default_rng(77)
+    boxes, kinds = [], []
+    count = {k: 0 for k in want}
+    tries = 0
+    while min(count.values()) < 4 and tries < 20000:
+        tries += 1
+        off = np.float32(40.0 * (len(boxes) // 2) - 200.0)   # the pair's place: searched AT its final coordinates
+        la, wa = np.float32(rng.uniform(2.0, 5.0)), np.float32(rng.uniform(1.0, 2.5))
+        lb, wb = np.float32(rng.uniform(2.0, 5.0)), np.float32(rng.uniform(1.0, 2.5))
+        dy = np.float32(rng.uniform(0.0, 0.5))
+        A = np.array([[off, 0, -1, la, wa, 1.5, 0]], np.float32)
+        # overlap length along x needed for IoU 0.01: ov / (a + b - ov) = t -> ov = t (a + b) / (1 + t); oy = overlap in y
+        oy = min(wa / 2, dy + wb / 2) - max(-wa / 2, dy - wb / 2)
+        if oy <= 0.2:
+            continue
+        ox = float(th) * (la * wa + lb * wb) / (1 + float(th)) / oy
+        bx = np.float32(off + (la + lb) / 2 - ox)
+        hit = None
+        for _ in range(200):                       # walk the floats around the analytic solution
+            B = np.array([[bx, dy, -1, lb, wb, 1.5, 0]], np.float32)
+            v = ref_iou(A, B)[0, 0]
+            for name, target in want.items():
+                if v == target and count[name] < 6 and count[name] <= min(count.values()) + 1:
+                    hit = name
+            if hit:
+                break
+            bx = np.nextafter(bx, np.float32(1e6) if v > th else np.float32(-1e6))
+        if hit:
+            boxes += [A[0].copy(), B[0].copy()]
+            kinds.append(hit)
+            count[hit] += 1
+    assert all(c >= 2 for c in count.values()), count
+    boxes = np.array(boxes, np.float32)
+    iou = ref_iou(boxes, boxes)
+    pair_iou = np.array([iou[2 * i, 2 * i + 1] for i in range(len(kinds))], np.float32)
+    kinds_now = np.array([0 if v == th else 1 if v > th else -1 for v in pair_iou], np.int32)   # after the translation
+    keep = greedy_keep(iou, float(th))
+    np.savez(os.path.join(HERE, "nms_threshold.npz"), boxes=boxes, pair_iou=pair_iou, pair_kind=kinds_now, keep_001=keep,
+             thresh=np.array([th], np.float32))
+    print("nms_threshold.npz:", len(kinds), "pairs; kinds after translation (0 equal / +1 above / -1 below):",
+          np.bincount(kinds_now + 1, minlength=3).tolist(), "kept", len(keep), "of", len(boxes))
 
 
 def main():
@@ -1009,6 +1060,9 @@ if __name__ == "__main__":
     if "--driver-only" in sys.argv:
         driver_golden()
         sys.exit(0)
+    if "--nms-threshold-only" in sys.argv:
+        nms_threshold_golden()
+        sys.exit(0)
     if "--train-wiring-only" in sys.argv:
         train_wiring_golden()
         sys.exit(0)
@@ -1038,3 +1092,4 @@ if __name__ == "__main__":
         wiring_golden()
         train_wiring_golden()
         driver_golden()
+        nms_threshold_golden()

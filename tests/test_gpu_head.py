@@ -57,6 +57,18 @@ def test_nms_keep_lists_vs_reference_golden(golden_dir):
     assert len(_nms(g["dense"][:0], 0.01, 500)) == 0  # empty input
 
 
+def test_nms_predicate_at_its_threshold_vs_reference_golden(golden_dir):
+    """Pairs whose IoU -- as the reference's compiled iou3d_cpu.cpp computes it -- is the float 0.01 itself / one ulp above / one
+    ulp below (axis-aligned boxes: sin 0 and cos 0 are exact on the device too, so this case IS bit-comparable, unlike the
+    rotated ones): the device IoU is the same float and k_nms_mask's `>` suppresses exactly the 'above' partners."""
+    g = G(golden_dir, "nms_threshold.npz")
+    b = g["boxes"]
+    iou = _iou(b, b)
+    pair = np.array([iou[2 * i, 2 * i + 1] for i in range(len(b) // 2)], np.float32)
+    np.testing.assert_array_equal(pair, g["pair_iou"])
+    np.testing.assert_array_equal(_nms(b, float(g["thresh"][0]), 500), g["keep_001"])
+
+
 def test_nms_large_matches_oracle():
     rng = np.random.default_rng(4)
     n = 4096

@@ -73,6 +73,21 @@ def test_nms_keep_lists(golden_dir):
     np.testing.assert_array_equal(R.nms_bev(g["dense"], 0.5), g["keep_05"])
 
 
+def test_nms_predicate_at_its_threshold(golden_dir):
+    """iou > 0.01 (iou3d_nms_kernel.cu:298-307) with the reference's own IoU exactly ON the float threshold and one ulp either
+    side (axis-aligned pairs, tests/golden/make_golden.py: nms_threshold_golden): the oracle's IoU is the same float and its
+    keep list suppresses exactly the 'above' partners."""
+    g = G(golden_dir, "nms_threshold.npz")
+    b, th = g["boxes"], g["thresh"][0]
+    iou = R.iou_bev_matrix(b, b)
+    pair = np.array([iou[2 * i, 2 * i + 1] for i in range(len(b) // 2)], np.float32)
+    np.testing.assert_array_equal(pair, g["pair_iou"])
+    assert set(g["pair_kind"].tolist()) == {-1, 0, 1}
+    np.testing.assert_array_equal((pair > th), g["pair_kind"] == 1)
+    np.testing.assert_array_equal(R.nms_bev(b, float(th)), g["keep_001"])
+    assert len(g["keep_001"]) == len(b) - int((g["pair_kind"] == 1).sum())
+
+
 def test_post_process_end_to_end(golden_dir):
     g = G(golden_dir, "post_process.npz")
     boxes, scores, labels, _ = R.post_process(g["cls"], g["boxes"], 0.1, 0.01, int(g["pre_max"]), int(g["post_max"]))
