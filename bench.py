@@ -200,15 +200,175 @@ def read_profile(lib):
     return {lib.insmos_prof_name(ids[i]).decode(): (ms[i], cnt[i]) for i in range(n)}
 
 
+def synthetic_gt_boxes(rng, m=40):
+    """(1, M, 8) ground-truth boxes [x, y, z, dx, dy, dz, yaw, class 1..3] inside the point-cloud range (what
+    dataloader/datasets.py hands CenterHead.assign_targets; synthetic: there is no dataset here)."""
+    g = np.zeros((1, m, 8), np.float32)
+    g[0, :, 0] = rng.uniform(-55, 55, m)
+    g[0, :, 1] = rng.uniform(-45, 45, m)
+    g[0, :, 2] = rng.uniform(-1.5, -0.5, m)
+    g[0, :, 3:6] = rng.uniform([1.5, 0.6, 1.2], [4.5, 2.0, 1.8], (m, 3))
+    g[0, :, 6] = rng.uniform(-3.1, 3.1, m)
+    g[0, :, 7] = rng.integers(1, 4, m)
+    return g
+
+
+def main_cfg5(args, rank, world, gpu, dev, host_cores):
+    """BASELINE.json configs[4]: one TRAINING step = InsMOS_Model.forward(list, 'train') (models/models.py:313-345: MotionNet and
+    the 3D branch in train mode, CenterHead targets + loss, MOS losses) + backward + Adam (models/models.py:188-193) over a batch
+    of `--windows-per-step` windows per rank; N ranks = DDP (scripts/train.py:74-83): every rank its own windows, gradients
+    all-reduced in 8 MB buckets that leave during backward (insmos_amd/ddp.py).  `value` = windows trained per second, whole job."""
+    import torch.distributed as dist
+    from insmos_amd import _lib, autograd, params as P
+    from insmos_amd.synth import make_labels
+    from insmos_amd.train_unet import InsMOSTrainer
+    if args.train_bf16:
+        os.environ["INSMOS_TRAIN_BF16"] = "1"
+    cfg = P.default_cfg()
+    B = max(1, args.windows_per_step)
+    seeds = [rank * B + i for i in range(B)]
+    wins = load_windows(seeds, args.n_az)
+    rng = np.random.default_rng(1000 + rank)
+    batch = [{"past_point_clouds": torch.from_numpy(w).to(dev),
+              "past_labels": [None, torch.from_numpy(make_labels(w[w[:, 4] == 0], seed=sd_)).to(dev)],
+              "gt_boxes": torch.from_numpy(synthetic_gt_boxes(rng)).to(dev)} for sd_, w in zip(seeds, wins)]
+    tr = InsMOSTrainer(cfg, P.random_state_dict(cfg, 0, cls_bias=-2.0, box_w_std=0.05), device=dev)
+    opt = torch.optim.Adam(list(tr.params.values()), lr=float(cfg["TRAIN"]["LR"]),
+                           weight_decay=float(cfg["TRAIN"].get("WEIGHT_DECAY", 0.0)))
+    red = tr.make_reducer(bucket_bytes=8 << 20, overlap=True) if world > 1 else None
+    lib = _lib.load()
+    last = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = tr.forward(batch, "train")
+        out[0].backward()
+        if red is not None:
+            red.reduce(average=True)
+        opt.step()
+        last["loss"], last["tb"] = out[0], out[1]
+
+    warmup = args.warmup
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * args.steps * B / dt
+    loss = float(last["loss"].detach())
+    out = {
+        "metric": "train_scans_per_sec", "value": round(value, 3),
+        "unit": "windows (N=10 scans, ~120k pts/scan) trained per second: forward + losses + backward + Adam",
+        "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": warmup,
+        "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 conv operands (forward, d/dx), fp32 accumulate / d/dW / BatchNorm / losses" if args.train_bf16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg-5 (BASELINE.json configs[4], NOT the headline): training step of the whole model on synthetic "
+                               "S0-style windows (seeds rank*B ..), synthetic point labels and 40 ground-truth boxes per window, "
+                               "seeded random weights",
+                   "windows_per_step_per_rank": B, "n_az": args.n_az, "points_per_window": int(len(wins[0])),
+                   "optimizer": "Adam(lr=%g, weight_decay=%g)" % (float(cfg["TRAIN"]["LR"]), float(cfg["TRAIN"].get("WEIGHT_DECAY", 0.0))),
+                   "parallelism": f"ddp{world} (per-rank batch of {B} windows; gradients all-reduced in 8 MB buckets during backward)",
+                   "backend": (dist.get_backend() if world > 1 else None), "grad_buckets": (len(red.buckets) if red else 0),
+                   "host_cores_per_rank": host_cores},
+        "ms_per_window": round(1000.0 * dt / (args.steps * B), 3), "timed_region_s": round(dt, 3),
+        "loss": round(loss, 4), "loss_terms": {k: round(float(v), 4) for k, v in dict(last["tb"][0] if isinstance(last["tb"], (list, tuple)) else last["tb"]).items()},
+    }
+    if rank == 0:
+        # ---- roofline of the convolution kernels of the step (forward + d/dx + d/dW, all on the fp32 MFMA path): executed flops
+        # counted at the autograd nodes / their HIP-event time in a second, profiled pass
+        autograd.WORK_COUNTER = {}
+        nprof = 2
+        lib.insmos_prof_reset()
+        lib.insmos_prof_enable(1)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        prof = read_profile(lib)
+        lib.insmos_prof_enable(0)
+        lib.insmos_prof_reset()
+        wc, autograd.WORK_COUNTER = autograd.WORK_COUNTER, None
+        flops = sum(wc.get(k, 0) for k in ("forward", "dx", "dw")) / nprof
+        conv_ms, conv_launches = prof.get("sparse_conv_mfma", (0.0, 0))
+        conv_ms /= nprof
+        ach = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "k_sparse_conv* (forward and d/dx) + k_conv_dw_rows (d/dW) of one training step",
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_step": round(flops / 1e9, 3),
+            "gflop_forward_dx_dw": [round(wc.get(k, 0) / nprof / 1e9, 3) for k in ("forward", "dx", "dw")],
+            "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": conv_launches // nprof,
+            "method": "executed flops = 2 * pairs * Cin * Cout per conv node, for its forward, its d/dx (where the input needs a "
+                      "gradient) and its d/dW launch / HIP-event time of those launches (library profiler, second pass)"}
+        out["kernel_ms_per_step"] = {k: round(v[0] / nprof, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        out["device_ms_per_step_sum"] = round(sum(v[0] for v in prof.values()) / nprof, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            # ---- CPU baseline (a port, bounded sample): the oracle's forward of ONE smaller window + the float64 numpy backward
+            # (oracle/ref_ops.sparse_conv_backward) of the 24 table convolutions of MotionNet on the oracle's own kernel maps.
+            # The 3D branch's backward, BatchNorm and the losses are NOT in it: an UPPER bound of the CPU rate.
+            from oracle import ref_model as M
+            from oracle import ref_ops as R
+            az = args.cpu_sample_az if args.cpu_sample_az != 1886 else 236
+            sw = load_window(0, az)
+            sd = tr.export_state_dict() if hasattr(tr, "export_state_dict") else P.random_state_dict(cfg, 0, cls_bias=-2.0, box_w_std=0.05)
+            t1 = time.perf_counter()
+            M.forward_window(sd, cfg, sw)
+            t_fwd = time.perf_counter() - t1
+            _, dbg = M.motionnet_forward(sd, sw, want_debug=True)
+            t1 = time.perf_counter()
+            rng2 = np.random.default_rng(0)
+            nb = 0
+            for name, ci, co in P.ME_BLOCKS:
+                lvl = {"block1.0": 1, "block2.0": 2, "block3.0": 3, "block6.0": 2, "block7.0": 1, "block8.0": 0}[name]
+                nbr = dbg["nbr81"][lvl]
+                n = nbr.shape[1]
+                for cin_, cout_ in ((ci, co), (co, co)):
+                    taps = rng2.normal(size=(81, cin_, cout_))
+                    R.sparse_conv_backward(rng2.normal(size=(n, cin_)), nbr, taps, rng2.normal(size=(n, cout_)))
+                    nb += 1
+            t_bwd = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(1.0 / (t_fwd + t_bwd), 4), "unit": "windows/s", "cores": R.num_threads(), "kind": "port",
+                "sample": f"ONE window of n_az={az} ({len(sw)} points = {len(sw) / len(wins[0]):.3f} of a bench window): oracle forward "
+                          f"{t_fwd:.1f} s + float64 numpy backward of MotionNet's {nb} 81-tap convolutions {t_bwd:.1f} s; 3D-branch "
+                          "backward, BatchNorm and losses not included (an upper bound of the CPU rate); CPU restatement, NOT the "
+                          "reference's libraries",
+                "seconds": round(t_fwd + t_bwd, 2)}
+        print(json.dumps(out), flush=True)
+    if red is not None:
+        red.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=str, default="cfg2", choices=["cfg2", "cfg4"],
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before the timed ones (default 3; cfg5: 4 -- the caching "
+                    "allocator needs a few training steps to settle, with fewer the timed steps still hit hipMalloc)")
+    ap.add_argument("--config", type=str, default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default, the headline): BASELINE.json configs[1], S0 windows, voxel 0.1 m.  cfg4: configs[3], the dense "
                          "stress scene -- 300k pts/scan (n_az 4710), voxel 0.05 m, BEV 250 x 300 x 640, the 100 000-voxel cap hit "
-                         "(models/models.py:287); launch sets of 2 (a set's level-0 table must stay below 2 GiB), 4 windows per step")
+                         "(models/models.py:287); launch sets of 2 (a set's level-0 table must stay below 2 GiB), 4 windows per step.  "
+                         "cfg5: configs[4], the TRAINING step (forward in train mode, the four losses, backward, Adam; fp32, "
+                         "--train-bf16 for the bf16-operand opt-in), 4 windows per step and rank, gradients all-reduced in buckets "
+                         "over the process group")
+    ap.add_argument("--train-bf16", action="store_true", help="cfg5 only: bf16 operands in the convolutions' forward and d/dx "
+                    "(fp32 accumulate; d/dW, BatchNorm and losses stay fp32) -- a labelled extra, not the fp32 line")
     ap.add_argument("--n-az", type=int, default=None, help="azimuth steps of the synthetic scan (default: 1886 = S0, 120k pts; cfg4: 4710)")
     ap.add_argument("--candidates", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +405,9 @@ def main():
     if args.cpu_sample_az is None:
         args.cpu_sample_az = 1178 if cfg4 else 1886
     if args.windows_per_step is None:
-        args.windows_per_step = 4 if cfg4 else 32
+        args.windows_per_step = 4 if (cfg4 or args.config == "cfg5") else 32
+    if args.warmup is None:
+        args.warmup = 4 if args.config == "cfg5" else 3
     if cfg4:
         os.environ.setdefault("INSMOS_WINDOWS_PER_LAUNCH", "2")
         os.environ.setdefault("INSMOS_WINDOWS_IN_FLIGHT", "2")
@@ -295,6 +457,8 @@ def main():
     from insmos_amd.models import InsMOSNet
     from insmos_amd.synth import make_labels
 
+    if args.config == "cfg5":
+        return main_cfg5(args, rank, world, gpu, dev, host_cores)
     cfg = P.default_cfg()
     if cfg4:
         import copy

@@ -97,6 +97,26 @@ def _pad_cols(x, c):
     return y
 
 
+# bench.py --config cfg5: executed flops of the convolution kernels of a training step (forward, d/dx, d/dW: 2 * pairs * Cin * Cout
+# each, pairs = valid entries of the layer's kernel map).  None = off (the default: counting costs a device reduction per table).
+WORK_COUNTER = None
+_pairs_cache = {}
+
+
+def _count_work(kind, nbr, n_rows, cin, cout):
+    if WORK_COUNTER is None:
+        return
+    if nbr is None:
+        pairs = int(n_rows)
+    else:
+        key = (nbr.data_ptr(), tuple(nbr.shape))
+        if key not in _pairs_cache:
+            _pairs_cache[key] = int((nbr >= 0).sum().item())
+        pairs = _pairs_cache[key]
+    WORK_COUNTER[kind] = WORK_COUNTER.get(kind, 0) + 2 * pairs * cin * cout
+    WORK_COUNTER["launches_" + kind] = WORK_COUNTER.get("launches_" + kind, 0) + 1
+
+
 class SparseConvFunction(torch.autograd.Function):
     """y[o] = sum_k x[nbr[k][o]] @ taps[k] + bias.  nbr (K, n_out) int32 (-1 = no neighbour); nbr_t (K, n_in) int32 is the
     TRANSPOSED table (nbr_t[k][i] = o  <=>  nbr[k][o] = i); for a submanifold layer pass nbr_t=None and the layer's own
@@ -119,6 +139,7 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.prec = current_train_conv_precision()
         y = _conv(lib, xp, n_in, cin_pad, nbr, K, n_out, _packed(lib, taps, cin_pad, cout, False, False, st), bias_pad, cout, st,
                   mask, mode=ctx.prec)
+        _count_work("forward", nbr, n_out, cin, cout)
         ctx.masks = (mask, mask_t)
         ctx.save_for_backward(xp, taps, nbr if nbr is not None else torch.empty(0), nbr_t if nbr_t is not None else torch.empty(0))
         ctx.meta = (K, cin, cout, n_in, n_out, nbr is not None, nbr_t is not None, bias is not None)
@@ -134,6 +155,7 @@ class SparseConvFunction(torch.autograd.Function):
         dy = dy.contiguous().float()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            _count_work("dx", nbr if has_nbr else None, n_out, cin, cout)
             # dx[i] = sum_k dy[nbr_t[k][i]] @ taps[k]^T : the forward kernel, transposed taps, transposed table
             cp = _padc(cout)
             dyp = _pad_cols(dy, cp)
@@ -146,6 +168,7 @@ class SparseConvFunction(torch.autograd.Function):
                 assert n_in == n_out
                 dx = _conv(lib, dyp, n_out, cp, nbr, K, n_in, _packed(lib, taps, cp, cin, True, True, st), zero_b, cin, st, mask, mode=ctx.prec)
         if ctx.needs_input_grad[1]:
+            _count_work("dw", nbr if has_nbr else None, n_out, cin, cout)
             dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dy.device)
             ws = torch.empty(int(lib.insmos_sparse_conv_backward_weight_ws_floats(n_out, K, cin, cout)), dtype=torch.float32,
                              device=dy.device)

@@ -141,3 +141,31 @@ def test_bench_gpus_2_dry_run_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("dp2") and j["config"]["backend"] == "gloo"
     assert j["confusion_points"] == 2 * 2 * 4 * j["config"]["current_points"] or j["confusion_points"] > 2 * 4 * j["config"]["current_points"]
     assert abs(j["value"] - 2 * 2 * 4 / j["timed_region_s"]) / j["value"] < 2e-2
+
+
+def test_bench_cfg5_training_step_two_rank_dry_run():
+    """`bench.py --config cfg5 --gpus 2` (BASELINE.json configs[4], the training step): both ranks on GPU 0 over gloo, bucketed
+    gradient exchange during backward, ONE line from rank 0 with the DDP world in it; and the single-rank line carries the
+    roofline of the convolution kernels (forward + d/dx + d/dW)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--config", "cfg5", "--steps", "2", "--warmup", "1", "--n-az", "160", "--windows-per-step", "2", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-index", "0"] + common,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    j = lines[0]
+    assert j["metric"] == "train_scans_per_sec" and j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("ddp2")
+    assert j["config"]["grad_buckets"] >= 1 and j["config"]["backend"] == "gloo" and j["loss"] > 0
+    assert abs(j["value"] - 2 * 2 * 2 / j["timed_region_s"]) / j["value"] < 2e-2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    j1 = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')][0]
+    rf = j1["roofline"]
+    assert j1["n_gpus"] == 1 and rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["algorithmic_gflop_per_step"] > 0
+    assert len(rf["gflop_forward_dx_dw"]) == 3 and all(v > 0 for v in rf["gflop_forward_dx_dw"])
