@@ -354,6 +354,26 @@ int insmos_tslice_starts_batched(const uint64_t* keys, int64_t n, int max_d, int
  * insmos_sparse_conv over insmos_dense_nbr2d).  Same result as that table path up to fp32 summation order. */
 int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
                        float* out, int ld_out, int cout, int relu, void* stream);
+/* The same layer with CONSTANT-REGION SKIPPING (round 4; csrc/bev.hip): the empty part of a BEV map (86 % of the sites of the S0
+ * window) stays one constant vector per layer through the 3x3 stack of base_bev_backbone.py:33-61 -- layer 0 maps an all-zero
+ * neighbourhood to relu(bias), layer l a neighbourhood that is c_{l-1} everywhere to a fixed c_l -- so 16-site row groups that
+ * hold only such sites skip their matrix work and store c_l.  dist = insmos_bev_distance_map of the scattered voxels, layer =
+ * position in the stack (0 reads the scattered map: its padding value IS the constant; later layers treat sites within layer - 1
+ * of the image border as non-constant), cvec = insmos_bev_constant of this layer (cout floats).  Output bits are those of
+ * insmos_bev_conv3x3 (tests/test_gpu_conv.py). */
+int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                            float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
+                            void* stream);
+size_t insmos_bev_distance_map_ws_bytes(int B, int H, int W);
+/* coords (n, 4) int32 [b, z, y, x] (spconv indices of the voxels HeightCompression scatters, height_compression.py:24-31) ->
+ * dist (B * H * W bytes): Chebyshev distance of every site to the nearest occupied site of its image, capped at cap + 1. */
+int insmos_bev_distance_map(const int32_t* coords, int64_t n, int B, int H, int W, int cap, uint8_t* dist, void* ws, size_t ws_bytes,
+                            void* stream);
+size_t insmos_bev_constant_ws_floats(int cin, int cout);
+/* c_out (cout floats) = what the layer produces at a site whose whole 3x3 neighbourhood is c_in (cin floats; null = zeros),
+ * evaluated by the product kernel itself (same bits); ws: insmos_bev_constant_ws_floats floats, 16-byte aligned. */
+int insmos_bev_constant(const float* wpacked, const float* bias, int cin, int cout, int relu, const float* c_in, float* c_out,
+                        float* ws, void* stream);
 /* Fused BEV deblock + heads (base_bev_backbone.py:104-115, center_head.py:65-72): x (n_site, cin) NHWC BEV features;
  * wd_packed / bd = the ConvTranspose2d(k=2,s=2)+BN as a 1x1 layer with 4*cup outputs laid out [ky][kx][co] (cup = 256);
  * wh_packed / bh = the merged 1x1 heads (cup -> head_cout <= 16).  head ((4*n_site), ld_head): row site*4 + ky*2 + kx.

@@ -88,6 +88,12 @@ SIGNATURES = {
     "insmos_forward_windows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "insmos_tslice_starts_batched": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_conv3x3": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "insmos_bev_conv3x3_skip": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp,
+                                        c_vp]),
+    "insmos_bev_distance_map_ws_bytes": (c_sz, [c_int, c_int, c_int]),
+    "insmos_bev_distance_map": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_bev_constant_ws_floats": (c_sz, [c_int, c_int]),
+    "insmos_bev_constant": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),

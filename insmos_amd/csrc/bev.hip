@@ -34,10 +34,21 @@ constexpr int BEV_PITCH = 24;        // floats per halo site in LDS: 16 channels
 // NCG: output-channel groups (waves = 2 row halves x NCG; a wave owns COT = Cout / 16 / NCG channel tiles)
 // PREC = 3: the split-bf16 x 3 experiment (prec.h; never the default): the halo is split into (hi4 | lo4) bf16 when it is
 // staged into LDS -- once per element, same 16 bytes per lane and the same bank pattern --, the weights arrive pre-split
-template <int TH, int COT, int NCG, bool YM, int PREC = 0>
+// SKIP (round 4): constant-region skipping.  A BEV map is mostly EMPTY (13.6 % of the sites of the S0 window hold a voxel), and an
+// empty region stays a CONSTANT through the stack: layer 0 maps an all-zero 3x3 neighbourhood to relu(bias) =: c_0, and layer
+// l >= 1 maps a neighbourhood that is c_{l-1} everywhere (and inside the image: zero padding breaks the constant) to one fixed
+// vector c_l -- the same expression on the same operands, hence the same bits, at every such site.  c_l depends on the weights
+// only (insmos_bev_constant computes it with THIS kernel on a constant image).  `dist` = Chebyshev distance of every site to the
+// nearest occupied site (bytes, capped); a site is non-constant after layer l iff dist <= reach (= l + 1) or it lies within
+// `breach` (= l - 1; -1 for layer 0, whose constant is the padding value itself) of the image border.  A 16-site row group
+// without such a site skips its MFMAs and LDS reads and stores c_l; a workgroup without one skips its halo loads as well.
+// Output bits are identical with and without SKIP (tests/test_gpu_conv.py, and the native runner against the step path).
+template <int TH, int COT, int NCG, bool YM, int PREC = 0, bool SKIP = false>
 __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty) {
+                                                     float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty,
+                                                     const uint8_t* __restrict__ dist, int reach, int breach,
+                                                     const float* __restrict__ cvec) {
     constexpr int JT = TH / 2;                          // row groups per wave
     constexpr int NSITE = (TH + 2) * BEV_HW;            // halo sites
     constexpr int NTHR = 128 * NCG;
@@ -53,6 +64,30 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     const int u0 = tx * BEV_TW, v0 = ty * TH;
     const int U = YM ? H : W, V = YM ? W : H;
     const int ntile = NCG * COT;
+
+    // ---- SKIP: which of the patch's TH row groups hold a non-constant output site (bit r of `pact`; wave-uniform, and the same in
+    // every wave of the workgroup: each wave looks at the whole patch)
+    uint32_t pact = ~0u;
+    if constexpr (SKIP) {
+        pact = 0;
+        const int gu_l = u0 + (lane & 15);
+#pragma unroll
+        for (int r4 = 0; r4 < TH; r4 += 4) {          // lane group g tests row group r4 + g
+            const int r = r4 + (lane >> 4);
+            const int gv_l = v0 + r;
+            bool on = false;
+            if (r < TH && gu_l < U && gv_l < V) {
+                const int gy_l = YM ? gu_l : gv_l, gx_l = YM ? gv_l : gu_l;
+                const int bd = min(min(gy_l, H - 1 - gy_l), min(gx_l, W - 1 - gx_l));
+                on = (int)dist[((size_t)img * H + gy_l) * W + gx_l] <= reach || bd <= breach;
+            }
+            const unsigned long long bal = __ballot(on);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r4 + q < TH && ((bal >> (16 * q)) & 0xFFFFull)) pact |= 1u << (r4 + q);
+        }
+        pact = __builtin_amdgcn_readfirstlane(pact);
+    }
 
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_img * H * W * ld_x * 4), 0x00020000);
@@ -108,59 +143,77 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     const uint32_t blk_bytes = (uint32_t)ntile * 1024u;          // one (tap, chunk) block
     const uint32_t tap_bytes = (uint32_t)n16 * blk_bytes;
 
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    f32x4 a[3][COT];  // weight ring: item (c, k) lives in slot k % 3 (9 taps = 3 turns: the slot of a tap is chunk-independent)
-    auto load_a = [&](int slot, int k, int c) {
-        const uint32_t so = (uint32_t)k * tap_bytes + (uint32_t)c * blk_bytes;
-#pragma unroll
-        for (int it = 0; it < COT; ++it)
-            a[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, aoff + (uint32_t)it * 1024u, so, 0));
-    };
-    load_a(0, 0, 0);
-    for (int c = 0; c < n16; ++c) {
-        const int buf = c & 1;
-        const float* hb = halo[buf];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            // next item's weights: tap k+1 of this chunk, or tap 0 of the next chunk (clamped on the very last item)
-            if (k < 8) load_a((k + 1) % 3, k + 1, c);
-            else load_a(0, 0, c + 1 < n16 ? c + 1 : c);
-            // the next chunk's halo: requested behind the second tap's weights (so that the first tap's MFMAs wait for
-            // their own operands only), in flight during the rest of this chunk's MFMAs
-            if (k == 1 && c + 1 < n16) fetch(c + 1);
-            const int ky = k / 3, kx = k % 3;
-            const int ku = YM ? ky : kx, kv = YM ? kx : ky;   // tap offset along the patch's fast / slow axis
-            f32x4 b[JT];
-#pragma unroll
-            for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
-            if constexpr (PREC == 3) {
-                s16x4 ah[COT], al[COT];
-#pragma unroll
-                for (int it = 0; it < COT; ++it) unpack_split(a[k % 3][it], ah[it], al[it]);
-#pragma unroll
-                for (int r = 0; r < JT; ++r) {
-                    s16x4 bh, bl;
-                    unpack_split(b[r], bh, bl);
-#pragma unroll
-                    for (int it = 0; it < COT; ++it) {
-                        acc[it][r] = MFMA_BF16(al[it], bh, acc[it][r]);  // small terms first
-                        acc[it][r] = MFMA_BF16(ah[it], bl, acc[it][r]);
-                        acc[it][r] = MFMA_BF16(ah[it], bh, acc[it][r]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int r = 0; r < JT; ++r)
-#pragma unroll
-                        for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
-            }
-        }
-        if (c + 1 < n16) stage(buf ^ 1);  // (that buffer was last read in chunk c-1; every wave is past that barrier)
+    const uint32_t ract = SKIP ? ((pact >> (rh * JT)) & ((1u << JT) - 1u)) : ~0u;   // this wave's row groups
+    if (!SKIP || pact != 0) {
+        fetch(0);
+        stage(0);
         __syncthreads();
+        f32x4 a[3][COT];  // weight ring: item (c, k) lives in slot k % 3 (9 taps = 3 turns: the slot of a tap is chunk-independent)
+        auto load_a = [&](int slot, int k, int c) {
+            const uint32_t so = (uint32_t)k * tap_bytes + (uint32_t)c * blk_bytes;
+    #pragma unroll
+            for (int it = 0; it < COT; ++it)
+                a[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, aoff + (uint32_t)it * 1024u, so, 0));
+        };
+        load_a(0, 0, 0);
+        for (int c = 0; c < n16; ++c) {
+            const int buf = c & 1;
+            const float* hb = halo[buf];
+    #pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                // next item's weights: tap k+1 of this chunk, or tap 0 of the next chunk (clamped on the very last item)
+                if (k < 8) load_a((k + 1) % 3, k + 1, c);
+                else load_a(0, 0, c + 1 < n16 ? c + 1 : c);
+                // the next chunk's halo: requested behind the second tap's weights (so that the first tap's MFMAs wait for
+                // their own operands only), in flight during the rest of this chunk's MFMAs
+                if (k == 1 && c + 1 < n16) fetch(c + 1);
+                const int ky = k / 3, kx = k % 3;
+                const int ku = YM ? ky : kx, kv = YM ? kx : ky;   // tap offset along the patch's fast / slow axis
+                if constexpr (SKIP) {
+                    static_assert(!SKIP || PREC == 0, "constant-region skipping is built for the exact fp32 path");
+                    // row-group major: a skipped group costs one scalar branch; inside a group the COT accumulators alternate, so
+                    // two MFMAs on the same accumulator are 64 cycles apart (dependent latency 40).  Same chain per accumulator.
+    #pragma unroll
+                    for (int r = 0; r < JT; ++r) {
+                        if (!((ract >> r) & 1u)) continue;
+                        const f32x4 br = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
+    #pragma unroll
+                        for (int s = 0; s < 4; ++s)
+    #pragma unroll
+                            for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], br[s], acc[it][r]);
+                    }
+                    continue;
+                }
+                f32x4 b[JT];
+    #pragma unroll
+                for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
+                if constexpr (PREC == 3) {
+                    s16x4 ah[COT], al[COT];
+    #pragma unroll
+                    for (int it = 0; it < COT; ++it) unpack_split(a[k % 3][it], ah[it], al[it]);
+    #pragma unroll
+                    for (int r = 0; r < JT; ++r) {
+                        s16x4 bh, bl;
+                        unpack_split(b[r], bh, bl);
+    #pragma unroll
+                        for (int it = 0; it < COT; ++it) {
+                            acc[it][r] = MFMA_BF16(al[it], bh, acc[it][r]);  // small terms first
+                            acc[it][r] = MFMA_BF16(ah[it], bl, acc[it][r]);
+                            acc[it][r] = MFMA_BF16(ah[it], bh, acc[it][r]);
+                        }
+                    }
+                } else {
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s)
+    #pragma unroll
+                        for (int r = 0; r < JT; ++r)
+    #pragma unroll
+                            for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
+                }
+            }
+            if (c + 1 < n16) stage(buf ^ 1);  // (that buffer was last read in chunk c-1; every wave is past that barrier)
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane (g, j) holds channels co0..co0+3 of site (u0 + j, v0 + rh*JT + r)
@@ -174,6 +227,10 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
 #pragma unroll
         for (int it = 0; it < COT; ++it) {
             const int co0 = (ch * COT + it) * 16 + 4 * g;
+            if (SKIP && !((ract >> r) & 1u)) {   // a constant row group: the layer's constant vector (bias and ReLU included)
+                *(f32x4*)(op + co0) = *(const f32x4*)(cvec + co0);
+                continue;
+            }
             f32x4 v = acc[it][r] + *(const f32x4*)(bias + co0);
             if (relu) {
 #pragma unroll
@@ -184,6 +241,37 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     }
 }
 
+// ---- Chebyshev distance of every BEV site to the nearest occupied site (bytes, capped at cap + 1), two separable passes
+__global__ void k_bev_occupancy(const int32_t* __restrict__ coords, int64_t n, int H, int W, uint8_t* __restrict__ occ) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 q = *(const int4*)(coords + i * 4);   // [b, d, y, x]
+    occ[((int64_t)q.x * H + q.z) * W + q.w] = 1;
+}
+// rowd[site] = min |dx| over occupied sites of the same row within `cap` (cap + 1 if none)
+__global__ void k_bev_dist_rows(const uint8_t* __restrict__ occ, int64_t n_site, int W, int cap, uint8_t* __restrict__ rowd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_site) return;
+    const int x = (int)(i % W);
+    int best = cap + 1;
+    for (int d = 0; d <= cap && d < best; ++d) {
+        if ((x - d >= 0 && occ[i - d]) || (x + d < W && occ[i + d])) best = d;
+    }
+    rowd[i] = (uint8_t)best;
+}
+// dist[site] = min over dy of max(|dy|, rowd[y + dy][x])
+__global__ void k_bev_dist_cols(const uint8_t* __restrict__ rowd, int64_t n_site, int H, int W, int cap, uint8_t* __restrict__ dist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_site) return;
+    const int y = (int)((i / W) % H);
+    int best = cap + 1;
+    for (int d = 0; d <= cap && d < best; ++d) {
+        if (y - d >= 0) best = min(best, max(d, (int)rowd[i - (int64_t)d * W]));
+        if (y + d < H) best = min(best, max(d, (int)rowd[i + (int64_t)d * W]));
+    }
+    dist[i] = (uint8_t)best;
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -191,8 +279,9 @@ using namespace insmos;
 // x (B, H, W, cin) NHWC with row pitch ld_x floats -> out (B, H, W, cout) with row pitch ld_out: 3x3, stride 1, zero
 // padding 1, + bias (folded BatchNorm) + optional ReLU.  wpacked / bias as insmos_pack_weights_host(taps (9, cin, cout))
 // with tap = ky * 3 + kx.  Supported: cin a multiple of 16, cout = 128 or 64.
-extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
-                                  float* out, int ld_out, int cout, int relu, void* stream) {
+static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                            float* out, int ld_out, int cout, int relu, const uint8_t* dist, int reach, int breach,
+                            const float* cvec, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
     if (!x || !wpacked || !bias || !out || cin <= 0 || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || (cout != 128 && cout != 64) ||
         ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
@@ -227,14 +316,18 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
     // wave per SIMD); Cout = 64: 2 x 2 waves of 2 tiles
     // (experiment, never the default: split-bf16 x 3 when the mode is set and this layer's split weights are registered)
     const float* wsplit = conv_precision() == 3 ? (const float*)split_weights_of(wpacked) : nullptr;
+    const bool skip = dist != nullptr && cvec != nullptr && !wsplit;
 #define BEV_GO(TH_, NCG_, YM_)                                                                                                  \
     do {                                                                                                                        \
         if (wsplit)                                                                                                             \
             INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 3>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wsplit, \
-                          bias, out, ld_out, relu, n_tx, n_ty);                                                                 \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr);                                          \
+        else if (skip)                                                                                                          \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0, true>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16,   \
+                          wpacked, bias, out, ld_out, relu, n_tx, n_ty, dist, reach, breach, cvec);                             \
         else                                                                                                                    \
             INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, \
-                          bias, out, ld_out, relu, n_tx, n_ty);                                                                 \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr);                                          \
     } while (0)
 #define BEV_TH(NCG_, YM_) \
     do { if (best_th == 10) BEV_GO(10, NCG_, YM_); else if (best_th == 8) BEV_GO(8, NCG_, YM_); else BEV_GO(4, NCG_, YM_); } while (0)
@@ -243,5 +336,65 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
 #undef BEV_TH
 #undef BEV_GO
     HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                                  float* out, int ld_out, int cout, int relu, void* stream) {
+    return bev_conv3x3_impl(x, B, H, W, ld_x, cin, wpacked, bias, out, ld_out, cout, relu, nullptr, 0, 0, nullptr, stream);
+}
+
+// The same layer with constant-region skipping (see k_bev_conv3x3, SKIP): dist = insmos_bev_distance_map of the map's occupied
+// sites, `layer` = position of this layer in the 3x3 stack (0 = the layer that reads the scattered BEV map), cvec = the layer's
+// constant vector (insmos_bev_constant; relu must be what it was computed with).  Output bits == insmos_bev_conv3x3's.
+extern "C" int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                                       float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
+                                       void* stream) {
+    if (!dist || !cvec || layer < 0 || layer > 200) return INSMOS_EINVAL;
+    return bev_conv3x3_impl(x, B, H, W, ld_x, cin, wpacked, bias, out, ld_out, cout, relu, dist, layer + 1, layer - 1, cvec, stream);
+}
+
+extern "C" size_t insmos_bev_distance_map_ws_bytes(int B, int H, int W) { return 2 * pad256((size_t)B * H * W); }
+
+// coords (n, 4) int32 [b, z, y, x] of the voxels scattered into the BEV map (spconv indices of the last encoder level) ->
+// dist (B * H * W bytes): Chebyshev distance to the nearest occupied site, capped at cap + 1 (cap <= 254)
+extern "C" int insmos_bev_distance_map(const int32_t* coords, int64_t n, int B, int H, int W, int cap, uint8_t* dist, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || cap < 0 || cap > 254 || !dist || !ws || (n > 0 && !coords) ||
+        ws_bytes < insmos_bev_distance_map_ws_bytes(B, H, W))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_site = (int64_t)B * H * W;
+    uint8_t* occ = (uint8_t*)ws;
+    uint8_t* rowd = occ + pad256((size_t)n_site);
+    ProfScope ps(KK_TO_BEV, s);
+    HIP_TRY(hipMemsetAsync(occ, 0, (size_t)n_site, s));
+    if (n > 0) INSMOS_LAUNCH(k_bev_occupancy, dim3(cdiv(n, 256)), dim3(256), 0, s, coords, n, H, W, occ);
+    INSMOS_LAUNCH(k_bev_dist_rows, dim3(cdiv(n_site, 256)), dim3(256), 0, s, occ, n_site, W, cap, rowd);
+    INSMOS_LAUNCH(k_bev_dist_cols, dim3(cdiv(n_site, 256)), dim3(256), 0, s, rowd, n_site, H, W, cap, dist);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_bev_constant_ws_floats(int cin, int cout) { return (size_t)25 * (size_t)(cin + cout) + 64; }
+
+// The constant a 3x3 layer maps a constant neighbourhood to: c_out = epilogue(conv(x == c_in everywhere)) evaluated by the product
+// kernel itself at the centre of a 5 x 5 image filled with c_in (cin floats; null = zeros), so that it carries exactly the bits
+// the kernel produces at such a site.  Depends on the weights only: computed once per checkpoint and layer.
+extern "C" int insmos_bev_constant(const float* wpacked, const float* bias, int cin, int cout, int relu, const float* c_in,
+                                   float* c_out, float* ws, void* stream) {
+    if (!wpacked || !bias || !c_out || !ws || cin <= 0 || cin % 16 != 0 || (cout != 64 && cout != 128)) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* img = ws;                       // (25, cin)
+    float* res = ws + (((size_t)25 * cin + 63) & ~(size_t)63);   // (25, cout), 256-byte aligned
+    if (c_in) {
+        for (int i = 0; i < 25; ++i)
+            HIP_TRY(hipMemcpyAsync(img + (size_t)i * cin, c_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(hipMemsetAsync(img, 0, (size_t)25 * cin * sizeof(float), s));
+    }
+    int rc = bev_conv3x3_impl(img, 1, 5, 5, cin, cin, wpacked, bias, res, cout, cout, relu, nullptr, 0, 0, nullptr, stream);
+    if (rc != INSMOS_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c_out, res + (size_t)12 * cout, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     return INSMOS_OK;
 }

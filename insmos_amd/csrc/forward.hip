@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -31,7 +32,42 @@ struct Ctx {
     // quantise + sort + read-back through the fallback; a context that has seen one starts at the pair sort from then on (far
     // returns are a property of the sensor / voxel size, not of one window).  Re-armed every 256 sets.
     mutable std::atomic<int> packed_overflow{0};
+    // constant vectors of the dense BEV stack ((n_bev_layers + 1) x 128 floats; csrc/bev.hip, SKIP): functions of the weights only,
+    // computed with the product kernel on the first forward of the context
+    mutable std::mutex bev_mu;
+    mutable float* bev_const = nullptr;
+    ~Ctx() {
+        if (bev_const) (void)hipFree(bev_const);
+    }
 };
+
+// c_0 = relu(bias_0), c_l = layer l applied to a neighbourhood that is c_{l-1} everywhere (insmos_bev_constant)
+int ensure_bev_constants(const Ctx& C, hipStream_t s, const float** out) {
+    std::lock_guard<std::mutex> lk(C.bev_mu);
+    if (!C.bev_const) {
+        const int L = C.cfg.n_bev_layers + 1;
+        float* cv = nullptr;
+        float* ws = nullptr;
+        HIP_TRY(hipMalloc(&cv, (size_t)L * 128 * sizeof(float)));
+        size_t wsf = 0;
+        for (int l = 0; l < L; ++l) {
+            const InsmosConvW& w = C.L.at("bev" + std::to_string(l));
+            wsf = std::max(wsf, insmos_bev_constant_ws_floats(w.cin, w.cout));
+        }
+        if (hipMalloc(&ws, wsf * sizeof(float)) != hipSuccess) { (void)hipFree(cv); return INSMOS_EHIP; }
+        int rc = INSMOS_OK;
+        for (int l = 0; l < L && rc == INSMOS_OK; ++l) {
+            const InsmosConvW& w = C.L.at("bev" + std::to_string(l));
+            rc = insmos_bev_constant(w.w, w.b, w.cin, w.cout, 1, l ? cv + (size_t)(l - 1) * 128 : nullptr, cv + (size_t)l * 128, ws, s);
+        }
+        if (rc == INSMOS_OK && hipStreamSynchronize(s) != hipSuccess) rc = INSMOS_EHIP;
+        (void)hipFree(ws);
+        if (rc != INSMOS_OK) { (void)hipFree(cv); return rc; }
+        C.bev_const = cv;
+    }
+    *out = C.bev_const;
+    return INSMOS_OK;
+}
 
 struct Arena {
     char* base;
@@ -688,9 +724,35 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     bool tb_ready = B == 1;  // (a batch builds its stacked 9-tap table only if a layer falls back to the generic kernel)
     // the dense 3x3 layers: LDS-tiled implicit GEMM (csrc/bev.hip) for the shapes it is built for, else the 9-tap table
     static const bool bev_kernel = [] { const char* e = getenv("INSMOS_BEV_KERNEL"); return !(e && e[0] == '0'); }();
+    // constant-region skipping (csrc/bev.hip, SKIP): the empty part of the map stays a per-layer constant through the stack; row
+    // groups of constant sites skip their MFMAs and store the constant.  Same bits (INSMOS_BEV_SKIP=0 computes every site).
+    static const bool bev_skip = [] { const char* e = getenv("INSMOS_BEV_SKIP"); return !(e && e[0] == '0'); }();
+    const uint8_t* bev_dist = nullptr;
+    const float* bev_cv = nullptr;
+    if (bev_kernel && bev_skip) {
+        bool all_ok = true;
+        for (int k = 0; k <= g.n_bev_layers; ++k) {
+            const InsmosConvW* w = Lr("bev" + std::to_string(k));
+            all_ok = all_ok && w && w->K == 9 && w->cin % 16 == 0 && (w->cout == 64 || w->cout == 128);
+        }
+        if (all_ok) {
+            CK(ensure_bev_constants(C, s, &bev_cv));
+            uint8_t* d = A.take<uint8_t>((size_t)nsite);
+            const size_t wsb = insmos_bev_distance_map_ws_bytes(B, g.bevH, g.bevW);
+            void* ws = A.take<char>(wsb);
+            NEED_ARENA();
+            CK(insmos_bev_distance_map(co[5], nv[5], B, g.bevH, g.bevW, g.n_bev_layers + 1, d, ws, wsb, s));
+            bev_dist = d;
+        }
+    }
+    int bev_layer = 0;
     auto bev_conv = [&](const std::string& name, const float* x, int ld_in, float* o) -> int {
         const InsmosConvW* w = Lr(name);
         if (!w) return INSMOS_EINVAL;
+        const int layer = bev_layer++;
+        if (bev_kernel && bev_dist)
+            return insmos_bev_conv3x3_skip(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, bev_dist, layer,
+                                           bev_cv + (size_t)layer * 128, s);
         if (bev_kernel && w->K == 9 && w->cin % 16 == 0 && (w->cout == 64 || w->cout == 128))
             return insmos_bev_conv3x3(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, s);
         if (!tb_ready) {

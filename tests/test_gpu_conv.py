@@ -568,3 +568,75 @@ def test_lds_staged_81_tap_kernel_is_bitwise_the_generic_one(cin, cout, res_mode
     assert torch.equal(run(1), a)                                       # deterministic
     for r0 in (16, 64 * 5 + 32, 64 * 30):
         assert torch.equal(run(1, r0)[r0:], b[r0:])                     # a row suffix: other block boundaries, the same rows' bits
+
+
+@pytest.mark.parametrize("B,H,W,c0", [(1, 125, 150, 256), (3, 37, 53, 32), (2, 16, 20, 64)])
+def test_bev_constant_region_skipping_is_bitwise_the_dense_kernel(B, H, W, c0):
+    """insmos_bev_conv3x3_skip against insmos_bev_conv3x3 over a stack of three 3x3 layers on a mostly EMPTY map (the BEV map of a
+    LiDAR window: 14 % of the sites occupied): the empty region stays one constant vector per layer (insmos_bev_constant, evaluated
+    by the kernel itself), row groups of constant sites skip their matrix work -- every output bit equal, layer after layer, with
+    the constant really reached far from the occupied sites, zero padding honoured at the image border, an all-empty image and an
+    all-occupied one in the batch."""
+    from gpu_util import dev, lib, pack_layer, stream
+    from insmos_amd import params as P, _lib
+    rng = np.random.default_rng(B * 100 + H)
+    occ = np.zeros((B, H, W), bool)
+    for b in range(B):
+        for _ in range(max(1, H * W // 400)):                      # a few blobs per image
+            y, x = rng.integers(0, H), rng.integers(0, W)
+            occ[b, max(0, y - 1):y + 2, max(0, x - 2):x + 2] |= rng.uniform(size=occ[b, max(0, y - 1):y + 2, max(0, x - 2):x + 2].shape) < 0.6
+    if B >= 2:
+        occ[1] = False                                              # an image without a single voxel
+    if B >= 3:
+        occ[2] = True                                               # and a full one
+    x0 = np.zeros((B, H, W, c0), np.float32)
+    x0[occ] = np.abs(rng.normal(size=(int(occ.sum()), c0))).astype(np.float32)
+    ys, xs = np.nonzero(occ.reshape(B * H, W))
+    coords = np.stack([ys // H, np.zeros_like(ys), ys % H, xs], 1).astype(np.int32)   # [b, z, y, x]
+    chans = [c0, 128, 128, 128]
+    layers = []
+    for l in range(3):
+        w = (rng.normal(size=(chans[l + 1], chans[l], 3, 3)) * (1.0 / np.sqrt(9 * chans[l]))).astype(np.float32)
+        layers.append(pack_layer(P.conv2d_weight_to_taps(w), (rng.normal(size=chans[l + 1]) * 0.3).astype(np.float32), chans[l], chans[l + 1]))
+    L = lib()
+    st = stream()
+    dist = torch.empty(B * H * W, dtype=torch.uint8, device="cuda:0")
+    ws = torch.empty(int(L.insmos_bev_distance_map_ws_bytes(B, H, W)), dtype=torch.uint8, device="cuda:0")
+    cd = dev(coords) if len(coords) else None
+    _lib.check(L.insmos_bev_distance_map(cd.data_ptr() if cd is not None else None, len(coords), B, H, W, 4, dist.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), st), "insmos_bev_distance_map")
+    # the distance map against a brute-force numpy one (capped at cap + 1 = 5)
+    want = np.full((B, H, W), 5, np.int64)
+    for b in range(B):
+        oy, ox = np.nonzero(occ[b])
+        if len(oy):
+            yy, xx = np.mgrid[0:H, 0:W]
+            d = np.maximum(np.abs(yy[..., None] - oy), np.abs(xx[..., None] - ox)).min(-1)
+            want[b] = np.minimum(d, 5)
+    np.testing.assert_array_equal(dist.cpu().numpy().reshape(B, H, W).astype(np.int64), want)
+    consts, prev = [], None
+    for l in range(3):
+        cv = torch.empty(128, device="cuda:0")
+        wsf = torch.empty(int(L.insmos_bev_constant_ws_floats(chans[l], 128)), device="cuda:0")
+        _lib.check(L.insmos_bev_constant(layers[l].w.data_ptr(), layers[l].b.data_ptr(), chans[l], 128, 1,
+                                         prev.data_ptr() if prev is not None else None, cv.data_ptr(), wsf.data_ptr(), st), "insmos_bev_constant")
+        consts.append(cv)
+        prev = cv
+    xa = dev(x0.reshape(B * H * W, c0))
+    xb = xa.clone()
+    for l in range(3):
+        oa = torch.empty((B * H * W, 128), device="cuda:0")
+        ob = torch.full((B * H * W, 128), -3.0, device="cuda:0")
+        _lib.check(L.insmos_bev_conv3x3(xa.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(),
+                                        oa.data_ptr(), 128, 128, 1, st), "insmos_bev_conv3x3")
+        _lib.check(L.insmos_bev_conv3x3_skip(xb.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(),
+                                             ob.data_ptr(), 128, 128, 1, dist.data_ptr(), l, consts[l].data_ptr(), st), "insmos_bev_conv3x3_skip")
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob), (l, float((oa - ob).abs().max()))
+        # the constant is what the kernel computes far from every voxel and from the border (when the map has such a site)
+        far = (want > l + 1)
+        far[:, :max(l, 0), :] = False; far[:, H - max(l, 0):, :] = False; far[:, :, :max(l, 0)] = False; far[:, :, W - max(l, 0):] = False
+        if far.any():
+            rows = oa.reshape(B, H, W, 128)[torch.from_numpy(far).cuda()]
+            assert torch.equal(rows, consts[l].expand_as(rows)), l
+        xa, xb = oa, ob
