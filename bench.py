@@ -608,12 +608,14 @@ def main():
             f_ref = eng.algorithmic_work()["flops"]
             flops_ref += f_ref
             eng.prune_dead_rows = True
+            eng.bev_skip_accounting = os.environ.get("INSMOS_BEV_SKIP", "1") != "0"   # count what the runner's BEV kernels execute
             eng.forward_window(p, native=False)  # fills the launch log the EXECUTED work is counted from
             wk = eng.algorithmic_work()
             flops += wk["flops"]
             gather += wk["gather_bytes"]
             comp += wk["compulsory_bytes"]
             launches = wk["launches"]
+            eng.bev_skip_accounting = False
             seen_work[sd_] = (f_ref, wk)
             if counts0 is None:
                 counts0 = dict(eng.last_counts)
@@ -653,8 +655,9 @@ def main():
                               if traffic else None,
             "algorithmic_gflop_per_window": round(flops_w / 1e9, 3),
             "reference_gflop_per_window": round(flops_ref_w / 1e9, 3),
-            "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed); MotionNet rows "
-                         "nothing consumes are skipped (DESIGN.md 3.3), the reference computes reference_gflop_per_window",
+            "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed): MotionNet rows nothing "
+                         "consumes are skipped (DESIGN.md 3.3) and so are the BEV row groups that hold only the layer's constant "
+                         "(DESIGN.md 3.9); the reference computes reference_gflop_per_window",
             "method": f"one launch set of {wpl} windows at a time on one stream: achieved = algorithmic FLOP of the conv "
                       "launches / sum of their HIP-event durations (= rocprofv3 kernel stats of INSMOS_WINDOWS_IN_FLIGHT=1 "
                       "bench.py --timed-only, tools/roofline_from_rocprof.py)",

@@ -369,6 +369,9 @@ size_t insmos_bev_distance_map_ws_bytes(int B, int H, int W);
  * dist (B * H * W bytes): Chebyshev distance of every site to the nearest occupied site of its image, capped at cap + 1. */
 int insmos_bev_distance_map(const int32_t* coords, int64_t n, int B, int H, int W, int cap, uint8_t* dist, void* ws, size_t ws_bytes,
                             void* stream);
+/* Accounting (bench.py's executed-flop count): the (site, tap) pairs insmos_bev_conv3x3_skip computes for `layer`; *pairs_dev =
+ * 8 bytes of device memory. */
+int insmos_bev_skip_executed_pairs(const uint8_t* dist, int B, int H, int W, int layer, unsigned long long* pairs_dev, void* stream);
 size_t insmos_bev_constant_ws_floats(int cin, int cout);
 /* c_out (cout floats) = what the layer produces at a site whose whole 3x3 neighbourhood is c_in (cin floats; null = zeros),
  * evaluated by the product kernel itself (same bits); ws: insmos_bev_constant_ws_floats floats, 16-byte aligned. */

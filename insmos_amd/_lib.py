@@ -92,6 +92,7 @@ SIGNATURES = {
                                         c_vp]),
     "insmos_bev_distance_map_ws_bytes": (c_sz, [c_int, c_int, c_int]),
     "insmos_bev_distance_map": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_bev_skip_executed_pairs": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "insmos_bev_constant_ws_floats": (c_sz, [c_int, c_int]),
     "insmos_bev_constant": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),

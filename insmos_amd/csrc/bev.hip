@@ -272,6 +272,33 @@ __global__ void k_bev_dist_cols(const uint8_t* __restrict__ rowd, int64_t n_site
     dist[i] = (uint8_t)best;
 }
 
+// valid (in-image) taps of the in-image sites of the row groups the SKIP kernel computes for `layer` (accounting only)
+__global__ void k_bev_skip_pairs(const uint8_t* __restrict__ dist, int n_img, int H, int W, int ym, int reach, int breach,
+                                 unsigned long long* __restrict__ out) {
+    const int U = ym ? H : W, V = ym ? W : H;
+    const int n_tu = (U + 15) / 16;
+    const int64_t grp = (int64_t)blockIdx.x * (blockDim.x / 16) + threadIdx.x / 16;   // 16 lanes = one row group
+    const int j = threadIdx.x & 15;
+    const int64_t n_grp = (int64_t)n_img * V * n_tu;
+    bool on = false;
+    int taps = 0;
+    if (grp < n_grp) {
+        const int img = (int)(grp / ((int64_t)V * n_tu));
+        const int v = (int)((grp / n_tu) % V), u = (int)(grp % n_tu) * 16 + j;
+        if (u < U) {
+            const int gy = ym ? u : v, gx = ym ? v : u;
+            const int bd = min(min(gy, H - 1 - gy), min(gx, W - 1 - gx));
+            on = (int)dist[((size_t)img * H + gy) * W + gx] <= reach || bd <= breach;
+            taps = ((gy > 0) + 1 + (gy < H - 1)) * ((gx > 0) + 1 + (gx < W - 1));
+        }
+    }
+    // any lane of the 16-lane group on -> the whole group is computed
+    const unsigned long long bal = __ballot(on);
+    const int sh = (threadIdx.x & 63) & ~15;
+    const bool grp_on = ((bal >> sh) & 0xFFFFull) != 0;
+    if (grp_on && taps) atomicAdd(out, (unsigned long long)taps);
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -279,19 +306,10 @@ using namespace insmos;
 // x (B, H, W, cin) NHWC with row pitch ld_x floats -> out (B, H, W, cout) with row pitch ld_out: 3x3, stride 1, zero
 // padding 1, + bias (folded BatchNorm) + optional ReLU.  wpacked / bias as insmos_pack_weights_host(taps (9, cin, cout))
 // with tap = ky * 3 + kx.  Supported: cin a multiple of 16, cout = 128 or 64.
-static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
-                            float* out, int ld_out, int cout, int relu, const uint8_t* dist, int reach, int breach,
-                            const float* cvec, void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
-    if (!x || !wpacked || !bias || !out || cin <= 0 || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || (cout != 128 && cout != 64) ||
-        ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
-        (int64_t)B * H * W * ld_x * 4 >= (1ll << 31))
-        return INSMOS_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const int n16 = cin / 16;
-    // patch shape: 16 sites along one axis x TH in {10, 8, 4} along the other.  Every site's value is the same expression
-    // whatever patch it falls into, so the choice is free: least padded work, at least one workgroup per CU, tallest wins ties
-    // (a taller patch re-uses each weight fragment for more row groups).
+// patch shape: 16 sites along one axis x TH in {10, 8, 4} along the other.  Every site's value is the same expression
+// whatever patch it falls into, so the choice is free: least padded work, at least one workgroup per CU, tallest wins ties
+// (a taller patch re-uses each weight fragment for more row groups).
+static void bev_choose_patch(int B, int H, int W, int* th_out, int* ym_out) {
     constexpr int kCUs = 256;  // MI355X
     int best_th = 0, best_ym = 0;
     double best_cost = 1e30;
@@ -307,6 +325,22 @@ static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int c
             cost /= 0.5 + 0.5 * last_round;                                 // a part-empty last round of workgroups
             if (cost < best_cost) { best_cost = cost; best_th = th; best_ym = ym; }
         }
+    *th_out = best_th;
+    *ym_out = best_ym;
+}
+
+static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                            float* out, int ld_out, int cout, int relu, const uint8_t* dist, int reach, int breach,
+                            const float* cvec, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
+    if (!x || !wpacked || !bias || !out || cin <= 0 || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || (cout != 128 && cout != 64) ||
+        ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
+        (int64_t)B * H * W * ld_x * 4 >= (1ll << 31))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int n16 = cin / 16;
+    int best_th = 0, best_ym = 0;
+    bev_choose_patch(B, H, W, &best_th, &best_ym);
     const int U = best_ym ? H : W, V = best_ym ? W : H;
     const int n_tx = (U + BEV_TW - 1) / BEV_TW, n_ty = (V + best_th - 1) / best_th;
     const unsigned grid = (unsigned)((int64_t)B * n_ty * n_tx);
@@ -396,5 +430,22 @@ extern "C" int insmos_bev_constant(const float* wpacked, const float* bias, int 
     int rc = bev_conv3x3_impl(img, 1, 5, 5, cin, cin, wpacked, bias, res, cout, cout, relu, nullptr, 0, 0, nullptr, stream);
     if (rc != INSMOS_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c_out, res + (size_t)12 * cout, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return INSMOS_OK;
+}
+
+// Accounting (bench.py): the (site, tap) pairs insmos_bev_conv3x3_skip executes for `layer` on a (B, H, W) map with this distance
+// map -- in-image taps of the in-image sites of the 16-site row groups (in the orientation the launcher picks) that hold a
+// non-constant site.  *pairs_dev (device, 8 bytes) is overwritten.
+extern "C" int insmos_bev_skip_executed_pairs(const uint8_t* dist, int B, int H, int W, int layer, unsigned long long* pairs_dev,
+                                              void* stream) {
+    if (!dist || !pairs_dev || B <= 0 || H <= 0 || W <= 0 || layer < 0) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int th = 0, ym = 0;
+    bev_choose_patch(B, H, W, &th, &ym);
+    const int U = ym ? H : W, V = ym ? W : H;
+    const int64_t n_grp = (int64_t)B * V * ((U + 15) / 16);
+    HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long), s));
+    INSMOS_LAUNCH(k_bev_skip_pairs, dim3(cdiv(n_grp, 16)), dim3(256), 0, s, dist, B, H, W, ym, layer + 1, layer - 1, pairs_dev);
+    HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -340,6 +340,12 @@ class Engine:
                        "insmos_bev_conv3x3")
             self._conv_log.append((self.nbr_bev, nsite, layer, 0))
             self._conv_nin.append(nsite)
+            if getattr(self, "_bev_dist", None) is not None:
+                # accounting only (bench.py): the pairs the native runner's constant-region skipping executes for this layer
+                cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+                _lib.check(self.lib.insmos_bev_skip_executed_pairs(self._bev_dist.data_ptr(), 1, self.bevH, self.bevW, int(layer.name[3:]),
+                                                                   cnt.data_ptr(), self._stream()), "insmos_bev_skip_executed_pairs")
+                self._bev_exec_pairs[layer.name] = int(cnt.item())
         else:
             self.conv(layer, x, ld_in, self.nbr_bev, nsite, out, ld_out, relu_post=1)
 
@@ -707,6 +713,14 @@ class Engine:
                                             self.bevW, bev.data_ptr(), st), "insmos_sparse_to_bev")
         nf = L["bev0"].cout
         fa, fb = E((nsite, nf)), E((nsite, nf))
+        # (the step path computes every site -- it is the cross-check of the native runner's constant-region skipping, csrc/bev.hip;
+        #  with bev_skip_accounting it also COUNTS what the runner executes, for the roofline numerator of bench.py)
+        self._bev_dist, self._bev_exec_pairs = None, {}
+        if getattr(self, "bev_skip_accounting", False):
+            self._bev_dist = torch.empty(nsite, dtype=torch.uint8, device=self.device)
+            wsd = torch.empty(int(lib.insmos_bev_distance_map_ws_bytes(1, self.bevH, self.bevW)), dtype=torch.uint8, device=self.device)
+            _lib.check(lib.insmos_bev_distance_map(coords[5].data_ptr(), nv[5], 1, self.bevH, self.bevW, self.n_bev_layers + 1,
+                                                   self._bev_dist.data_ptr(), wsd.data_ptr(), wsd.numel(), st), "insmos_bev_distance_map")
         self.bev_conv(L["bev0"], bev, self.nbev, fa, nf)
         for k in range(self.n_bev_layers):
             self.bev_conv(L[f"bev{k + 1}"], fa, nf, fb, nf)
@@ -1052,6 +1066,8 @@ class Engine:
                     cache[key] = int((tab[:, row0:] >= 0).sum().item())
                 pairs = cache[key]
             cin = layer.flops_per_pair // (2 * layer.cout_real)
+            if nbr is self.nbr_bev and layer.name in getattr(self, "_bev_exec_pairs", {}):
+                pairs = self._bev_exec_pairs[layer.name]   # executed by the runner's constant-region skipping (bev_skip_accounting)
             flops += pairs * layer.flops_per_pair
             gather += 4 * pairs * (cin + layer.cout_real) + 8 * pairs
             pairs_total += pairs

@@ -34,6 +34,8 @@ def layer_work(eng):
                 tab = nbr.nbr if isinstance(nbr, NbrTable) else nbr
                 cache[key] = int((tab[:, row0:] >= 0).sum().item())
             pairs = cache[key]
+        if layer.name in getattr(eng, "_bev_exec_pairs", {}):      # what the runner's constant-region skipping executes
+            pairs = eng._bev_exec_pairs[layer.name]
         if layer.name == "head" and rows and rows[-1][0] == "deconv":   # one fused launch (k_deconv_head)
             nm, K, ci, co, r, fl = rows[-1]
             rows[-1] = ("deconv+head", K, ci, co, r, fl + pairs * layer.flops_per_pair)
@@ -54,9 +56,11 @@ def main():
         eng.set_conv_precision(int(os.environ["INSMOS_CONV_PRECISION"]))
     lib = eng.lib
     per_win = []
+    eng.bev_skip_accounting = os.environ.get("INSMOS_BEV_SKIP", "1") != "0"
     for w in wins:
         eng.forward_window(w, native=False)
         per_win.append(layer_work(eng))
+    eng.bev_skip_accounting = False
     n_layers = len(per_win[0])
     kk = next(k for k in range(64) if lib.insmos_prof_name(k) == b"sparse_conv_mfma")
 

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""tools/pmc_gather_layers.py -- HBM bytes and GB/s PER LAYER of the convolution launches of one launch set, in particular the
+81-tap small-channel layers (the "rulebook gather" the north star asks evidence for), with the FETCH_SIZE counter CALIBRATED on
+launches of the same kernels over tables with a known byte count (the microarch guide calibrates the gfx950 x2 correction for
+16 B/lane streaming only).
+
+Two roles:
+  workload (no arguments; run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE`, tools/pmc_gather_layers.sh):
+      1. calibration launches: insmos_sparse_conv on a shifted-identity table (tap k of row r = row (r + 64 k) mod n: every tap
+         gathers a coalesced run of rows; every table entry is needed exactly once from HBM per launch, the features once -- the
+         table is far larger than L2 + MALL) -- known bytes = 4 K n (table) + 4 n Cin (features) read, 4 n Cout written -- for the
+         row-lane kernel (8 -> 8) and the MFMA quad kernel (8 -> 8, 16 -> 16), plus a device-to-device copy of 1 GiB;
+      2. one warm-up and ONE measured launch set of 8 windows through the native runner (the product path);
+      writes gpurun_out/pmc_gather/workload.json: the calibration launches' known bytes and the measured set's layer list.
+  join (`--join DIR TAG`): reads the two passes' counter_collection + kernel_trace CSVs, prints / writes the per-layer table.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CONV_KERNELS = ("k_sparse_conv", "k_conv_rowlane", "k_deconv_head", "k_bev_conv3x3", "k_const_conv125")
+
+
+def workload():
+    import numpy as np
+    import torch
+    import bench
+    from insmos_amd import _lib, params as P
+    from insmos_amd.engine import ConvLayer
+    from insmos_amd.models import InsMOSNet
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from batch_layers import layer_work
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    out = {"calibration": []}
+    # ---- 1. calibration launches (81 * 1.5 M * 4 B = 486 MB of table: beyond L2 + MALL)
+    n, K = 1_500_000, 81
+    r = torch.arange(n, dtype=torch.int64, device=dev)
+    nbr = torch.stack([((r + 64 * k) % n).to(torch.int32) for k in range(K)]).contiguous()
+    rng = np.random.default_rng(0)
+    for cin, cout, mode, label in ((8, 8, 15, "rowlane 8->8"), (8, 8, 0, "mfma quad 8->8"), (16, 16, 0, "mfma quad 16->16")):
+        taps = (rng.normal(size=(K, cin, cout)) * 0.05).astype(np.float32)
+        layer = ConvLayer(lib, taps, np.zeros(cout, np.float32), cin, cout, dev)
+        x = torch.randn((n, cin), device=dev)
+        y = torch.empty((n, cout), device=dev)
+        lib.insmos_debug_conv_rowlane(mode, 1)
+        for _ in range(2):   # (the join reads the second launch: caches in steady state)
+            _lib.check(lib.insmos_sparse_conv(x.data_ptr(), n, cin, cin, nbr.data_ptr(), None, K, n, layer.w.data_ptr(), layer.b.data_ptr(),
+                                              y.data_ptr(), cout, cout, None, 0, 0, 0, 1, st), "insmos_sparse_conv")
+        torch.cuda.synchronize()
+        out["calibration"].append({"label": label, "K": K, "cin": cin, "cout": cout, "rows": n,
+                                   "known_read_bytes": 4 * K * n + 4 * n * cin, "known_write_bytes": 4 * n * cout})
+    lib.insmos_debug_conv_rowlane(-1, 0)
+    del nbr
+    # ---- 2. the product path: one launch set of 8 windows
+    B = 8
+    cfg = P.default_cfg()
+    model = InsMOSNet(cfg, state_dict=P.random_state_dict(cfg, seed=0)).cuda().eval()
+    wins = [torch.from_numpy(w).cuda() for w in bench.load_windows(list(range(B)), 1886)]
+    bench.calibrate_head(model, wins[0], 1500, cache="/tmp/insmos_bench_calibration.json", tag="rank0_az1886_c1500")
+    eng = model.model.engine
+    per_win = []
+    for w in wins:
+        eng.forward_window(w, native=False)
+        per_win.append(layer_work(eng))
+    lib.insmos_forward_streams(0)
+    eng.forward_windows(wins)
+    torch.cuda.synchronize()
+    eng.forward_windows(wins)          # <- the measured set: the LAST conv launches of the trace
+    torch.cuda.synchronize()
+    layers = []
+    for i, (name, Kk, ci, co, _, _) in enumerate(per_win[0]):
+        layers.append({"name": name, "K": Kk, "cin": ci, "cout": co, "rows": sum(pw[i][4] for pw in per_win),
+                       "flops": sum(pw[i][5] for pw in per_win)})
+    out["layers"] = layers
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "pmc_gather"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "pmc_gather", "workload.json"), "w"), indent=1)
+    print("calibration launches:", len(out["calibration"]), "layers:", len(layers))
+
+
+def _read(root, counter):
+    f = glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def join(root, tag):
+    wl = json.load(open(os.path.join(root, "workload.json")))
+    res = {}
+    ncal = 2 * len(wl["calibration"])
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        conv = [r for r in _read(root, c) if any(k in r["Kernel_Name"] for k in CONV_KERNELS)]
+        assert len(conv) >= ncal + 2 * len(wl["layers"]), (len(conv), ncal, len(wl["layers"]))
+        res[c] = {"cal": conv[:ncal], "set": conv[-len(wl["layers"]):]}
+    tf = glob.glob(os.path.join(root, "FETCH_SIZE", "**", "*kernel_trace.csv"), recursive=True)[0]
+    dur = {int(r["Dispatch_Id"]): (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in csv.DictReader(open(tf))}
+    KB = 1024.0
+    out = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/pmc_gather_layers.sh); counter "
+                     "unit KB; fetch factor = known read bytes / raw FETCH_SIZE of a launch of the SAME kernel over a shifted-identity "
+                     "table (every table entry and every feature row needed once from HBM); layers of kernels without a "
+                     "calibration launch use the guide's x2", "calibration": [], "layers": []}
+    factor = {}
+    for i, cal in enumerate(wl["calibration"]):
+        rec = res["FETCH_SIZE"]["cal"][2 * i + 1]
+        rf = float(rec["Counter_Value"]) * KB
+        rw = float(res["WRITE_SIZE"]["cal"][2 * i + 1]["Counter_Value"]) * KB
+        us = dur.get(int(rec["Dispatch_Id"]), 0.0)
+        f = cal["known_read_bytes"] / rf if rf else 0.0
+        factor[cal["label"]] = f
+        out["calibration"].append({**cal, "kernel": rec["Kernel_Name"].split("(")[0][-48:], "raw_fetch_bytes": rf, "raw_write_bytes": rw,
+                                   "fetch_factor": round(f, 3), "write_factor": round(cal["known_write_bytes"] / rw, 3) if rw else None,
+                                   "us": round(us, 1),
+                                   "known_gbs": round((cal["known_read_bytes"] + cal["known_write_bytes"]) / us / 1e3, 1) if us else None})
+    f_rl, f_mf = factor.get("rowlane 8->8", 2.0), factor.get("mfma quad 8->8", 2.0)
+    for i, L in enumerate(wl["layers"]):
+        rfr, rwr = res["FETCH_SIZE"]["set"][i], res["WRITE_SIZE"]["set"][i]
+        kname = rfr["Kernel_Name"]
+        us = dur.get(int(rfr["Dispatch_Id"]), 0.0)
+        f = f_rl if "k_conv_rowlane" in kname else f_mf if (L["cin"] <= 16 and L["K"] > 1 and "k_sparse_conv" in kname) else 2.0
+        fetch = float(rfr["Counter_Value"]) * KB * f
+        write = float(rwr["Counter_Value"]) * KB
+        out["layers"].append({**L, "kernel": kname.split("(")[0][-48:], "us": round(us, 1), "fetch_factor": round(f, 3),
+                              "hbm_read_bytes": round(fetch), "hbm_write_bytes": round(write),
+                              "hbm_gbs": round((fetch + write) / us / 1e3, 1) if us else None,
+                              "frac_of_8tbs": round((fetch + write) / us / 1e3 / 8000.0, 4) if us else None,
+                              "tflops": round(L["flops"] / us / 1e6, 2) if us else None})
+    sel = [l for l in out["layers"] if l["K"] == 81 and l["cin"] <= 16]
+    sus = sum(l["us"] for l in sel)
+    sb = sum(l["hbm_read_bytes"] + l["hbm_write_bytes"] for l in sel)
+    out["summary_81tap_small_channel"] = {"layers": [l["name"] for l in sel], "us": round(sus, 1), "hbm_bytes": sb,
+                                          "hbm_gbs": round(sb / max(sus, 1e-9) / 1e3, 1),
+                                          "frac_of_8tbs": round(sb / max(sus, 1e-9) / 1e3 / 8000.0, 4)}
+    tot_us = sum(l["us"] for l in out["layers"])
+    tot_b = sum(l["hbm_read_bytes"] + l["hbm_write_bytes"] for l in out["layers"])
+    out["all_conv_launches"] = {"us": round(tot_us, 1), "hbm_bytes_per_window": round(tot_b / 8), "hbm_gbs": round(tot_b / tot_us / 1e3, 1)}
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_gather_layers.json"), "w"), indent=1)
+    print(json.dumps(out["calibration"], indent=1))
+    for l in out["layers"]:
+        if l["K"] >= 8 and l["cin"] <= 16:
+            print("%-28s K%3d %3d->%3d %9d rows %8.1f us  read %7.1f MB write %6.1f MB  %7.1f GB/s (%.3f of 8 TB/s) %s" % (
+                l["name"], l["K"], l["cin"], l["cout"], l["rows"], l["us"], l["hbm_read_bytes"] / 1e6, l["hbm_write_bytes"] / 1e6,
+                l["hbm_gbs"], l["frac_of_8tbs"], l["kernel"][-28:]))
+    print(json.dumps(out["summary_81tap_small_channel"]), json.dumps(out["all_conv_launches"]))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "--join":
+        join(sys.argv[2], sys.argv[3])
+    else:
+        workload()
