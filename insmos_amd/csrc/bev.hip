@@ -17,6 +17,7 @@
 // Arithmetic: v_mfma_f32_16x16x4_f32, exact fp32, fixed summation order (chunk, tap, 4 channel steps): deterministic,
 // every output site a function of its own 3x3 neighbourhood only.  Weights are the same pre-packed A fragments
 // k_sparse_conv uses ([tap][chunk][channel tile][lane][4]); fragment roles as there: i = output channel, j = site.
+#include <cstdlib>
 #include "common.h"
 #include "prec.h"
 
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty,
                                                      const uint8_t* __restrict__ dist, int reach, int breach,
-                                                     const float* __restrict__ cvec) {
+                                                     const float* __restrict__ cvec, int ty_fast) {
     constexpr int JT = TH / 2;                          // row groups per wave
     constexpr int NSITE = (TH + 2) * BEV_HW;            // halo sites
     constexpr int NTHR = 128 * NCG;
@@ -59,7 +60,13 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     const int rh = wave & 1, ch = wave >> 1;            // row half, output-channel half
     const int g = lane >> 4, j = lane & 15;
     const int bid = blockIdx.x;
-    const int tx = bid % n_tx, ty = (bid / n_tx) % n_ty, img = bid / (n_tx * n_ty);
+    // workgroup b runs on XCD b % 8.  With constant-region skipping the work of a patch depends on WHERE it lies (voxels cluster
+    // around the sensor), so the patches of one XCD must be a spatial mix: the axis whose patch count shares the fewest factors of
+    // two with the XCD count runs fastest (cfg-2: 8 x 15 patches -- with the 8-patch axis fastest every XCD owned one strip of the
+    // map and the launch lasted as long as the busiest strip: measured, tools/bev_skip_probe.py)
+    const int img = bid / (n_tx * n_ty);
+    const int pq = bid % (n_tx * n_ty);
+    const int tx = ty_fast ? pq / n_ty : pq % n_tx, ty = ty_fast ? pq % n_ty : pq / n_tx;
     // patch origin: (u, v) = (fast axis, slow axis) of the patch; u is x (v is y) unless YM
     const int u0 = tx * BEV_TW, v0 = ty * TH;
     const int U = YM ? H : W, V = YM ? W : H;
@@ -309,12 +316,15 @@ using namespace insmos;
 // patch shape: 16 sites along one axis x TH in {10, 8, 4} along the other.  Every site's value is the same expression
 // whatever patch it falls into, so the choice is free: least padded work, at least one workgroup per CU, tallest wins ties
 // (a taller patch re-uses each weight fragment for more row groups).
-static void bev_choose_patch(int B, int H, int W, int* th_out, int* ym_out) {
+// only_th > 0: that patch height only (constant-region skipping takes the flattest patches: more, smaller workgroups balance the
+// uneven work per patch better and more of them are skipped whole -- measured 16 x 4 against 16 x 8 / 16 x 10, tools/bev_skip_probe.py)
+static void bev_choose_patch(int B, int H, int W, int* th_out, int* ym_out, int only_th = 0) {
     constexpr int kCUs = 256;  // MI355X
     int best_th = 0, best_ym = 0;
     double best_cost = 1e30;
     for (int ym = 0; ym < 2; ++ym)
         for (int th : {10, 8, 4}) {
+            if (only_th && th != only_th) continue;
             const int U = ym ? H : W, V = ym ? W : H;
             const int64_t nblk = (int64_t)B * ((U + 15) / 16) * ((V + th - 1) / th);
             double cost = (double)nblk * 16.0 * th;                        // padded sites
@@ -325,6 +335,9 @@ static void bev_choose_patch(int B, int H, int W, int* th_out, int* ym_out) {
             cost /= 0.5 + 0.5 * last_round;                                 // a part-empty last round of workgroups
             if (cost < best_cost) { best_cost = cost; best_th = th; best_ym = ym; }
         }
+    // probe only (tools/bev_skip_probe.py): INSMOS_BEV_TH / INSMOS_BEV_YM force the patch height / orientation
+    if (const char* e = getenv("INSMOS_BEV_TH")) { const int v = atoi(e); if (v == 10 || v == 8 || v == 4) best_th = v; }
+    if (const char* e = getenv("INSMOS_BEV_YM")) { const int v = atoi(e); if (v == 0 || v == 1) best_ym = v; }
     *th_out = best_th;
     *ym_out = best_ym;
 }
@@ -340,10 +353,12 @@ static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int c
     hipStream_t s = (hipStream_t)stream;
     const int n16 = cin / 16;
     int best_th = 0, best_ym = 0;
-    bev_choose_patch(B, H, W, &best_th, &best_ym);
+    bev_choose_patch(B, H, W, &best_th, &best_ym, (dist && cvec) ? 4 : 0);
     const int U = best_ym ? H : W, V = best_ym ? W : H;
     const int n_tx = (U + BEV_TW - 1) / BEV_TW, n_ty = (V + best_th - 1) / best_th;
     const unsigned grid = (unsigned)((int64_t)B * n_ty * n_tx);
+    auto pow2 = [](int v) { int p = 0; while (v > 0 && (v & 1) == 0 && p < 3) { v >>= 1; ++p; } return p; };
+    const int ty_fast = pow2(n_ty) < pow2(n_tx) ? 1 : 0;   // (see the kernel: spatial mix of patches per XCD)
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 9; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = (int64_t)B * H * W;
     // Cout = 128: 2 x 4 waves of 2 channel tiles (10-row patches: the accumulators of 4 tiles x 5 row groups would leave one
@@ -355,13 +370,13 @@ static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int c
     do {                                                                                                                        \
         if (wsplit)                                                                                                             \
             INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 3>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wsplit, \
-                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr);                                          \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast);                                          \
         else if (skip)                                                                                                          \
             INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0, true>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16,   \
-                          wpacked, bias, out, ld_out, relu, n_tx, n_ty, dist, reach, breach, cvec);                             \
+                          wpacked, bias, out, ld_out, relu, n_tx, n_ty, dist, reach, breach, cvec, ty_fast);                             \
         else                                                                                                                    \
             INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, \
-                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr);                                          \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast);                                          \
     } while (0)
 #define BEV_TH(NCG_, YM_) \
     do { if (best_th == 10) BEV_GO(10, NCG_, YM_); else if (best_th == 8) BEV_GO(8, NCG_, YM_); else BEV_GO(4, NCG_, YM_); } while (0)
@@ -441,7 +456,7 @@ extern "C" int insmos_bev_skip_executed_pairs(const uint8_t* dist, int B, int H,
     if (!dist || !pairs_dev || B <= 0 || H <= 0 || W <= 0 || layer < 0) return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int th = 0, ym = 0;
-    bev_choose_patch(B, H, W, &th, &ym);
+    bev_choose_patch(B, H, W, &th, &ym, 4);
     const int U = ym ? H : W, V = ym ? W : H;
     const int64_t n_grp = (int64_t)B * V * ((U + 15) / 16);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long), s));

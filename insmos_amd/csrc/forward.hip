@@ -750,7 +750,10 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         const InsmosConvW* w = Lr(name);
         if (!w) return INSMOS_EINVAL;
         const int layer = bev_layer++;
-        if (bev_kernel && bev_dist)
+        // (the constant region shrinks by one ring per layer: past INSMOS_BEV_SKIP_LAYERS layers the skipped work no longer pays
+        //  for the uneven workgroups; on the S0 windows it pays on all six layers, profiles/r04_bev_skip_layers.txt: default = all)
+        static const int skip_layers = [] { const char* e = getenv("INSMOS_BEV_SKIP_LAYERS"); return e ? atoi(e) : 99; }();
+        if (bev_kernel && bev_dist && layer < skip_layers)
             return insmos_bev_conv3x3_skip(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, bev_dist, layer,
                                            bev_cv + (size_t)layer * 128, s);
         if (bev_kernel && w->K == 9 && w->cin % 16 == 0 && (w->cout == 64 || w->cout == 128))

@@ -340,7 +340,7 @@ class Engine:
                        "insmos_bev_conv3x3")
             self._conv_log.append((self.nbr_bev, nsite, layer, 0))
             self._conv_nin.append(nsite)
-            if getattr(self, "_bev_dist", None) is not None:
+            if getattr(self, "_bev_dist", None) is not None and int(layer.name[3:]) < int(os.environ.get("INSMOS_BEV_SKIP_LAYERS", "99")):
                 # accounting only (bench.py): the pairs the native runner's constant-region skipping executes for this layer
                 cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
                 _lib.check(self.lib.insmos_bev_skip_executed_pairs(self._bev_dist.data_ptr(), 1, self.bevH, self.bevW, int(layer.name[3:]),
