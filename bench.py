@@ -285,16 +285,18 @@ def main_cfg5(args, rank, world, gpu, dev, host_cores):
         "ms_per_window": round(1000.0 * dt / (args.steps * B), 3), "timed_region_s": round(dt, 3),
         "loss": round(loss, 4), "loss_terms": {k: round(float(v), 4) for k, v in dict(last["tb"][0] if isinstance(last["tb"], (list, tuple)) else last["tb"]).items()},
     }
+    # ---- roofline of the convolution kernels of the step (forward + d/dx + d/dW, all on the fp32 MFMA path): executed flops
+    # counted at the autograd nodes / their HIP-event time in a second, profiled pass.  EVERY rank runs the pass (its steps hold
+    # the gradient collectives); rank 0 alone profiles and counts.
+    nprof = 2
     if rank == 0:
-        # ---- roofline of the convolution kernels of the step (forward + d/dx + d/dW, all on the fp32 MFMA path): executed flops
-        # counted at the autograd nodes / their HIP-event time in a second, profiled pass
         autograd.WORK_COUNTER = {}
-        nprof = 2
         lib.insmos_prof_reset()
         lib.insmos_prof_enable(1)
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         prof = read_profile(lib)
         lib.insmos_prof_enable(0)
         lib.insmos_prof_reset()

@@ -132,7 +132,7 @@ def test_bench_gpus_2_dry_run_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-index", "0",
                         "--steps", "2", "--warmup", "1", "--n-az", "320", "--windows-per-step", "4", "--sustain-seconds", "0",
                         "--no-cpu-baseline", "--candidates", "200"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       timeout=900)
+                       timeout=400)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     lines = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')]
@@ -152,7 +152,7 @@ def test_bench_cfg5_training_step_two_rank_dry_run():
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--config", "cfg5", "--steps", "2", "--warmup", "1", "--n-az", "160", "--windows-per-step", "2", "--no-cpu-baseline"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-index", "0"] + common,
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     lines = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')]
@@ -162,7 +162,7 @@ def test_bench_cfg5_training_step_two_rank_dry_run():
     assert j["config"]["grad_buckets"] >= 1 and j["config"]["backend"] == "gloo" and j["loss"] > 0
     assert abs(j["value"] - 2 * 2 * 2 / j["timed_region_s"]) / j["value"] < 2e-2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=900)
+                       stderr=subprocess.STDOUT, timeout=400)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     j1 = [json.loads(l) for l in out.splitlines() if l.startswith('{"metric"')][0]
