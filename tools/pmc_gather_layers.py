@@ -104,7 +104,7 @@ def join(root, tag):
     out = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/pmc_gather_layers.sh); counter "
                      "unit KB; fetch factor = known read bytes / raw FETCH_SIZE of a launch of the SAME kernel over a shifted-identity "
                      "table (every table entry and every feature row needed once from HBM); layers of kernels without a "
-                     "calibration launch use the guide's x2", "calibration": [], "layers": []}
+                     "calibration launch are reported at face value (see the comment in join())", "calibration": [], "layers": []}
     factor = {}
     for i, cal in enumerate(wl["calibration"]):
         rec = res["FETCH_SIZE"]["cal"][2 * i + 1]
@@ -117,15 +117,25 @@ def join(root, tag):
                                    "fetch_factor": round(f, 3), "write_factor": round(cal["known_write_bytes"] / rw, 3) if rw else None,
                                    "us": round(us, 1),
                                    "known_gbs": round((cal["known_read_bytes"] + cal["known_write_bytes"]) / us / 1e3, 1) if us else None})
-    f_rl, f_mf = factor.get("rowlane 8->8", 2.0), factor.get("mfma quad 8->8", 2.0)
+    # What the calibration launches say (profiles/r04_pmc_gather_layers.json): the MFMA gather kernels come out at 1.00 (8 B/lane and
+    # 16 B/lane gathers alike: a gathered row is a 32-64 B piece, i.e. 64-B fabric requests, which FETCH_SIZE tallies at face value --
+    # the guide's x2 is for 1 KiB-per-wave streaming reads that go out as 128-B requests).  The row-lane kernel has no launch with a
+    # clean known byte count: on the shifted-identity table it really fetches 3.3x the minimum (every tap of a tile reads another
+    # 2 KiB run of rows, re-fetched per XCD), so its factor is NOT a counter scale; its layers are reported at face value like the
+    # other gather kernels.  Kernels without a calibration launch (the >= 32-channel tiles, the dense BEV kernel, whose loads
+    # are 64-B pieces as well) are reported at face value too, with the x2 figure next to it as an upper bound.
+    f_mf = factor.get("mfma quad 8->8", 1.0)
+    f_rl = 1.0
     for i, L in enumerate(wl["layers"]):
         rfr, rwr = res["FETCH_SIZE"]["set"][i], res["WRITE_SIZE"]["set"][i]
         kname = rfr["Kernel_Name"]
         us = dur.get(int(rfr["Dispatch_Id"]), 0.0)
-        f = f_rl if "k_conv_rowlane" in kname else f_mf if (L["cin"] <= 16 and L["K"] > 1 and "k_sparse_conv" in kname) else 2.0
+        calibrated = "k_sparse_conv_q" in kname
+        f = f_rl if "k_conv_rowlane" in kname else f_mf if calibrated else 1.0
         fetch = float(rfr["Counter_Value"]) * KB * f
         write = float(rwr["Counter_Value"]) * KB
         out["layers"].append({**L, "kernel": kname.split("(")[0][-48:], "us": round(us, 1), "fetch_factor": round(f, 3),
+                              "fetch_calibrated_on_this_kernel": calibrated,
                               "hbm_read_bytes": round(fetch), "hbm_write_bytes": round(write),
                               "hbm_gbs": round((fetch + write) / us / 1e3, 1) if us else None,
                               "frac_of_8tbs": round((fetch + write) / us / 1e3 / 8000.0, 4) if us else None,
@@ -138,7 +148,11 @@ def join(root, tag):
                                           "frac_of_8tbs": round(sb / max(sus, 1e-9) / 1e3 / 8000.0, 4)}
     tot_us = sum(l["us"] for l in out["layers"])
     tot_b = sum(l["hbm_read_bytes"] + l["hbm_write_bytes"] for l in out["layers"])
-    out["all_conv_launches"] = {"us": round(tot_us, 1), "hbm_bytes_per_window": round(tot_b / 8), "hbm_gbs": round(tot_b / tot_us / 1e3, 1)}
+    tot_r = sum(l["hbm_read_bytes"] for l in out["layers"])
+    out["all_conv_launches"] = {"us": round(tot_us, 1), "hbm_bytes_per_window": round(tot_b / 8), "hbm_gbs": round(tot_b / tot_us / 1e3, 1),
+                                "hbm_bytes_per_window_if_uncalibrated_fetch_x2": round((tot_b + sum(l["hbm_read_bytes"] for l in out["layers"]
+                                                                                                  if not l["fetch_calibrated_on_this_kernel"])) / 8),
+                                "read_bytes_per_window": round(tot_r / 8)}
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_gather_layers.json"), "w"), indent=1)
     print(json.dumps(out["calibration"], indent=1))
     for l in out["layers"]:
