@@ -650,6 +650,9 @@ def main():
                       % launches,
             "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            # the same kernel time against the flops the REFERENCE computes for the window (every MotionNet row, every BEV site):
+            # what skipping constant / unused work buys shows up here, not in `frac`
+            "frac_reference_work": round(flops_ref_w / (conv_ms_per_window * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if conv_ms_per_window > 0 else 0.0,
             "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic else None,
             "traffic_bytes_per_window": round(traffic["hbm_bytes_per_window"]) if traffic else None,
             "traffic_source": ("NOT measured in this run: read from the committed %s (rocprofv3 --pmc passes of `bench.py "

@@ -7,7 +7,7 @@ import os
 import sys
 
 root, tag, wpl = sys.argv[1], sys.argv[2], int(sys.argv[3])
-CONV = ("k_sparse_conv", "k_deconv_head", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125", "k_bev_conv")
+CONV = ("k_sparse_conv", "k_conv_rowlane", "k_deconv_head", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125", "k_bev_conv")
 tot, allk = {}, {}
 launches = 0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -17,18 +17,25 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tot[c] = sum(float(r["Counter_Value"]) for r in conv) * 1024.0  # counter unit: KB
     allk[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0
     launches = len(conv)
-hbm = 2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+# Round 4: FETCH_SIZE calibrated on launches of the gather kernels themselves over tables with a known byte count
+# (tools/pmc_gather_layers.py, profiles/r04_pmc_gather_layers.json): factor 1.00 for 8 B/lane and 16 B/lane gathers alike -- a
+# gathered row is a 32-64 B piece, i.e. 64-B fabric requests, tallied at face value.  The x2 of MI355X_MICROARCH.md is for 1 KiB-per-wave
+# streaming reads (128-B requests); rounds 1-3 applied it to everything and so doubled the fetch side.  The x2 figure stays in the
+# file as an upper bound.
+hbm = tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
 out = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --timed-only --steps 1 "
                f"--warmup 0 --windows-per-step {wpl} (INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH={wpl})",
     "scope": f"all convolution launches of ONE launch set of {wpl} cfg-2 S0 windows",
     "windows_per_launch": wpl,
-    "fetch_size_raw_bytes": tot["FETCH_SIZE"], "fetch_size_corrected_bytes": 2 * tot["FETCH_SIZE"],
-    "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane loads -> x2; "
-                  "WRITE_SIZE uncalibrated, taken as is; counter unit KB",
+    "fetch_size_raw_bytes": tot["FETCH_SIZE"], "fetch_size_x2_upper_bound_bytes": 2 * tot["FETCH_SIZE"],
+    "correction": "FETCH_SIZE at face value: calibrated = 1.00 on the gather kernels (64-B requests; tools/pmc_gather_layers.py); "
+                  "the guide's x2 applies to 128-B streaming requests only and is kept as an upper bound "
+                  "(hbm_bytes_per_window_x2_upper_bound); WRITE_SIZE calibrated = 1.00; counter unit KB",
+    "hbm_bytes_per_window_x2_upper_bound": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / wpl,
     "write_size_bytes": tot["WRITE_SIZE"], "hbm_bytes_per_launch_set": hbm, "hbm_bytes_per_window": hbm / wpl,
     "conv_launches_per_launch_set": launches, "hbm_bytes_per_launch": hbm / max(launches, 1),
-    "all_kernels_hbm_bytes_per_window": (2 * allk["FETCH_SIZE"] + allk["WRITE_SIZE"]) / wpl,
+    "all_kernels_hbm_bytes_per_window": (allk["FETCH_SIZE"] + allk["WRITE_SIZE"]) / wpl,
 }
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"{tag}_pmc_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
