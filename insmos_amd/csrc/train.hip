@@ -650,6 +650,223 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_dx(const float* __restrict__ 
     }
 }
 
+
+// ---- the same four kernels with 16-byte accesses (round 4).  The kernels above walk a chunk with 16 row lanes x 16 channels of
+// scalar loads (half the lanes idle at c = 8, two integer divisions per element in the apply / dx loops) and ran at ~0.3 TB/s;
+// BatchNorm was 18 of the 67 ms of a training step (profiles/r04_bench_cfg5.json).  Here a thread owns ONE group of four
+// consecutive channels (c / 4 = 2^L4 groups per row, a power of two) and walks the chunk's rows with float4 loads: consecutive
+// threads read consecutive 16-byte pieces.  Same outputs as the scalar kernels up to the summation order inside a chunk
+// (fixed, deterministic); the cross-chunk merges are the same code.
+typedef float bn_f4 __attribute__((ext_vector_type(4)));
+
+template <int NV>   // tree reduction of NV float4 per thread over the row lanes (threads t, t + G, t + 2G, ... share channel group t % G)
+__device__ __forceinline__ void bn_reduce_rows(bn_f4 (&v)[NV], bn_f4* __restrict__ sm, int G) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[i * 256 + t] = v[i];
+    __syncthreads();
+    for (int sdist = 128; sdist >= G; sdist >>= 1) {
+        if (t < sdist) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sm[i * 256 + t] += sm[i * 256 + t + sdist];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = sm[i * 256 + (t & (G - 1))];
+    __syncthreads();
+}
+
+// grid (chunks); block 256; G = c / 4 = 1 << L4 channel groups (G <= 64)
+__global__ void __launch_bounds__(256) k_bnseg_stats_v4(const float* __restrict__ x, int ld, int c, int L4, const BnChunk* __restrict__ chunks,
+                                                        float* __restrict__ part, int* __restrict__ counter,
+                                                        const int* __restrict__ seg_first, const int* __restrict__ seg_rows, int S, float eps,
+                                                        float* __restrict__ stats, float momentum, float* __restrict__ rmean,
+                                                        float* __restrict__ rvar) {
+    __shared__ bn_f4 smv[256];
+    __shared__ double sagg[256][3];
+    const BnChunk ch = chunks[blockIdx.x];
+    const int G = 1 << L4, t = threadIdx.x;
+    const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
+    bn_f4 acc[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
+    for (int r = ch.r0 + rl; r < ch.r1; r += RL) acc[0] += *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg);
+    bn_reduce_rows<1>(acc, smv, G);
+    const float inv = 1.0f / (float)(ch.r1 - ch.r0);
+    const bn_f4 mean = acc[0] * inv;
+    bn_f4 m2[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
+    for (int r = ch.r0 + rl; r < ch.r1; r += RL) {
+        const bn_f4 d = *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg) - mean;
+        m2[0] += d * d;
+    }
+    bn_reduce_rows<1>(m2, smv, G);
+    if (rl == 0) {
+        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 0) * c + 4 * cg) = mean;
+        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 1) * c + 4 * cg) = m2[0];
+    }
+    if (!last_block_done(counter, (int)gridDim.x)) return;
+    // (merge per (segment, channel): the code of k_bnseg_stats)
+    const int pairs = S * c;
+    int tpp = 1;
+    while (tpp * 2 * pairs <= 256) tpp *= 2;
+    for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
+        const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
+        double n = 0.0, mu = 0.0, mm = 0.0;
+        if (pr < pairs) {
+            const int sgi = pr / c, cc = pr % c;
+            const int q0 = seg_first[sgi], q1 = seg_first[sgi + 1];
+            const int per = (q1 - q0 + tpp - 1) / tpp;
+            const int a0 = q0 + sub * per, a1 = min(a0 + per, q1);
+            for (int q = a0; q < a1; ++q) {
+                const double nb = (double)(chunks[q].r1 - chunks[q].r0);
+                const double mb = part[((int64_t)q * 2 + 0) * c + cc], m2b = part[((int64_t)q * 2 + 1) * c + cc];
+                const double d = mb - mu, nt = n + nb;
+                mu += d * nb / nt;
+                mm += m2b + d * d * n * nb / nt;
+                n = nt;
+            }
+        }
+        sagg[threadIdx.x][0] = n; sagg[threadIdx.x][1] = mu; sagg[threadIdx.x][2] = mm;
+        __syncthreads();
+        if (pr < pairs && sub == 0) {
+            double N = 0.0, MU = 0.0, M2 = 0.0;
+            for (int q = 0; q < tpp; ++q) {
+                const double nb = sagg[threadIdx.x + q][0], mb = sagg[threadIdx.x + q][1], m2b = sagg[threadIdx.x + q][2];
+                if (nb <= 0.0) continue;
+                const double d = mb - MU, nt = N + nb;
+                MU += d * nb / nt;
+                M2 += m2b + d * d * N * nb / nt;
+                N = nt;
+            }
+            const int sgi = pr / c, cc = pr % c;
+            const float var = N > 0.0 ? (float)(M2 / N) : 0.f;
+            float* st = stats + (int64_t)sgi * 3 * c;
+            st[cc] = (float)MU;
+            st[c + cc] = 1.0f / sqrtf(var + eps);
+            st[2 * c + cc] = var;
+        }
+        __syncthreads();
+    }
+    if (rmean && rvar) {
+        __threadfence_block();
+        for (int cc = threadIdx.x; cc < c; cc += 256) {
+            float m = rmean[cc], v = rvar[cc];
+            for (int sgi = 0; sgi < S; ++sgi) {
+                const int n = seg_rows[sgi];
+                if (n <= 0) continue;
+                const float* st = stats + (int64_t)sgi * 3 * c;
+                m = m * (1.0f - momentum) + momentum * st[cc];
+                v = v * (1.0f - momentum) + momentum * (st[2 * c + cc] * ((float)n / (float)max(n - 1, 1)));
+            }
+            rmean[cc] = m;
+            rvar[cc] = v;
+        }
+    }
+}
+
+// grid (chunks, 4): a quarter of the chunk's rows per block
+__global__ void __launch_bounds__(256) k_bnseg_apply_v4(const float* __restrict__ x, int ld_x, int c, int L4, const BnChunk* __restrict__ chunks,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int relu, float* __restrict__ xhat,
+                                                        float* __restrict__ y, int ld_y) {
+    const BnChunk ch = chunks[blockIdx.x];
+    const float* st = stats + (int64_t)ch.seg * 3 * c;
+    const int rows = ch.r1 - ch.r0, q = (rows + 3) / 4;
+    const int ra = ch.r0 + (int)blockIdx.y * q, rb = min(ra + q, ch.r1);
+    const int G = 1 << L4, cg = threadIdx.x & (G - 1), rl = threadIdx.x >> L4, RL = 256 >> L4;
+    const bn_f4 mu = *(const bn_f4*)(st + 4 * cg), is = *(const bn_f4*)(st + c + 4 * cg);
+    const bn_f4 ga = *(const bn_f4*)(gamma + 4 * cg), be = *(const bn_f4*)(beta + 4 * cg);
+    for (int r = ra + rl; r < rb; r += RL) {
+        const bn_f4 h = (*(const bn_f4*)(x + (int64_t)r * ld_x + 4 * cg) - mu) * is;
+        *(bn_f4*)(xhat + (int64_t)r * c + 4 * cg) = h;
+        bn_f4 v = h * ga + be;
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        *(bn_f4*)(y + (int64_t)r * ld_y + 4 * cg) = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                           const float* __restrict__ xhat, int c, int L4, int relu,
+                                                           const BnChunk* __restrict__ chunks, float* __restrict__ part,
+                                                           int* __restrict__ counter, const int* __restrict__ seg_first, int S,
+                                                           float* __restrict__ segsum, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    __shared__ bn_f4 smv[512];
+    const BnChunk ch = chunks[blockIdx.x];
+    const int G = 1 << L4, t = threadIdx.x;
+    const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
+    bn_f4 ab[2] = {(bn_f4){0.f, 0.f, 0.f, 0.f}, (bn_f4){0.f, 0.f, 0.f, 0.f}};
+    for (int r = ch.r0 + rl; r < ch.r1; r += RL) {
+        bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
+        if (relu) {
+            const bn_f4 yy = *(const bn_f4*)(y + (int64_t)r * ld_y + 4 * cg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!(yy[i] > 0.f)) g[i] = 0.f;
+        }
+        ab[0] += g;
+        ab[1] += g * *(const bn_f4*)(xhat + (int64_t)r * c + 4 * cg);
+    }
+    bn_reduce_rows<2>(ab, smv, G);
+    if (rl == 0) {
+        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 0) * c + 4 * cg) = ab[0];
+        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 1) * c + 4 * cg) = ab[1];
+    }
+    if (!last_block_done(counter, (int)gridDim.x)) return;
+    for (int pr = threadIdx.x; pr < S * c; pr += 256) {   // per (segment, channel), chunks in table order
+        const int sgi = pr / c, cc = pr % c;
+        float ta = 0.f, tb = 0.f;
+        for (int q = seg_first[sgi]; q < seg_first[sgi + 1]; ++q) {
+            ta += part[((int64_t)q * 2 + 0) * c + cc];
+            tb += part[((int64_t)q * 2 + 1) * c + cc];
+        }
+        segsum[((int64_t)sgi * 2 + 0) * c + cc] = ta;
+        segsum[((int64_t)sgi * 2 + 1) * c + cc] = tb;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+        float ta = 0.f, tb = 0.f;
+        for (int sgi = 0; sgi < S; ++sgi) {
+            ta += segsum[((int64_t)sgi * 2 + 0) * c + cc];
+            tb += segsum[((int64_t)sgi * 2 + 1) * c + cc];
+        }
+        dbeta[cc] = ta;
+        dgamma[cc] = tb;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bnseg_bwd_dx_v4(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                         const float* __restrict__ xhat, int c, int L4, int relu,
+                                                         const BnChunk* __restrict__ chunks, const int* __restrict__ seg_rows,
+                                                         const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                         const float* __restrict__ segsum, float* __restrict__ dx, int ld_dx) {
+    const BnChunk ch = chunks[blockIdx.x];
+    const float* st = stats + (int64_t)ch.seg * 3 * c;
+    const float* sg = segsum + (int64_t)ch.seg * 2 * c;
+    const float inv_n = 1.0f / (float)seg_rows[ch.seg];
+    const int rows = ch.r1 - ch.r0, q = (rows + 3) / 4;
+    const int ra = ch.r0 + (int)blockIdx.y * q, rb = min(ra + q, ch.r1);
+    const int G = 1 << L4, cg = threadIdx.x & (G - 1), rl = threadIdx.x >> L4, RL = 256 >> L4;
+    const bn_f4 gi = *(const bn_f4*)(gamma + 4 * cg) * *(const bn_f4*)(st + c + 4 * cg);
+    const bn_f4 s0 = *(const bn_f4*)(sg + 4 * cg) * inv_n, s1 = *(const bn_f4*)(sg + c + 4 * cg) * inv_n;
+    const bn_f4 ga = *(const bn_f4*)(gamma + 4 * cg), is = *(const bn_f4*)(st + c + 4 * cg);
+    (void)gi;
+    for (int r = ra + rl; r < rb; r += RL) {
+        bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
+        if (relu) {
+            const bn_f4 yy = *(const bn_f4*)(y + (int64_t)r * ld_y + 4 * cg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!(yy[i] > 0.f)) g[i] = 0.f;
+        }
+        const bn_f4 xh = *(const bn_f4*)(xhat + (int64_t)r * c + 4 * cg);
+        // the scalar kernel's expression, element for element: gamma * invstd * (g - sum_g / n - x^ * (sum_gx / n))
+        *(bn_f4*)(dx + (int64_t)r * ld_dx + 4 * cg) = ga * is * (g - s0 - xh * s1);
+    }
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -830,6 +1047,17 @@ extern "C" int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, i
 // left zero) are DEVICE arrays; stats: S x 3c floats
 // ([mean | invstd | biased var] per segment); ws: insmos_batchnorm_seg_ws_floats.  running_mean / running_var (optional) are updated
 // segment after segment (momentum, unbiased variance), as the reference's item-by-item forwards do.
+// log2(c / 4) when the 16-byte kernels apply (c / 4 a power of two <= 64, every pitch a multiple of 4 floats, every pointer
+// 16-byte aligned; INSMOS_BN_VEC=0 keeps the scalar kernels), else -1
+static int bn_vec_log2(int c, int ld_a, int ld_b, int ld_c, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4) {
+    static const bool on = [] { const char* e = getenv("INSMOS_BN_VEC"); return !(e && e[0] == '0'); }();
+    if (!on || c < 4 || (c & 3) || ((c / 4) & (c / 4 - 1)) || c / 4 > 64 || (ld_a & 3) || (ld_b & 3) || (ld_c & 3)) return -1;
+    if ((((uintptr_t)p0) | ((uintptr_t)p1) | ((uintptr_t)p2) | ((uintptr_t)p3) | ((uintptr_t)p4)) & 15) return -1;
+    int l = 0;
+    while ((4 << l) < c) ++l;
+    return l;
+}
+
 extern "C" size_t insmos_batchnorm_seg_ws_floats(int n_chunks, int c, int S) {
     return (size_t)2 * (size_t)(n_chunks > 0 ? n_chunks : 1) * (size_t)c + (size_t)2 * (size_t)(S > 0 ? S : 1) * (size_t)c + 64;
 }
@@ -846,6 +1074,14 @@ extern "C" int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int
     hipStream_t s = (hipStream_t)stream;
     const BnChunk* ch = (const BnChunk*)chunks;
     ProfScope ps(KK_BATCHNORM, s);
+    const int l4 = bn_vec_log2(c, ld_x, ld_y, c, x, y, xhat, gamma, beta);
+    if (l4 >= 0) {
+        INSMOS_LAUNCH(k_bnseg_stats_v4, dim3(n_chunks), dim3(256), 0, s, x, ld_x, c, l4, ch, ws, ticket, seg_first, seg_rows, S, eps, stats,
+                      momentum, running_mean, running_var);
+        INSMOS_LAUNCH(k_bnseg_apply_v4, dim3(n_chunks, 4), dim3(256), 0, s, x, ld_x, c, l4, ch, stats, gamma, beta, relu, xhat, y, ld_y);
+        HIP_TRY(hipGetLastError());
+        return INSMOS_OK;
+    }
     INSMOS_LAUNCH(k_bnseg_stats, dim3(n_chunks, cdiv(c, 16)), dim3(256), 0, s, x, ld_x, c, ch, ws, ticket, seg_first, seg_rows, S, eps, stats,
                   momentum, running_mean, running_var);
     INSMOS_LAUNCH(k_bnseg_apply, dim3(n_chunks, 4), dim3(256), 0, s, x, ld_x, c, ch, stats, gamma, beta, relu, xhat, y, ld_y);
@@ -866,6 +1102,15 @@ extern "C" int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const f
     float* part = ws;
     float* segsum = ws + (size_t)2 * n_chunks * c;
     ProfScope ps(KK_BATCHNORM, s);
+    const int l4 = bn_vec_log2(c, ld_dy, relu ? ld_y : c, ld_dx, dy, relu ? y : dy, xhat, gamma, dx);
+    if (l4 >= 0) {
+        INSMOS_LAUNCH(k_bnseg_bwd_sums_v4, dim3(n_chunks), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, part, ticket, seg_first,
+                      S, segsum, dgamma, dbeta);
+        INSMOS_LAUNCH(k_bnseg_bwd_dx_v4, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, seg_rows, gamma, stats,
+                      segsum, dx, ld_dx);
+        HIP_TRY(hipGetLastError());
+        return INSMOS_OK;
+    }
     INSMOS_LAUNCH(k_bnseg_bwd_sums, dim3(n_chunks, cdiv(c, 16)), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, relu, ch, part, ticket, seg_first,
                   S, segsum, dgamma, dbeta);
     INSMOS_LAUNCH(k_bnseg_bwd_dx, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, relu, ch, seg_rows, gamma, stats, segsum,
