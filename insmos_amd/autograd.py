@@ -14,6 +14,7 @@ The optimiser step stays torch.optim's.
 """
 import contextlib
 import ctypes
+import os
 import threading
 
 import torch
@@ -251,15 +252,24 @@ class BnPlan:
     of <= 1024-row chunks of one segment each, sorted by segment.  Built once per coordinate level and step, shared by every
     layer on that level."""
 
-    CHUNK = 1024
+    CHUNK = 1024   # (upper bound of the adaptive chunk length below when INSMOS_BN_CHUNK pins it)
+
+    @staticmethod
+    def chunk_rows(n_rows):
+        """Rows per chunk.  1024 is the measured optimum of these kernels (tools/bn_chunk_probe.sh, BatchNorm ms per cfg-5 step:
+        adaptive 128-2368 rows: 18.6, 1024: 13.4, 4096: 23.8, 16384: 62.8): one block per chunk, and a block streams its rows
+        serially."""
+        fixed = os.environ.get("INSMOS_BN_CHUNK")
+        return max(16, int(fixed)) if fixed else BnPlan.CHUNK
 
     def __init__(self, runs, n_rows, n_seg, device):
         """runs: iterable of (row_start, row_end, segment) covering [0, n_rows) (any order)."""
         import numpy as np
         ch = []
+        step = self.chunk_rows(n_rows)
         for r0, r1, sg in runs:
-            for a in range(int(r0), int(r1), self.CHUNK):
-                ch.append((a, min(a + self.CHUNK, int(r1)), int(sg), 0))
+            for a in range(int(r0), int(r1), step):
+                ch.append((a, min(a + step, int(r1)), int(sg), 0))
         ch = np.asarray(ch, np.int32).reshape(-1, 4)
         ch = ch[np.argsort(ch[:, 2], kind="stable")]
         first = np.searchsorted(ch[:, 2], np.arange(n_seg + 1)).astype(np.int32)
