@@ -178,9 +178,41 @@ struct JoinGuard {
     ~JoinGuard() { (void)link_streams(s2, s); }
 };
 
-int read_counts(const int32_t* dev, int32_t* host, int n, hipStream_t s) {
-    HIP_TRY(hipMemcpyAsync(host, dev, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+// Count read-backs.  A launch set has about a dozen of them and, for ONE window per forward(), each is an idle gap on the GPU
+// (profiles/r04_b1_trace.txt: ~27 us per read-back = copy kernel + host wake-up + next launch).  Two things shorten the gap:
+// the copy lands in PINNED host memory of the calling thread (a pageable destination is staged by the runtime), and in latency mode
+// (tl_spin: one launch set per forward(), set with the second-stream mask) the host polls the stream instead of sleeping in
+// hipStreamSynchronize.  With several sets in flight the threads sleep as before (a spinning thread per set would take the cores the
+// other sets' launch threads need).
+struct PinnedCounts {
+    int32_t* p = nullptr;
+    ~PinnedCounts() {}   // (left to process teardown: freeing pinned memory after the runtime is gone crashes)
+    int32_t* get() {
+        if (!p && hipHostMalloc((void**)&p, 4096, hipHostMallocDefault) != hipSuccess) p = nullptr;
+        return p;
+    }
+};
+thread_local PinnedCounts tl_pinned;
+thread_local bool tl_spin = false;
+static const bool kSpinEnv = [] { const char* e = getenv("INSMOS_READBACK_SPIN"); return !(e && e[0] == '0'); }();
+
+int wait_stream(hipStream_t s) {
+    if (tl_spin && kSpinEnv) {
+        hipError_t q;
+        while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+        if (q != hipSuccess) { insmos::g_last_hip_error = (int)q; return INSMOS_EHIP; }
+        return INSMOS_OK;
+    }
     HIP_TRY(hipStreamSynchronize(s));
+    return INSMOS_OK;
+}
+
+int read_counts(const int32_t* dev, int32_t* host, int n, hipStream_t s) {
+    int32_t* pin = (size_t)n * sizeof(int32_t) <= 4096 ? tl_pinned.get() : nullptr;
+    HIP_TRY(hipMemcpyAsync(pin ? pin : host, dev, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    int rc = wait_stream(s);
+    if (rc != INSMOS_OK) return rc;
+    if (pin) memcpy(host, pin, n * sizeof(int32_t));
     return INSMOS_OK;
 }
 }  // namespace
@@ -235,6 +267,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // passes on the second stream (default 15 = all; 0 = everything on the caller's stream)
     static const int ts_env = [] { const char* e = getenv("INSMOS_TWO_STREAMS"); return e ? atoi(e) : -1; }();
     const int ts_mask = ts_env >= 0 ? ts_env : tl_stream_mask >= 0 ? tl_stream_mask : 15;
+    tl_spin = ts_mask != 0;   // latency mode: one launch set per forward() (insmos_amd/models.py passes mask 15 then, 0 otherwise)
     hipStream_t s2 = s;
     if (ts_mask) {
         CK(tl_aux.init());
@@ -887,9 +920,13 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // the one unavoidable read-back: the caller's output tensors are sized by the box counts
     {
         int32_t hk[4 * INSMOS_MAX_BATCH], hcand[4 * INSMOS_MAX_BATCH];
-        HIP_TRY(hipMemcpyAsync(hk, cnt_k, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(hcand, cnt_c, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        int32_t* pin = tl_pinned.get();   // (2 x 4 B ints <= 4096 bytes: B <= 16)
+        int32_t* hk_dst = pin ? pin : hk;
+        int32_t* hc_dst = pin ? pin + 4 * INSMOS_MAX_BATCH : hcand;
+        HIP_TRY(hipMemcpyAsync(hk_dst, cnt_k, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hc_dst, cnt_c, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CK(wait_stream(s));
+        if (pin) { memcpy(hk, hk_dst, (size_t)B * 16); memcpy(hcand, hc_dst, (size_t)B * 16); }
         for (int b = 0; b < B; ++b) {
             outs[b].n_boxes = hk[4 * b];
             outs[b].n_candidates = hcand[4 * b];
