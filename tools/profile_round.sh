@@ -7,7 +7,7 @@
 R=$(pwd); TAG=${1:-r03}; WPL=${2:-8}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 2> $O/bench.err | tail -1 > $O/bench.json; cut -c1-300 $O/bench.json
+python bench.py --steps 10 --warmup 3 2> $O/bench_profile.err | tail -1 > $O/bench_profile.json; cut -c1-300 $O/bench_profile.json
 for FL in 1 4; do
   rm -rf $O/prof_fl$FL
   ( cd /tmp && INSMOS_TWO_STREAMS=0 INSMOS_WINDOWS_IN_FLIGHT=$FL INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_fl$FL -o prof --output-format csv -- \
@@ -16,7 +16,7 @@ for FL in 1 4; do
   ST=$(find $O/prof_fl$FL -name "*kernel_stats.csv" | head -1)
   cp "$ST" $O/rocprof_kernel_stats_fl$FL.csv
   find $O/prof_fl$FL -name "*kernel_trace.csv" -delete
-  python tools/roofline_from_rocprof.py $O/rocprof_kernel_stats_fl$FL.csv --windows ${NWIN:-120} --bench-json $O/bench.json --json > $O/roofline_fl$FL.json
+  python tools/roofline_from_rocprof.py $O/rocprof_kernel_stats_fl$FL.csv --windows ${NWIN:-120} --bench-json $O/bench_profile.json --json > $O/roofline_fl$FL.json
   cat $O/roofline_fl$FL.json
 done
 head -40 $O/rocprof_kernel_stats_fl1.csv | cut -c1-200
