@@ -989,7 +989,7 @@ class Engine:
         ctx = self._native_ctx()
         N = sum(int(p.shape[0]) for p in pts_list)
         if self._arena is None:
-            self._arena = torch.empty(640 * N + (192 << 20), dtype=torch.uint8, device=self.device)
+            self._arena = torch.empty(900 * N + (256 << 20), dtype=torch.uint8, device=self.device)   # (generous: a retry repeats launches)
         win_ptr = (ctypes.c_void_p * B)(*[p.data_ptr() for p in pts_list])
         win_n = (ctypes.c_int64 * B)(*[int(p.shape[0]) for p in pts_list])
         outs = (_lib.ForwardOut * B)()

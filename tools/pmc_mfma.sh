@@ -4,13 +4,15 @@ R=$(pwd); TAG=${1:-r03}; WPL=${2:-4}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_mfma
 ( cd /tmp && INSMOS_TWO_STREAMS=0 INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES \
-    -d $R/gpurun_out/pmc_mfma/p -o p --output-format csv -- python $R/bench.py --timed-only --steps 1 --warmup 0 --windows-per-step $WPL ) > $R/gpurun_out/pmc_mfma/p.log 2>&1
+    -d $R/gpurun_out/pmc_mfma/p -o p --output-format csv -- python $R/bench.py --timed-only --steps 1 --warmup 1 --windows-per-step $WPL ) > $R/gpurun_out/pmc_mfma/p.log 2>&1
 echo "rc=$?"
 python - <<PY
 import csv, glob, json, os
 f = glob.glob("$R/gpurun_out/pmc_mfma/p/**/*counter_collection.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+starts = [i for i, r in enumerate(rows) if "k_parent_cubes" in r["Kernel_Name"]]   # the LAST launch set of the trace only
+rows = rows[starts[-1]:] if starts else rows
 conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sparse_conv", "k_conv_rowlane", "k_deconv_head", "k_bev_conv", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125"))]
 tot = {}
 for r in conv:

@@ -13,6 +13,11 @@ launches = 0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # the LAST launch set of the trace only (the run does one warm-up step first: a first call may repeat part of its launches
+    # while the arena grows, and computes the BEV constants): everything from the last first-layer kernel on
+    starts = [i for i, r in enumerate(rows) if "k_parent_cubes" in r["Kernel_Name"]]
+    rows = rows[starts[-1]:] if starts else rows
     conv = [r for r in rows if any(k in r["Kernel_Name"] for k in CONV)]
     tot[c] = sum(float(r["Counter_Value"]) for r in conv) * 1024.0  # counter unit: KB
     allk[c] = sum(float(r["Counter_Value"]) for r in rows) * 1024.0

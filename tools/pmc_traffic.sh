@@ -10,7 +10,7 @@ mkdir -p $R/gpurun_out/pmc_traffic
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_traffic/$c
   ( cd /tmp && INSMOS_TWO_STREAMS=0 INSMOS_WINDOWS_IN_FLIGHT=1 INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 240 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic/$c -o p --output-format csv -- \
-      python $R/bench.py --timed-only --steps 1 --warmup 0 --windows-per-step $WPL ) > $R/gpurun_out/pmc_traffic/$c.log 2>&1
+      python $R/bench.py --timed-only --steps 1 --warmup 1 --windows-per-step $WPL ) > $R/gpurun_out/pmc_traffic/$c.log 2>&1
   echo "$c rc=$?"
 done
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic $TAG $WPL
