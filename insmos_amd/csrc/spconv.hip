@@ -926,10 +926,19 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     if (split_env && !ident && co_ok && (ck == 0 || ck == 8) &&
         ((mask16 && K >= 16 && (wide || tile_work >= split_work)) || (!ck && wide && split_dense && P.n16 % 4 == 0 && K >= 3))) {
         ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0);
+        int cot_split = P.ntile_co;
+        // Few row groups (one window alone: the level-4 layers have ~420): the chunk-split tiles of a wide layer leave most CUs with
+        // one or two 4-wave blocks, each latency-bound on its operand loads.  Two blocks per tile, half of the channel tiles each,
+        // double the waves (the tile's rows are gathered twice; every output channel keeps its summation order: same bits).
+        static const int half_below = env_int("INSMOS_CONV_SPLIT_HALF", 1536);
+        if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
+            ConvKernel hk = pick_split(P.ntile_co / 2, ck, true);
+            if (hk) { sk = hk; cot_split = P.ntile_co / 2; }
+        }
         if (sk) {
             split = 4;
             by_chunk = (!ck && P.n16 % 4 == 0);
-            best = {P.ntile_co, 1};
+            best = {cot_split, 1};
             P.n_otiles = (int)groups;
             kern = sk;
         }
