@@ -35,24 +35,39 @@ __global__ void k_score_keys(const float* __restrict__ head, int ld, int ncls, i
                              float thresh, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
                              int32_t* __restrict__ counts) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_cells * B) return;
-    const int b = (int)(r / n_cells);
-    const float* h = head + r * ld;
-    float best = sigmoidf_(h[0]);
-    for (int c = 1; c < ncls; ++c) {
-        float p = sigmoidf_(h[c]);
-        if (p > best) best = p;  // first max wins
-    }
+    const bool in = r < n_cells * B;
+    const int b = in ? (int)(r / n_cells) : -1;
+    bool pass = false;
     uint64_t key = INSMOS_INVALID_KEY;
-    if (best >= thresh) {
-        int row, col;
-        cell_of_row(r - (int64_t)b * n_cells, W, up, row, col);
-        uint32_t cell = (uint32_t)(row * W + col);
-        key = ((uint64_t)b << CAND_WIN_SHIFT) | ((uint64_t)(0x3F800000u - __float_as_uint(best)) << CAND_CELL_BITS) | cell;
-        atomicAdd(&counts[b * 4 + 1], 1);
+    if (in) {
+        const float* h = head + r * ld;
+        float best = sigmoidf_(h[0]);
+        for (int c = 1; c < ncls; ++c) {
+            float p = sigmoidf_(h[c]);
+            if (p > best) best = p;  // first max wins
+        }
+        if (best >= thresh) {
+            int row, col;
+            cell_of_row(r - (int64_t)b * n_cells, W, up, row, col);
+            uint32_t cell = (uint32_t)(row * W + col);
+            key = ((uint64_t)b << CAND_WIN_SHIFT) | ((uint64_t)(0x3F800000u - __float_as_uint(best)) << CAND_CELL_BITS) | cell;
+            pass = true;
+        }
+        keys[r] = key;
+        vals[r] = (uint32_t)r;
     }
-    keys[r] = key;
-    vals[r] = (uint32_t)r;
+    // candidate count per window: ONE atomic per wave and window (a head that fires on most cells -- an untrained or a
+    // mid-training one -- put 300 000 same-address atomics in a row: 3.4 ms for this kernel in the cfg-5 training step)
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int b_first = __shfl(b, __builtin_ctzll(m)), b_last = __shfl(b, 63 - __builtin_clzll(m));
+        if (b_first == b_last) {
+            if (lane == __builtin_ctzll(m)) atomicAdd(&counts[b_first * 4 + 1], __builtin_popcountll(m));
+        } else if (pass) {
+            atomicAdd(&counts[b * 4 + 1], 1);   // (a wave that straddles two windows: rare)
+        }
+    }
 }
 
 // grid (candidate blocks, B): window b's candidates follow those of the windows before it in the sorted array

@@ -300,6 +300,40 @@ __global__ void k_conv_dw_reduce(const float* __restrict__ partial, int n_chunks
     dw[t] = acc;
 }
 
+// Two-level form for long chunk lists (round 4: a 1.9 M-row layer leaves ~3 700 partials per element, and the single loop above
+// walked them serially in a few blocks -- k_conv_dw_reduce was 6 of the 62 ms of a training step).  Stage 1: group g of GROUPS
+// sums its run of `len` consecutive chunks in order, in place into the run's first slot (a thread only ever touches its own
+// element column); stage 2: the loop above over the GROUPS slots (stride len).  Fixed order: deterministic.
+__global__ void k_reduce_chunk_groups(float* __restrict__ partial, int n_chunks, int64_t per_chunk, int len) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_chunk) return;
+    const int c0 = (int)blockIdx.y * len, c1 = min(c0 + len, n_chunks);
+    if (c0 >= c1) return;
+    float acc = partial[(int64_t)c0 * per_chunk + t];
+    for (int c = c0 + 1; c < c1; ++c) acc += partial[(int64_t)c * per_chunk + t];
+    partial[(int64_t)c0 * per_chunk + t] = acc;
+}
+__global__ void k_conv_dw_reduce_strided(const float* __restrict__ partial, int n_slots, int stride, int64_t per_chunk,
+                                         float* __restrict__ dw, int accumulate) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_chunk) return;
+    float acc = accumulate ? dw[t] : 0.f;
+    for (int c = 0; c < n_slots; ++c) acc += partial[(int64_t)c * stride * per_chunk + t];  // fixed order
+    dw[t] = acc;
+}
+// dw[t] (+)= sum over the chunks' partials; `partial` is scratch (stage 1 overwrites slots of it)
+static void launch_chunk_reduce(float* partial, int n_chunks, int64_t per_chunk, float* dw, int accumulate, hipStream_t s) {
+    constexpr int GROUPS = 16;
+    if (n_chunks <= 2 * GROUPS) {
+        INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(per_chunk, 256)), dim3(256), 0, s, partial, n_chunks, per_chunk, dw, accumulate);
+        return;
+    }
+    const int len = (n_chunks + GROUPS - 1) / GROUPS;
+    const int n_slots = (n_chunks + len - 1) / len;
+    INSMOS_LAUNCH(k_reduce_chunk_groups, dim3(cdiv(per_chunk, 256), n_slots), dim3(256), 0, s, partial, n_chunks, per_chunk, len);
+    INSMOS_LAUNCH(k_conv_dw_reduce_strided, dim3(cdiv(per_chunk, 256)), dim3(256), 0, s, partial, n_slots, len, per_chunk, dw, accumulate);
+}
+
 // ---- column sums (bias gradient): stage 1 per 1024-row block, stage 2 over the blocks ----
 __global__ void __launch_bounds__(256) k_col_sum(const float* __restrict__ a, int ld, int c, int64_t n, int rows_per_block,
                                                   float* __restrict__ partial) {
@@ -815,15 +849,39 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restri
         *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 1) * c + 4 * cg) = ab[1];
     }
     if (!last_block_done(counter, (int)gridDim.x)) return;
-    for (int pr = threadIdx.x; pr < S * c; pr += 256) {   // per (segment, channel), chunks in table order
-        const int sgi = pr / c, cc = pr % c;
-        float ta = 0.f, tb = 0.f;
-        for (int q = seg_first[sgi]; q < seg_first[sgi + 1]; ++q) {
-            ta += part[((int64_t)q * 2 + 0) * c + cc];
-            tb += part[((int64_t)q * 2 + 1) * c + cc];
+    // per (segment, channel): `tpp` threads share a pair, each over a contiguous run of the segment's chunk list (table order), then
+    // one of them adds their sums in thread order -- the result does not depend on which block merges, only on (S, c, chunk table)
+    {
+        float* sa2 = (float*)smv;          // (the reduction buffer is free again: 256 + 256 floats)
+        float* sb2 = sa2 + 256;
+        const int pairs = S * c;
+        int tpp = 1;
+        while (tpp * 2 * pairs <= 256) tpp *= 2;
+        for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
+            const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
+            float ta = 0.f, tb = 0.f;
+            if (pr < pairs) {
+                const int sgi = pr / c, cc = pr % c;
+                const int q0 = seg_first[sgi], q1 = seg_first[sgi + 1];
+                const int per = (q1 - q0 + tpp - 1) / tpp;
+                const int a0 = q0 + sub * per, a1 = min(a0 + per, q1);
+                for (int q = a0; q < a1; ++q) {
+                    ta += part[((int64_t)q * 2 + 0) * c + cc];
+                    tb += part[((int64_t)q * 2 + 1) * c + cc];
+                }
+            }
+            sa2[threadIdx.x] = ta;
+            sb2[threadIdx.x] = tb;
+            __syncthreads();
+            if (pr < pairs && sub == 0) {
+                float xa = 0.f, xb = 0.f;
+                for (int q = 0; q < tpp; ++q) { xa += sa2[threadIdx.x + q]; xb += sb2[threadIdx.x + q]; }
+                const int sgi = pr / c, cc = pr % c;
+                segsum[((int64_t)sgi * 2 + 0) * c + cc] = xa;
+                segsum[((int64_t)sgi * 2 + 1) * c + cc] = xb;
+            }
+            __syncthreads();
         }
-        segsum[((int64_t)sgi * 2 + 0) * c + cc] = ta;
-        segsum[((int64_t)sgi * 2 + 1) * c + cc] = tb;
     }
     __syncthreads();
     for (int cc = threadIdx.x; cc < c; cc += 256) {
@@ -979,7 +1037,7 @@ extern "C" int insmos_sparse_conv_backward_weight(const float* x, int64_t n_in, 
     INSMOS_LAUNCH(k_conv_dw, dim3(nch, K, n_ci * n_co), dim3(256), 0, s, x, ld_x, dy, ld_dy, nbr, n_out, cin, cout, rpc, n_co, ws,
                   K);
     const int64_t per = (int64_t)K * cin * cout;
-    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(per, 256)), dim3(256), 0, s, ws, nch, per, dw, accumulate);
+    launch_chunk_reduce(ws, nch, per, dw, accumulate, s);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
@@ -992,7 +1050,7 @@ extern "C" int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* o
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)((n + 1023) / 1024);
     if (nb > 0) INSMOS_LAUNCH(k_col_sum, dim3(nb, c), dim3(256), 0, s, a, ld, c, n, 1024, ws);
-    INSMOS_LAUNCH(k_conv_dw_reduce, dim3(cdiv(c, 256)), dim3(256), 0, s, ws, nb, (int64_t)c, out, accumulate);
+    launch_chunk_reduce(ws, nb, (int64_t)c, out, accumulate, s);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }
