@@ -255,33 +255,48 @@ class BnPlan:
     CHUNK = 1024   # (upper bound of the adaptive chunk length below when INSMOS_BN_CHUNK pins it)
 
     @staticmethod
-    def chunk_rows(n_rows):
-        """Rows per chunk.  1024 is the measured optimum of these kernels (tools/bn_chunk_probe.sh, BatchNorm ms per cfg-5 step:
-        adaptive 128-2368 rows: 18.6, 1024: 13.4, 4096: 23.8, 16384: 62.8): one block per chunk, and a block streams its rows
-        serially."""
+    def chunk_rows(c=8):
+        """Rows per chunk (one table per chunk length, `table(c)`).  1024 rows for every width is the measured optimum of these kernels
+        (tools/bn_chunk_probe.sh, BatchNorm ms per cfg-5 step: 1024: 12.6; 4096: 23.8; 16384: 62.8; chosen by row count, 128-2368:
+        18.6; chosen by width, 8192 / c elements per block: 26.2 -- shorter chunks multiply the per-block ticket and the last block's
+        merge, which folds chunks x channels partials, longer ones starve the launch of blocks).  INSMOS_BN_CHUNK pins another."""
         fixed = os.environ.get("INSMOS_BN_CHUNK")
         return max(16, int(fixed)) if fixed else BnPlan.CHUNK
 
     def __init__(self, runs, n_rows, n_seg, device):
         """runs: iterable of (row_start, row_end, segment) covering [0, n_rows) (any order)."""
         import numpy as np
-        ch = []
-        step = self.chunk_rows(n_rows)
-        for r0, r1, sg in runs:
-            for a in range(int(r0), int(r1), step):
-                ch.append((a, min(a + step, int(r1)), int(sg), 0))
-        ch = np.asarray(ch, np.int32).reshape(-1, 4)
-        ch = ch[np.argsort(ch[:, 2], kind="stable")]
-        first = np.searchsorted(ch[:, 2], np.arange(n_seg + 1)).astype(np.int32)
+        self._runs = [(int(r0), int(r1), int(sg)) for r0, r1, sg in runs]
+        self.n_rows, self.S, self.device = int(n_rows), int(n_seg), device
         rows = np.zeros(n_seg, np.int32)
-        np.add.at(rows, ch[:, 2], ch[:, 1] - ch[:, 0])
+        for r0, r1, sg in self._runs:
+            rows[sg] += r1 - r0
         assert int(rows.sum()) == int(n_rows), (int(rows.sum()), n_rows)
-        self.n_rows, self.S, self.n_chunks = int(n_rows), int(n_seg), int(len(ch))
         self.seg_rows_host = rows
-        self.chunks = torch.from_numpy(np.ascontiguousarray(ch)).to(device)
-        self.seg_first = torch.from_numpy(first).to(device)
         self.seg_rows = torch.from_numpy(rows).to(device)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)   # the kernels' last-block counter (left zero by each launch)
+        self._tables = {}
+        t = self.table(8)
+        self.chunks, self.seg_first, self.n_chunks = t.chunks, t.seg_first, t.n_chunks   # (the c = 8 table: the historical attributes)
+
+    def table(self, c):
+        """The chunk table for layers of c channels (built on first use, shared by every such layer on this level)."""
+        import numpy as np
+        step = self.chunk_rows(c)
+        if step not in self._tables:
+            ch = []
+            for r0, r1, sg in self._runs:
+                for a in range(r0, r1, step):
+                    ch.append((a, min(a + step, r1), sg, 0))
+            ch = np.asarray(ch, np.int32).reshape(-1, 4)
+            ch = ch[np.argsort(ch[:, 2], kind="stable")]
+            first = np.searchsorted(ch[:, 2], np.arange(self.S + 1)).astype(np.int32)
+            t = type("BnTable", (), {})()
+            t.n_chunks = int(len(ch))
+            t.chunks = torch.from_numpy(np.ascontiguousarray(ch)).to(self.device)
+            t.seg_first = torch.from_numpy(first).to(self.device)
+            self._tables[step] = t
+        return self._tables[step]
 
     @classmethod
     def whole(cls, n_rows, device):
@@ -315,10 +330,11 @@ class BatchNormSegFunction(torch.autograd.Function):
         y = torch.empty((n, c), dtype=torch.float32, device=x.device)
         xhat = torch.empty((n, c), dtype=torch.float32, device=x.device)
         stats = torch.empty(plan.S * 3 * c, dtype=torch.float32, device=x.device)
-        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(plan.n_chunks, c, plan.S)), dtype=torch.float32, device=x.device)
+        tab = plan.table(c)
+        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(tab.n_chunks, c, plan.S)), dtype=torch.float32, device=x.device)
         g32, b32 = gamma.contiguous().float(), beta.contiguous().float()
         _lib.check(lib.insmos_batchnorm_seg_forward(
-            x.data_ptr(), x.stride(0), c, n, plan.chunks.data_ptr(), plan.n_chunks, plan.seg_first.data_ptr(), plan.seg_rows.data_ptr(),
+            x.data_ptr(), x.stride(0), c, n, tab.chunks.data_ptr(), tab.n_chunks, tab.seg_first.data_ptr(), plan.seg_rows.data_ptr(),
             plan.S, g32.data_ptr(), b32.data_ptr(), float(eps), 1 if relu else 0, y.data_ptr(), c, xhat.data_ptr(), stats.data_ptr(),
             running_mean.data_ptr() if running_mean is not None else None, running_var.data_ptr() if running_var is not None else None,
             float(momentum), plan.ticket.data_ptr(), ws.data_ptr(), st), "insmos_batchnorm_seg_forward")
@@ -337,9 +353,10 @@ class BatchNormSegFunction(torch.autograd.Function):
         dx = torch.empty((n, c), dtype=torch.float32, device=dy.device)
         dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
-        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(plan.n_chunks, c, plan.S)), dtype=torch.float32, device=dy.device)
+        tab = plan.table(c)
+        ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(tab.n_chunks, c, plan.S)), dtype=torch.float32, device=dy.device)
         _lib.check(lib.insmos_batchnorm_seg_backward(
-            dy.data_ptr(), c, y.data_ptr(), c, xhat.data_ptr(), c, n, plan.chunks.data_ptr(), plan.n_chunks, plan.seg_first.data_ptr(),
+            dy.data_ptr(), c, y.data_ptr(), c, xhat.data_ptr(), c, n, tab.chunks.data_ptr(), tab.n_chunks, tab.seg_first.data_ptr(),
             plan.seg_rows.data_ptr(), plan.S, gamma.data_ptr(), stats.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), c,
             dgamma.data_ptr(), dbeta.data_ptr(), plan.ticket.data_ptr(), ws.data_ptr(), st), "insmos_batchnorm_seg_backward")
         return dx, dgamma, dbeta, None, None, None, None, None, None
