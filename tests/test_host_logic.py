@@ -456,6 +456,32 @@ def test_checkpoint_layout_check_and_first_contact_warning(tmp_path):
     assert any(p[1] == "MISSING" for p in problems)
 
 
+def test_bn_plan_chunk_tables_cover_every_row_once_per_segment():
+    """BnPlan (insmos_amd/autograd.py): the chunk table the segmented BatchNorm kernels walk -- chunks of one segment each, sorted by
+    segment, covering every row exactly once, segment row counts right; one table per chunk length, built on demand."""
+    import torch
+    from insmos_amd.autograd import BnPlan
+    seg = torch.tensor([0] * 2500 + [1] * 700 + [0] * 1030 + [2] * 5)
+    plan = BnPlan.from_segment_ids(seg, 4)                     # segment 3 is empty
+    assert plan.S == 4 and plan.n_rows == len(seg) and plan.seg_rows.tolist() == [3530, 700, 5, 0]
+    for c in (8, 128):
+        t = plan.table(c)
+        ch = t.chunks.numpy()
+        assert t.n_chunks == len(ch) and (ch[:, 1] > ch[:, 0]).all() and (ch[:, 1] - ch[:, 0] <= BnPlan.chunk_rows(c)).all()
+        assert (np.diff(ch[:, 2]) >= 0).all()                  # sorted by segment
+        cover = np.zeros(len(seg), np.int32)
+        for r0, r1, sg, _ in ch:
+            assert (seg[r0:r1] == sg).all()                    # a chunk never straddles segments
+            cover[r0:r1] += 1
+        assert (cover == 1).all()
+        first = t.seg_first.tolist()
+        assert first[0] == 0 and first[-1] == t.n_chunks and all(a <= b for a, b in zip(first, first[1:]))
+        assert first[3] == first[4]                            # the empty segment has no chunks
+    assert plan.table(8) is plan.table(16)                     # same chunk length -> the same table object
+    whole = BnPlan.whole(3000, "cpu")
+    assert whole.S == 1 and whole.table(8).n_chunks == 3 and whole.seg_rows.tolist() == [3000]
+
+
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus N` with no launcher around it starts N ranks (round-3 review: the flag was parsed and ignored, an
     8-GPU call would have measured one GPU); inside a launcher a --gpus that disagrees with WORLD_SIZE is refused.  The
