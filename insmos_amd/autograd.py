@@ -256,12 +256,19 @@ class BnPlan:
 
     @staticmethod
     def chunk_rows(c=8):
-        """Rows per chunk (one table per chunk length, `table(c)`).  1024 rows for every width is the measured optimum of these kernels
-        (tools/bn_chunk_probe.sh, BatchNorm ms per cfg-5 step: 1024: 12.6; 4096: 23.8; 16384: 62.8; chosen by row count, 128-2368:
-        18.6; chosen by width, 8192 / c elements per block: 26.2 -- shorter chunks multiply the per-block ticket and the last block's
-        merge, which folds chunks x channels partials, longer ones starve the launch of blocks).  INSMOS_BN_CHUNK pins another."""
+        """Rows per chunk for a layer of c channels (one table per chunk length, `table(c)`): about 64 K ELEMENTS per block -- 4096 rows
+        at c <= 16, 2048 at 32, 1024 at 64, 512 from 128 on.  Measured per shape (tools/bn_shape_probe.py, forward + backward of one
+        layer, us): 1.9 M x 8: 476 at 1024 rows, 282 at 4096; 850 k x 16: 330 / 265; 335 k x 32: 234 at 1024, 226 at 2048, 309 at
+        4096; 75 k x 128: 294 at 1024, 242 at 512, 790 at 4096.  (One length for every width cannot win: 4096 everywhere made the step's
+        BatchNorm 23.8 ms against 12.6 at 1024, SHORTER chunks for wider layers 26.2.)  INSMOS_BN_CHUNK pins one length."""
         fixed = os.environ.get("INSMOS_BN_CHUNK")
-        return max(16, int(fixed)) if fixed else BnPlan.CHUNK
+        if fixed:
+            return max(16, int(fixed))
+        rows = 65536 // max(int(c), 1)
+        p2 = 1
+        while p2 * 2 <= rows:
+            p2 *= 2
+        return int(min(4096, max(512, p2)))
 
     def __init__(self, runs, n_rows, n_seg, device):
         """runs: iterable of (row_start, row_end, segment) covering [0, n_rows) (any order)."""

@@ -477,9 +477,9 @@ def test_bn_plan_chunk_tables_cover_every_row_once_per_segment():
         first = t.seg_first.tolist()
         assert first[0] == 0 and first[-1] == t.n_chunks and all(a <= b for a, b in zip(first, first[1:]))
         assert first[3] == first[4]                            # the empty segment has no chunks
-    assert plan.table(8) is plan.table(16)                     # same chunk length -> the same table object
+    assert plan.table(8) is plan.table(16) and BnPlan.chunk_rows(128) == 512 and BnPlan.chunk_rows(8) == 4096   # same length -> same table
     whole = BnPlan.whole(3000, "cpu")
-    assert whole.S == 1 and whole.table(8).n_chunks == 3 and whole.seg_rows.tolist() == [3000]
+    assert whole.S == 1 and whole.table(64).n_chunks == 3 and whole.table(8).n_chunks == 1 and whole.seg_rows.tolist() == [3000]
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
