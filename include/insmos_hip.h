@@ -82,6 +82,15 @@ size_t insmos_level_down4d_ws_bytes(int64_t n);
 int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, uint64_t* out_keys, int32_t* out_coords,
                         int32_t* parent, int32_t* child_start, uint32_t* child_mask, int32_t* counts, void* ws,
                         size_t ws_bytes, void* stream);
+/* Levels 1 .. n_levels (<= 3) of that hierarchy -- the coordinate maps conv1p1s2, conv2p2s2, conv3p4s2 create one from the other
+ * (minkunet.py:139-160) -- in ONE chain of launches: every level's row count stays on the device and is what the next level's
+ * kernels read, so a caller waits once for all counts instead of once per level.  Host pointer lists, entry l - 1 = the arrays of
+ * level l, each with room for n0 rows; chain (device, 4 + 16 * (n_levels + 1) int32): [l - 1] = rows of level l, [4 + 16 * l + d] =
+ * insmos_tslice_starts_batched(level l's keys, max_d 16)[d] for l = 0 .. n_levels (0 = keys0).  n0 < 2^24; ws:
+ * insmos_level_down4d_ws_bytes(n0).  Same arrays (below each count) as the per-level calls. */
+int insmos_level_down4d_chain(const uint64_t* keys0, int64_t n0, int n_levels, int B, uint64_t* const* out_keys,
+                              int32_t* const* out_coords, int32_t* const* parent, int32_t* const* child_start,
+                              uint32_t* const* child_mask, int32_t* chain, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Search-free kernel maps from the Morton hierarchy (same tables insmos_build_nbr would produce, same
@@ -364,6 +373,11 @@ int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, c
 int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
                             float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
                             void* stream);
+/* Launch shape knob of the two entry points above (process-wide; the output bits do not depend on it, tests/test_gpu_conv.py): a
+ * 128-channel layer whose launch would have fewer than max_wgs workgroups -- one to three windows of base_bev_backbone.py's
+ * 150 x 125 map -- runs as two 64-channel workgroups per patch.  -1 = default (environment variable INSMOS_BEV_COSPLIT, else
+ * 1024), 0 = never. */
+int insmos_bev_cosplit(int max_wgs);
 size_t insmos_bev_distance_map_ws_bytes(int B, int H, int W);
 /* coords (n, 4) int32 [b, z, y, x] (spconv indices of the voxels HeightCompression scatters, height_compression.py:24-31) ->
  * dist (B * H * W bytes): Chebyshev distance of every site to the nearest occupied site of its image, capped at cap + 1. */

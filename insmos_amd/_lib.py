@@ -26,6 +26,7 @@ SIGNATURES = {
     "insmos_quantize4d_ex": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "insmos_level_down4d_ws_bytes": (c_sz, [c_i64]),
     "insmos_level_down4d": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "insmos_level_down4d_chain": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_nbr_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "insmos_nbr81_from_coarse": (c_int, [c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_nbr81_from_coarse_rows": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "insmos_build_nbr_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_build_nbr_rank_sparse": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_forward_regroup": (c_int, [c_int]),
+    "insmos_bev_cosplit": (c_int, [c_int]),
     "insmos_regroup_rows3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_regroup_ws_bytes": (c_sz, [c_i64]),
     "insmos_regroup_rows3d_global": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, int ld_out, int relu, int n_tx, int n_ty,
                                                      const uint8_t* __restrict__ dist, int reach, int breach,
-                                                     const float* __restrict__ cvec, int ty_fast) {
+                                                     const float* __restrict__ cvec, int ty_fast, int ntile) {
     constexpr int JT = TH / 2;                          // row groups per wave
     constexpr int NSITE = (TH + 2) * BEV_HW;            // halo sites
     constexpr int NTHR = 128 * NCG;
@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     // patch origin: (u, v) = (fast axis, slow axis) of the patch; u is x (v is y) unless YM
     const int u0 = tx * BEV_TW, v0 = ty * TH;
     const int U = YM ? H : W, V = YM ? W : H;
-    const int ntile = NCG * COT;
+    // ntile = channel tiles of the LAYER (the weight blocks' pitch); this workgroup owns NCG * COT of them from tile0 on
+    // (blockIdx.y: a 128-channel layer run as two 64-channel workgroups per patch when the patches alone cannot fill the chip)
+    const int tile0 = (int)blockIdx.y * NCG * COT;
 
     // ---- SKIP: which of the patch's TH row groups hold a non-constant output site (bit r of `pact`; wave-uniform, and the same in
     // every wave of the workgroup: each wave looks at the whole patch)
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
 #pragma unroll
     for (int r = 0; r < JT; ++r) boff[r] = (uint32_t)(((rh * JT + r) * BEV_HW + j) * BEV_PITCH + 4 * g);
     // byte offset of this lane's A fragment inside a (tap, chunk) block of `ntile` fragments
-    const uint32_t aoff = (uint32_t)((ch * COT) * 1024 + lane * 16);
+    const uint32_t aoff = (uint32_t)((tile0 + ch * COT) * 1024 + lane * 16);
     const uint32_t blk_bytes = (uint32_t)ntile * 1024u;          // one (tap, chunk) block
     const uint32_t tap_bytes = (uint32_t)n16 * blk_bytes;
 
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
         float* op = out + (((size_t)img * H + gy) * W + gx) * (size_t)ld_out;
 #pragma unroll
         for (int it = 0; it < COT; ++it) {
-            const int co0 = (ch * COT + it) * 16 + 4 * g;
+            const int co0 = (tile0 + ch * COT + it) * 16 + 4 * g;
             if (SKIP && !((ract >> r) & 1u)) {   // a constant row group: the layer's constant vector (bias and ReLU included)
                 *(f32x4*)(op + co0) = *(const f32x4*)(cvec + co0);
                 continue;
@@ -342,6 +344,19 @@ static void bev_choose_patch(int B, int H, int W, int* th_out, int* ym_out, int 
     *ym_out = best_ym;
 }
 
+// workgroup count below which a 128-channel layer is run as two 64-channel workgroups per patch (insmos_bev_cosplit; 0 = never)
+static int g_bev_cosplit = -1;
+static int bev_cosplit_max_wgs() {
+    if (g_bev_cosplit >= 0) return g_bev_cosplit;
+    static const int env = [] { const char* e = getenv("INSMOS_BEV_COSPLIT"); return e ? atoi(e) : 1024; }();
+    return env < 0 ? 0 : env;
+}
+extern "C" int insmos_bev_cosplit(int max_wgs) {
+    if (max_wgs < -1) return INSMOS_EINVAL;
+    g_bev_cosplit = max_wgs;
+    return INSMOS_OK;
+}
+
 static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
                             float* out, int ld_out, int cout, int relu, const uint8_t* dist, int reach, int breach,
                             const float* cvec, void* stream) {
@@ -366,22 +381,29 @@ static int bev_conv3x3_impl(const float* x, int B, int H, int W, int ld_x, int c
     // (experiment, never the default: split-bf16 x 3 when the mode is set and this layer's split weights are registered)
     const float* wsplit = conv_precision() == 3 ? (const float*)split_weights_of(wpacked) : nullptr;
     const bool skip = dist != nullptr && cvec != nullptr && !wsplit;
+    // Channel split (round 4): a 128-channel layer whose patches alone cannot fill the chip -- ONE window: 304 workgroups of 8 waves
+    // for 256 CUs, 48 CUs with two of them and the rest with one -- runs as two 64-channel workgroups of 4 waves per patch
+    // (gridDim.y = 2, the Cout = 64 kernel on channel tiles tile0 ..): twice the workgroups at half the matrix work each, the halo
+    // read twice (55 of 350 KB per workgroup).  Every output channel is the same chain of MFMAs either way: same bits
+    // (tests/test_gpu_conv.py).  Launch sets of four windows or more have workgroups enough and keep the 8-wave kernel.
+    const int ntile_all = cout / 16;
+    const int cosplit = (cout == 128 && (int64_t)grid < (int64_t)bev_cosplit_max_wgs()) ? 2 : 1;
 #define BEV_GO(TH_, NCG_, YM_)                                                                                                  \
     do {                                                                                                                        \
         if (wsplit)                                                                                                             \
-            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 3>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wsplit, \
-                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast);                                          \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 3>), dim3(grid, cosplit), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wsplit, \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast, ntile_all);                               \
         else if (skip)                                                                                                          \
-            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0, true>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16,   \
-                          wpacked, bias, out, ld_out, relu, n_tx, n_ty, dist, reach, breach, cvec, ty_fast);                             \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0, true>), dim3(grid, cosplit), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, \
+                          wpacked, bias, out, ld_out, relu, n_tx, n_ty, dist, reach, breach, cvec, ty_fast, ntile_all);                  \
         else                                                                                                                    \
-            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0>), dim3(grid), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, \
-                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast);                                          \
+            INSMOS_LAUNCH((k_bev_conv3x3<TH_, 2, NCG_, YM_, 0>), dim3(grid, cosplit), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, \
+                          bias, out, ld_out, relu, n_tx, n_ty, nullptr, 0, 0, nullptr, ty_fast, ntile_all);                               \
     } while (0)
 #define BEV_TH(NCG_, YM_) \
     do { if (best_th == 10) BEV_GO(10, NCG_, YM_); else if (best_th == 8) BEV_GO(8, NCG_, YM_); else BEV_GO(4, NCG_, YM_); } while (0)
-    if (cout == 128) { if (best_ym) BEV_TH(4, true); else BEV_TH(4, false); }
-    else             { if (best_ym) BEV_TH(2, true); else BEV_TH(2, false); }
+    if (cout == 128 && cosplit == 1) { if (best_ym) BEV_TH(4, true); else BEV_TH(4, false); }
+    else                             { if (best_ym) BEV_TH(2, true); else BEV_TH(2, false); }
 #undef BEV_TH
 #undef BEV_GO
     HIP_TRY(hipGetLastError());

@@ -1136,6 +1136,67 @@ __global__ void k_tslice_starts_b(const uint64_t* __restrict__ keys, int64_t n, 
     starts[d] = (int32_t)lo;
 }
 
+
+// ---- the level-down chain (insmos_level_down4d_chain): the same three kernels with the row count read from DEVICE memory, so that
+// levels 1..3 follow each other without a host round trip.  Grids are sized for the finest level (an upper bound of every count).
+__global__ void k_head_flags_dn(const uint64_t* __restrict__ keys, int64_t n_cap, const int32_t* __restrict__ n_dev, int64_t n_host,
+                                int shift_bits, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cap) return;
+    const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+    int f = 0;
+    if (i < n) {
+        const uint64_t k = keys[i];
+        if (k != INSMOS_INVALID_KEY) f = (i == 0) || ((k >> shift_bits) != (keys[i - 1] >> shift_bits));
+    }
+    flag[i] = f;   // (rows past the count flag 0: the scan over n_cap rows then ends on the level's count)
+}
+__global__ void k_level_down_scatter_dn(const uint64_t* __restrict__ keys, const int32_t* __restrict__ flag,
+                                        const int32_t* __restrict__ scan, const int32_t* __restrict__ n_dev, int64_t n_host,
+                                        int shift_bits, uint64_t* __restrict__ okeys, int32_t* __restrict__ ocoords,
+                                        int32_t* __restrict__ parent, int32_t* __restrict__ child_start,
+                                        uint32_t* __restrict__ child_mask, int32_t* __restrict__ count_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+    if (i >= n) return;
+    const int vid = scan[i] - 1;
+    if (flag[i]) {   // (the body of k_level_down_scatter; the chain is only used below 2^24 rows: child_start always rides in the mask)
+        const uint64_t k = (keys[i] >> shift_bits) << shift_bits;
+        okeys[vid] = k;
+        int x, y, z, t;
+        key4_decode(k, x, y, z, t);
+        *(int4*)(ocoords + (int64_t)vid * 4) = make_int4(x, y, z, t);
+        child_start[vid] = (int32_t)i;
+        uint32_t m = 0;
+        for (int j = 0; j < 8 && i + j < n; ++j) {
+            const uint64_t kj = keys[i + j];
+            if ((kj >> shift_bits) != (k >> shift_bits)) break;
+            m |= 1u << (unsigned)((kj >> (shift_bits - 3)) & 7ull);
+        }
+        child_mask[vid] = m | ((uint32_t)i << 8);
+    }
+    parent[i] = vid;
+    if (i == n - 1) *count_out = scan[i];
+}
+// k_tslice_starts_b with the row count on the device (null: n_host)
+__global__ void k_tslice_starts_bd(const uint64_t* __restrict__ keys, const int32_t* __restrict__ n_dev, int64_t n_host, int max_d, int B,
+                                   int32_t* __restrict__ starts) {
+    const int d = threadIdx.x;
+    if (d >= max_d) return;
+    const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+    if (n <= 0) { starts[d] = 0; return; }
+    const int tp_last = (int)(keys[n - 1] >> 48) - (int)INSMOS_KEY_BIAS;
+    const int tq_last = tp_last >= 0 ? tp_last / B : -((-tp_last + B - 1) / B);   // floor division
+    const long long want_tp = (long long)(tq_last - d) * B + (long long)INSMOS_KEY_BIAS;
+    const uint64_t want = want_tp > 0 ? (uint64_t)want_tp << 48 : 0ull;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    starts[d] = (int32_t)lo;
+}
+
 }  // namespace insmos
 
 using namespace insmos;
@@ -1359,6 +1420,53 @@ extern "C" int insmos_level_down4d(const uint64_t* keys, int64_t n, int shift, u
         INSMOS_LAUNCH(k_level_down_scatter, dim3(g), dim3(TPB), 0, s, keys, flag, scan, n, 3 * shift, out_keys,
                            out_coords, parent, child_start, child_mask, counts);
     }
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// Levels 1 .. n_levels of the MinkUNet coordinate hierarchy (minkunet.py:139-160: conv1p1s2, conv2p2s2, conv3p4s2 create them one
+// from the other) in ONE chain of launches: level l's row count stays on the device (chain[l - 1]) and is what level l + 1's kernels
+// read, so the host waits once -- for all counts and the time-slice starts -- instead of once per level (a single window's forward
+// is a chain of such round trips: DESIGN.md section 6).  Arrays of level l (1-based; index l - 1 of the pointer lists) need room for
+// n0 rows each (every level's count is <= n0).  chain (device, 4 + 16 * (n_levels + 1) int32): [l - 1] = rows of level l,
+// [4 + 16 * l + d] = first row of level l (0 = the given one) whose scan index is >= last - d (insmos_tslice_starts_batched,
+// max_d = 16).  n0 < 2^24 (EINVAL otherwise: the per-level call handles those).  Same outputs as n_levels calls of
+// insmos_level_down4d + insmos_tslice_starts_batched on the rows below each count.
+extern "C" int insmos_level_down4d_chain(const uint64_t* keys0, int64_t n0, int n_levels, int B, uint64_t* const* out_keys,
+                                         int32_t* const* out_coords, int32_t* const* parent, int32_t* const* child_start,
+                                         uint32_t* const* child_mask, int32_t* chain, void* ws, size_t ws_bytes, void* stream) {
+    if (!keys0 || n0 <= 0 || n0 >= (1ll << 24) || n_levels < 1 || n_levels > 3 || B < 1 || !out_keys || !out_coords || !parent ||
+        !child_start || !child_mask || !chain || !ws)
+        return INSMOS_EINVAL;
+    for (int l = 0; l < n_levels; ++l)
+        if (!out_keys[l] || !out_coords[l] || !parent[l] || !child_start[l] || !child_mask[l]) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    int32_t* flag = b.take<int32_t>((size_t)n0);
+    int32_t* scan = b.take<int32_t>((size_t)n0);
+    const size_t sc = scan_i32_temp((size_t)n0);
+    char* tmp = b.take<char>(sc);
+    if (!b.ok) return INSMOS_EWORKSPACE;
+    const unsigned g = cdiv(n0, TPB);
+    const uint64_t* kin = keys0;
+    for (int l = 1; l <= n_levels; ++l) {
+        const int32_t* n_dev = l == 1 ? nullptr : chain + (l - 2);
+        {
+            ProfScope ps(KK_LEVEL_DOWN, s);
+            INSMOS_LAUNCH(k_head_flags_dn, dim3(g), dim3(TPB), 0, s, kin, n0, n_dev, n0, 3 * l, flag);
+        }
+        int rc = inclusive_scan_i32(tmp, sc, flag, scan, (size_t)n0, s);
+        if (rc) return rc;
+        {
+            ProfScope ps(KK_LEVEL_DOWN, s);
+            INSMOS_LAUNCH(k_level_down_scatter_dn, dim3(g), dim3(TPB), 0, s, kin, flag, scan, n_dev, n0, 3 * l, out_keys[l - 1],
+                          out_coords[l - 1], parent[l - 1], child_start[l - 1], child_mask[l - 1], chain + (l - 1));
+            INSMOS_LAUNCH(k_tslice_starts_bd, dim3(1), dim3(64), 0, s, kin, n_dev, n0, 16, B, chain + 4 + 16 * (l - 1));
+        }
+        kin = out_keys[l - 1];
+    }
+    INSMOS_LAUNCH(k_tslice_starts_bd, dim3(1), dim3(64), 0, s, kin, (const int32_t*)(chain + (n_levels - 1)), n0, 16, B,
+                  chain + 4 + 16 * n_levels);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

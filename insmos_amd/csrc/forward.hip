@@ -354,34 +354,61 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     if (n[0] == 0) return INSMOS_EINVAL;
     for (int b = 0; b < B; ++b)
         if (outs[b].n_cur == 0) return INSMOS_EINVAL;  // (a window without t == 0 points; the caller reads n_cur)
-    for (int l = 1; l <= 3; ++l) {
-        const int64_t np = n[l - 1];
-        keys[l] = A.take<uint64_t>(np);
-        coords[l] = A.take<int32_t>(4 * np);
-        parent[l - 1] = A.take<int32_t>(np);
-        cstart[l - 1] = A.take<int32_t>(np);
-        cmask[l - 1] = A.take<uint32_t>(np);
-        const size_t wsb = insmos_level_down4d_ws_bytes(np);
-        const size_t mark = A.off;
-        void* ws = A.take<char>(wsb);
-        NEED_ARENA();
-        CK(insmos_level_down4d(keys[l - 1], np, l, keys[l], coords[l], parent[l - 1], cstart[l - 1], cmask[l - 1], counts, ws,
-                               wsb, s));
-        CK(read_counts(counts, hc, 1, s));
-        A.off = mark;
-        n[l] = hc[0];
-    }
-    for (int b = 0; b < B; ++b)
-        for (int l = 0; l < 4; ++l) outs[b].me_voxels[l] = n[l];  // batch totals
     // Dead-row elimination (same as Engine.motionnet): starts[l][d] = first level-l row with
     // t >= t_last - d; a layer whose output is needed d scans back computes rows [starts[l][d], n[l]) only.
     int32_t starts[4][16];
-    {
+    // INSMOS_LEVEL_CHAIN: 1 (default) = a single window's three level-downs and the four time-slice searches run as ONE chain of
+    // launches with the counts kept on the device (insmos_level_down4d_chain) and ONE read-back instead of four -- each read-back of
+    // this section is an idle gap on the GPU, nothing else is queued yet; 2 = launch sets too (their scans then run over the finest
+    // level's row count three times: not worth it with other sets in flight); 0 = level by level.
+    // (read per call, not cached: tools/b1_ab.py flips it inside one process)
+    const int chain_env = [] { const char* e = getenv("INSMOS_LEVEL_CHAIN"); return e ? atoi(e) : 1; }();
+    if (((chain_env == 1 && B == 1) || chain_env >= 2) && n[0] < (1ll << 24)) {
+        uint64_t* ok[3];
+        int32_t* oc[3];
+        for (int l = 1; l <= 3; ++l) {   // (room for n[0] rows each: every level's count is bounded by the finest one's)
+            keys[l] = ok[l - 1] = A.take<uint64_t>(n[0]);
+            coords[l] = oc[l - 1] = A.take<int32_t>(4 * n[0]);
+            parent[l - 1] = A.take<int32_t>(n[0]);
+            cstart[l - 1] = A.take<int32_t>(n[0]);
+            cmask[l - 1] = A.take<uint32_t>(n[0]);
+        }
+        int32_t* chain = A.take<int32_t>(4 + 64);
+        const size_t wsb = insmos_level_down4d_ws_bytes(n[0]);
+        const size_t mark = A.off;
+        void* ws = A.take<char>(wsb);
+        NEED_ARENA();
+        CK(insmos_level_down4d_chain(keys[0], n[0], 3, B, ok, oc, parent, cstart, cmask, chain, ws, wsb, s));
+        int32_t hch[4 + 64];
+        CK(read_counts(chain, hch, 4 + 64, s));
+        A.off = mark;
+        for (int l = 1; l <= 3; ++l) n[l] = hch[l - 1];
+        memcpy(&starts[0][0], hch + 4, sizeof(starts));
+    } else {
+        for (int l = 1; l <= 3; ++l) {
+            const int64_t np = n[l - 1];
+            keys[l] = A.take<uint64_t>(np);
+            coords[l] = A.take<int32_t>(4 * np);
+            parent[l - 1] = A.take<int32_t>(np);
+            cstart[l - 1] = A.take<int32_t>(np);
+            cmask[l - 1] = A.take<uint32_t>(np);
+            const size_t wsb = insmos_level_down4d_ws_bytes(np);
+            const size_t mark = A.off;
+            void* ws = A.take<char>(wsb);
+            NEED_ARENA();
+            CK(insmos_level_down4d(keys[l - 1], np, l, keys[l], coords[l], parent[l - 1], cstart[l - 1], cmask[l - 1], counts, ws,
+                                   wsb, s));
+            CK(read_counts(counts, hc, 1, s));
+            A.off = mark;
+            n[l] = hc[0];
+        }
         int32_t* sd = A.take<int32_t>(64);
         NEED_ARENA();
         for (int l = 0; l < 4; ++l) CK(insmos_tslice_starts_batched(keys[l], n[l], 16, B, sd + 16 * l, s));
         CK(read_counts(sd, &starts[0][0], 64, s));
     }
+    for (int b = 0; b < B; ++b)
+        for (int l = 0; l < 4; ++l) outs[b].me_voxels[l] = n[l];  // batch totals
     auto row_from = [&](int l, int d) -> int64_t { return d < 16 ? starts[l][d] : 0; };
 
     // kernels address a table with 32-bit byte offsets: a batch whose finest 81-tap table would pass 2 GiB is refused

@@ -692,6 +692,7 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_dx(const float* __restrict__ 
 // threads read consecutive 16-byte pieces.  Same outputs as the scalar kernels up to the summation order inside a chunk
 // (fixed, deterministic); the cross-chunk merges are the same code.
 typedef float bn_f4 __attribute__((ext_vector_type(4)));
+constexpr int BN_U = 8;   // rows a thread of the statistics kernel keeps in flight
 
 template <int NV>   // tree reduction of NV float4 per thread over the row lanes (threads t, t + G, t + 2G, ... share channel group t % G)
 __device__ __forceinline__ void bn_reduce_rows(bn_f4 (&v)[NV], bn_f4* __restrict__ sm, int G) {
@@ -722,15 +723,41 @@ __global__ void __launch_bounds__(256) k_bnseg_stats_v4(const float* __restrict_
     const BnChunk ch = chunks[blockIdx.x];
     const int G = 1 << L4, t = threadIdx.x;
     const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
+    // (a thread's rows are requested BN_U at a time and added in row order: the same sum chain as a one-row loop, with BN_U loads in
+    //  flight per thread instead of one -- at one block per chunk these loops were a chain of memory latencies, 66 us per launch
+    //  for a 16 us byte stream: profiles/r04_rocprof_kernel_stats_cfg5.csv)
     bn_f4 acc[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
-    for (int r = ch.r0 + rl; r < ch.r1; r += RL) acc[0] += *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg);
+    {
+        int r = ch.r0 + rl;
+        for (; r + (BN_U - 1) * RL < ch.r1; r += BN_U * RL) {
+            bn_f4 v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) v[u] = *(const bn_f4*)(x + (int64_t)(r + u * RL) * ld + 4 * cg);
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) acc[0] += v[u];
+        }
+        for (; r < ch.r1; r += RL) acc[0] += *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg);
+    }
     bn_reduce_rows<1>(acc, smv, G);
     const float inv = 1.0f / (float)(ch.r1 - ch.r0);
     const bn_f4 mean = acc[0] * inv;
     bn_f4 m2[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
-    for (int r = ch.r0 + rl; r < ch.r1; r += RL) {
-        const bn_f4 d = *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg) - mean;
-        m2[0] += d * d;
+    {
+        int r = ch.r0 + rl;
+        for (; r + (BN_U - 1) * RL < ch.r1; r += BN_U * RL) {
+            bn_f4 v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) v[u] = *(const bn_f4*)(x + (int64_t)(r + u * RL) * ld + 4 * cg);
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const bn_f4 d = v[u] - mean;
+                m2[0] += d * d;
+            }
+        }
+        for (; r < ch.r1; r += RL) {
+            const bn_f4 d = *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg) - mean;
+            m2[0] += d * d;
+        }
     }
     bn_reduce_rows<1>(m2, smv, G);
     if (rl == 0) {
@@ -832,16 +859,43 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restri
     const int G = 1 << L4, t = threadIdx.x;
     const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
     bn_f4 ab[2] = {(bn_f4){0.f, 0.f, 0.f, 0.f}, (bn_f4){0.f, 0.f, 0.f, 0.f}};
-    for (int r = ch.r0 + rl; r < ch.r1; r += RL) {
-        bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
-        if (relu) {
-            const bn_f4 yy = *(const bn_f4*)(y + (int64_t)r * ld_y + 4 * cg);
+    {
+        // (BN_UB rows' (dy, y, x^) requested together, folded in row order: the sums' chains are those of a one-row loop)
+        constexpr int BN_UB = 4;
+        int r = ch.r0 + rl;
+        for (; r + (BN_UB - 1) * RL < ch.r1; r += BN_UB * RL) {
+            bn_f4 g[BN_UB], yy[BN_UB], xh[BN_UB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (!(yy[i] > 0.f)) g[i] = 0.f;
+            for (int u = 0; u < BN_UB; ++u) {
+                g[u] = *(const bn_f4*)(dy + (int64_t)(r + u * RL) * ld_dy + 4 * cg);
+                xh[u] = *(const bn_f4*)(xhat + (int64_t)(r + u * RL) * c + 4 * cg);
+            }
+            if (relu) {
+#pragma unroll
+                for (int u = 0; u < BN_UB; ++u) yy[u] = *(const bn_f4*)(y + (int64_t)(r + u * RL) * ld_y + 4 * cg);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UB; ++u) {
+                if (relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (!(yy[u][i] > 0.f)) g[u][i] = 0.f;
+                }
+                ab[0] += g[u];
+                ab[1] += g[u] * xh[u];
+            }
         }
-        ab[0] += g;
-        ab[1] += g * *(const bn_f4*)(xhat + (int64_t)r * c + 4 * cg);
+        for (; r < ch.r1; r += RL) {
+            bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
+            if (relu) {
+                const bn_f4 yy = *(const bn_f4*)(y + (int64_t)r * ld_y + 4 * cg);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(yy[i] > 0.f)) g[i] = 0.f;
+            }
+            ab[0] += g;
+            ab[1] += g * *(const bn_f4*)(xhat + (int64_t)r * c + 4 * cg);
+        }
     }
     bn_reduce_rows<2>(ab, smv, G);
     if (rl == 0) {

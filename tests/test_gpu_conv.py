@@ -633,6 +633,20 @@ def test_bev_constant_region_skipping_is_bitwise_the_dense_kernel(B, H, W, c0):
                                              ob.data_ptr(), 128, 128, 1, dist.data_ptr(), l, consts[l].data_ptr(), st), "insmos_bev_conv3x3_skip")
         torch.cuda.synchronize()
         assert torch.equal(oa, ob), (l, float((oa - ob).abs().max()))
+        # launch shape: these small launches ran as two 64-channel workgroups per patch (insmos_bev_cosplit, default 1024 workgroups);
+        # the one-workgroup-per-patch launch gives the same bits, dense and skipping
+        try:
+            assert L.insmos_bev_cosplit(0) == 0 and L.insmos_bev_cosplit(-2) != 0
+            oc = torch.full((B * H * W, 128), -5.0, device="cuda:0")
+            od = torch.full((B * H * W, 128), -7.0, device="cuda:0")
+            _lib.check(L.insmos_bev_conv3x3(xa.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(),
+                                            oc.data_ptr(), 128, 128, 1, st), "insmos_bev_conv3x3")
+            _lib.check(L.insmos_bev_conv3x3_skip(xb.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(),
+                                                 od.data_ptr(), 128, 128, 1, dist.data_ptr(), l, consts[l].data_ptr(), st), "insmos_bev_conv3x3_skip")
+            torch.cuda.synchronize()
+        finally:
+            L.insmos_bev_cosplit(-1)
+        assert torch.equal(oa, oc) and torch.equal(oa, od), (l, float((oa - oc).abs().max()), float((oa - od).abs().max()))
         # the constant is what the kernel computes far from every voxel and from the border (when the map has such a site)
         far = (want > l + 1)
         far[:, :max(l, 0), :] = False; far[:, H - max(l, 0):, :] = False; far[:, :, :max(l, 0)] = False; far[:, :, W - max(l, 0):] = False

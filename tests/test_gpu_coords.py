@@ -542,3 +542,59 @@ def test_tables_derived_from_sparsely_stored_coarse_tables(window, engine):
                                                 out.data_ptr() + 32, 16, 1, cubes.data_ptr(), stream()) == 0
             torch.cuda.synchronize()
             assert torch.equal(out[:, 8:16], out_ref)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_level_down_chain_equals_the_per_level_calls(window, engine, B):
+    """insmos_level_down4d_chain (levels 1..3 and the time-slice starts in one chain of launches, counts on the device: one host wait
+    for a single window's forward instead of four) against three insmos_level_down4d + four insmos_tslice_starts_batched calls:
+    counts, keys, coordinates, parent / child_start / child_mask and the starts, every array below its level's count, bit for bit."""
+    import ctypes
+    from gpu_util import dev, lib, stream, ws
+    from insmos_amd import _lib
+    pts = dev(window)
+    engine.const_input = True
+    engine.motionnet(pts)
+    torch.cuda.synchronize()
+    keys0 = engine._me_tables["keys"][0].clone()
+    if B > 1:   # a launch set's time field is t * B + b: spread the rows over B windows (order kept: b ascends with the row)
+        k = keys0.cpu().numpy().view(np.uint64)
+        t = (k >> np.uint64(48)).astype(np.int64) - 32768
+        b = (np.arange(len(k)) * B // len(k)).astype(np.int64)
+        tp = t * B + b
+        k2 = (k & np.uint64((1 << 48) - 1)) | ((tp + 32768).astype(np.uint64) << np.uint64(48))
+        k2.sort()
+        keys0 = torch.from_numpy(k2.view(np.int64)).cuda()
+    n0 = int(keys0.shape[0])
+    L, st = lib(), stream()
+    w = ws(L.insmos_level_down4d_ws_bytes(n0))
+    counts = torch.zeros(8, dtype=torch.int32, device="cuda")
+    ref, n, kin = [], [n0], keys0
+    for l in (1, 2, 3):
+        arrs = [torch.empty(n[-1], dtype=torch.int64, device="cuda"), torch.empty((n[-1], 4), dtype=torch.int32, device="cuda")] + \
+               [torch.empty(n[-1], dtype=torch.int32, device="cuda") for _ in range(3)]
+        _lib.check(L.insmos_level_down4d(kin.data_ptr(), n[-1], l, *[a.data_ptr() for a in arrs], counts.data_ptr(), w.data_ptr(),
+                                         w.numel(), st), "insmos_level_down4d")
+        nl = int(counts[0].item())
+        ref.append(arrs)
+        n.append(nl)
+        kin = arrs[0][:nl]
+    starts = torch.zeros((4, 16), dtype=torch.int32, device="cuda")
+    level_keys = [keys0] + [r[0] for r in ref]
+    for l in range(4):
+        _lib.check(L.insmos_tslice_starts_batched(level_keys[l].data_ptr(), n[l], 16, B, starts[l].data_ptr(), st), "insmos_tslice_starts_batched")
+    got = [[torch.full((n0,), -7, dtype=torch.int64, device="cuda"), torch.full((n0, 4), -7, dtype=torch.int32, device="cuda")] +
+           [torch.full((n0,), -7, dtype=torch.int32, device="cuda") for _ in range(3)] for _ in range(3)]
+    chain = torch.full((4 + 64,), -1, dtype=torch.int32, device="cuda")
+    ptrs = [(ctypes.c_void_p * 3)(*[g[i].data_ptr() for g in got]) for i in range(5)]
+    _lib.check(L.insmos_level_down4d_chain(keys0.data_ptr(), n0, 3, B, *ptrs, chain.data_ptr(), w.data_ptr(), w.numel(), st),
+               "insmos_level_down4d_chain")
+    torch.cuda.synchronize()
+    ch = chain.cpu().numpy()
+    assert ch[:3].tolist() == n[1:], (ch[:3], n)
+    np.testing.assert_array_equal(ch[4:].reshape(4, 16), starts.cpu().numpy())
+    for l in range(3):
+        for i, rows in enumerate((n[l + 1], n[l + 1], n[l], n[l + 1], n[l + 1])):   # keys, coords, parent (per fine row), child_start, child_mask
+            assert torch.equal(got[l][i][:rows], ref[l][i][:rows]), (l, i)
+        assert int((got[l][0][n[l + 1]:] != -7).sum()) == 0                        # nothing written past the count
+    assert L.insmos_level_down4d_chain(keys0.data_ptr(), 1 << 24, 3, B, *ptrs, chain.data_ptr(), w.data_ptr(), w.numel(), st) != 0

@@ -54,7 +54,17 @@ def analyze(d):
         print("window: %d kernels, wall %.1f us, busy(union) %.1f us, kernel sum %.1f us, idle %.1f us in %d gaps (>%d us: %d, sum %.1f us)" % (
             len(g), (t1 - t0) / 1e3, busy / 1e3, ksum / 1e3, sum(gaps) / 1e3, len(gaps), 10, sum(1 for x in gaps if x > 10_000),
             sum(x for x in gaps if x > 10_000) / 1e3))
+    # the gaps of the last window, largest first: what ran before and after each (the read-backs and other host round trips)
     g = groups[-1]
+    hi, prev = g[0][0], g[0]
+    gl = []
+    for r in g:
+        if r[0] > hi:
+            gl.append((r[0] - hi, (hi - g[0][0]) / 1e3, prev[2].split("(")[0][-44:], r[2].split("(")[0][-44:]))
+        if r[1] > hi:
+            hi, prev = r[1], r
+    for d, at, a, b in sorted(gl, reverse=True)[:24]:
+        print("  gap %6.1f us at %7.1f us  after %-44s before %s" % (d / 1e3, at, a, b))
     agg = {}
     for s, e, n in g:
         k = n.split("(")[0][-60:]
