@@ -373,7 +373,14 @@ int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x, int cin, c
 int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
                             float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
                             void* stream);
-/* Launch shape knob of the two entry points above (process-wide; the output bits do not depend on it, tests/test_gpu_conv.py): a
+/* insmos_bev_conv3x3_skip over COMPACTED row groups (round 4): the layer's non-constant 16-site row groups are listed per image
+ * (ascending; ws: insmos_bev_skip_ws_bytes) and the workgroups walk the list four groups at a time, wherever they lie, so every
+ * wave of every workgroup has matrix work; the other groups get the constant.  Same arguments, same output bits. */
+size_t insmos_bev_skip_ws_bytes(int B, int H, int W);
+int insmos_bev_conv3x3_skip_ws(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                               float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
+                               void* ws, size_t ws_bytes, void* stream);
+/* Launch shape knob of the three entry points above (process-wide; the output bits do not depend on it, tests/test_gpu_conv.py): a
  * 128-channel layer whose launch would have fewer than max_wgs workgroups -- one to three windows of base_bev_backbone.py's
  * 150 x 125 map -- runs as two 64-channel workgroups per patch.  -1 = default (environment variable INSMOS_BEV_COSPLIT, else
  * 1024), 0 = never. */
@@ -702,6 +709,11 @@ int insmos_forward_streams(int mask);
  * current at that time; a thread that later runs on another device gets new ones automatically).  Worker threads call it
  * before they end. */
 int insmos_forward_thread_release(void);
+/* Host timeline of the calling thread's last insmos_forward_window(s) call: "stage:microseconds since the call began;..." -- when
+ * the host finished enqueueing each section and when each count read-back returned (the reference's caller hands over ONE window
+ * per call, scripts/predict_mos.py:290,434: that latency is a chain of these).  Recorded only with INSMOS_HOST_MARKS=1 in the
+ * environment (empty string otherwise); tools/b1_host_marks.py prints it. */
+int insmos_forward_host_marks(char* buf, size_t cap);
 /* Row regrouping of the runner's 3D levels 1..4, one decimal digit per level (level 1 = units): 0 = off, 1 = blocks of 256 rows,
  * 2 = 1024, 3 = 4096 (insmos_regroup_rows3d), 4 = whole windows (insmos_regroup_rows3d_global), 5 = 4096-row blocks with the
  * coordinate parity class above the signature (block_rows -4096); -1 = default (environment

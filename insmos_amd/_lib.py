@@ -83,6 +83,10 @@ SIGNATURES = {
     "insmos_build_nbr_rank_sparse": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_forward_regroup": (c_int, [c_int]),
     "insmos_bev_cosplit": (c_int, [c_int]),
+    "insmos_bev_skip_ws_bytes": (c_sz, [c_int, c_int, c_int]),
+    "insmos_bev_conv3x3_skip_ws": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp,
+                                           c_vp, c_sz, c_vp]),
+    "insmos_forward_host_marks": (c_int, [c_vp, c_sz]),
     "insmos_regroup_rows3d": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_regroup_ws_bytes": (c_sz, [c_i64]),
     "insmos_regroup_rows3d_global": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -17,6 +17,7 @@
 // Arithmetic: v_mfma_f32_16x16x4_f32, exact fp32, fixed summation order (chunk, tap, 4 channel steps): deterministic,
 // every output site a function of its own 3x3 neighbourhood only.  Weights are the same pre-packed A fragments
 // k_sparse_conv uses ([tap][chunk][channel tile][lane][4]); fragment roles as there: i = output channel, j = site.
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 #include "prec.h"
@@ -250,6 +251,207 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? 4 : 2) k_bev_conv3x3(con
     }
 }
 
+// ---- constant-region skipping over a COMPACTED list of row groups (round 4, second half).  The patch kernel above skips inside a
+// fixed 16 x 4 patch: a patch with one active row group of four still stages its whole halo, walks every chunk's barriers and keeps
+// six of its eight waves idle -- the stack executed 58-72 % of the dense (site, tap) pairs in 83-87 % of the dense time
+// (profiles/r04_bev_skip_layers.txt).  Here the ACTIVE 16-site row groups of an image are listed first (k_bev_group_lists:
+// ascending, deterministic) and a workgroup takes TH consecutive list entries, wherever they lie: every wave has work, every
+// workgroup the same amount.  A group brings its own 3 x 18-site halo (groups of one workgroup need not be neighbours: 54 halo
+// sites per group against 21.6 in a dense 16 x 10 patch -- LDS and L2 reads, not HBM: the input was just written by the previous
+// layer).  The inactive groups are the list's tail, written back to front; the workgroups behind the computing ones store the
+// layer's constant into them.  Per output element the MFMA chain is that of k_bev_conv3x3: same bits (tests/test_gpu_conv.py).
+template <int TH, int COT, int NCG, bool YM>
+__global__ void __launch_bounds__(128 * NCG, NCG == 4 ? (TH == 4 ? 6 : 4) : (TH == 4 ? 3 : 2)) k_bev_conv3x3_list(
+    const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int ld_out, int relu, const int32_t* __restrict__ lists, const int32_t* __restrict__ n_act, int G,
+    int n_chunk, int n_tu, const float* __restrict__ cvec, int ntile) {
+    constexpr int JT = TH / 2;                          // row groups per wave
+    constexpr int GS = 3 * BEV_HW;                      // halo sites of one group
+    constexpr int NSITE = TH * GS;
+    constexpr int NTHR = 128 * NCG;
+    constexpr int NQ = (NSITE * 4 + NTHR - 1) / NTHR;   // float4 pieces per thread per chunk
+    __shared__ __attribute__((aligned(16))) float halo[2][NSITE * BEV_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wave & 1, ch = wave >> 1;
+    const int g = lane >> 4, j = lane & 15;
+    const int img = (int)blockIdx.x / n_chunk, c = (int)blockIdx.x % n_chunk;
+    const int U = YM ? H : W, V = YM ? W : H;
+    const int tile0 = (int)blockIdx.y * NCG * COT;
+    const int32_t* __restrict__ L = lists + (size_t)img * G;
+    const int na = n_act[img];
+    const int nca = (na + TH - 1) / TH;
+    if (c >= nca) {
+        // ---- constant fill: TH inactive groups (list tail, back to front) per workgroup, this workgroup's channel tiles
+        constexpr int NV = NCG * COT * 4;               // float4 per site
+        const int first = (c - nca) * TH, n_in = G - na;
+        for (int r = 0; r < TH; ++r) {
+            const int k = first + r;
+            if (k >= n_in) break;
+            const int gid = L[G - 1 - k];
+            const int gv = gid / n_tu, u0 = (gid % n_tu) * BEV_TW;
+            for (int i = tid; i < BEV_TW * NV; i += NTHR) {
+                const int site = i / NV, q = i % NV;
+                const int gu = u0 + site;
+                if (gu >= U) continue;
+                const int gy = YM ? gu : gv, gx = YM ? gv : gu;
+                const int co0 = tile0 * 16 + q * 4;
+                *(f32x4*)(out + (((size_t)img * H + gy) * W + gx) * (size_t)ld_out + co0) = *(const f32x4*)(cvec + co0);
+            }
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_img * H * W * ld_x * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((size_t)9 * n16 * ntile * 1024), 0x00020000);
+    const int k0 = c * TH;                               // first list entry of this workgroup
+    uint32_t src[NQ], dst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + NTHR * q;
+        const int sidx = i >> 2, quarter = i & 3;
+        const int r = sidx / GS, rem = sidx % GS;
+        const int hv = rem / BEV_HW, hu = rem % BEV_HW;
+        bool ok = i < NSITE * 4 && k0 + r < na;
+        int gu = 0, gv = 0;
+        if (ok) {
+            const int gid = L[k0 + r];
+            gv = gid / n_tu - 1 + hv;
+            gu = (gid % n_tu) * BEV_TW - 1 + hu;
+            ok = gu >= 0 && gu < U && gv >= 0 && gv < V;
+        }
+        const int gy = YM ? gu : gv, gx = YM ? gv : gu;
+        src[q] = ok ? (uint32_t)((((size_t)img * H + gy) * W + gx) * (size_t)ld_x * 4u + quarter * 16u) : 0xFFFFFFF0u;
+        dst[q] = i < NSITE * 4 ? (uint32_t)(sidx * BEV_PITCH + quarter * 4) : 0xFFFFFFFFu;
+    }
+    f32x4 pf[NQ];
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            pf[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, src[q], (uint32_t)cc * 64u, 0));
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (dst[q] != 0xFFFFFFFFu) *(f32x4*)(&halo[buf][dst[q]]) = pf[q];
+    };
+    f32x4 acc[COT][JT];
+#pragma unroll
+    for (int it = 0; it < COT; ++it)
+#pragma unroll
+        for (int r = 0; r < JT; ++r) acc[it][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // LDS float offset of this lane's B fragment for tap (0, 0) of the wave's group r: site (row 0, j) of group rh*JT + r
+    uint32_t boff[JT];
+#pragma unroll
+    for (int r = 0; r < JT; ++r) boff[r] = (uint32_t)((((rh * JT + r) * 3) * BEV_HW + j) * BEV_PITCH + 4 * g);
+    const uint32_t aoff = (uint32_t)((tile0 + ch * COT) * 1024 + lane * 16);
+    const uint32_t blk_bytes = (uint32_t)ntile * 1024u;
+    const uint32_t tap_bytes = (uint32_t)n16 * blk_bytes;
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    f32x4 a[3][COT];
+    auto load_a = [&](int slot, int k, int cc) {
+        const uint32_t so = (uint32_t)k * tap_bytes + (uint32_t)cc * blk_bytes;
+#pragma unroll
+        for (int it = 0; it < COT; ++it)
+            a[slot][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, aoff + (uint32_t)it * 1024u, so, 0));
+    };
+    load_a(0, 0, 0);
+    for (int cc = 0; cc < n16; ++cc) {
+        const int buf = cc & 1;
+        const float* hb = halo[buf];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k < 8) load_a((k + 1) % 3, k + 1, cc);
+            else load_a(0, 0, cc + 1 < n16 ? cc + 1 : cc);
+            if (k == 1 && cc + 1 < n16) fetch(cc + 1);
+            const int ky = k / 3, kx = k % 3;
+            const int ku = YM ? ky : kx, kv = YM ? kx : ky;
+            f32x4 b[JT];
+#pragma unroll
+            for (int r = 0; r < JT; ++r) b[r] = *(const f32x4*)(hb + boff[r] + (kv * BEV_HW + ku) * BEV_PITCH);
+            // (the order of k_bev_conv3x3's dense loop; per accumulator the chain (chunk, tap, s) is the same in every variant)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < JT; ++r)
+#pragma unroll
+                    for (int it = 0; it < COT; ++it) acc[it][r] = BEV_MFMA(a[k % 3][it][s], b[r][s], acc[it][r]);
+        }
+        if (cc + 1 < n16) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < JT; ++r) {
+        const int kk = k0 + rh * JT + r;
+        if (kk >= na) continue;                          // (wave-uniform: the list's last workgroup may be short)
+        const int gid = L[kk];
+        const int gv = gid / n_tu, gu = (gid % n_tu) * BEV_TW + j;
+        if (gu >= U) continue;
+        const int gy = YM ? gu : gv, gx = YM ? gv : gu;
+        float* op = out + (((size_t)img * H + gy) * W + gx) * (size_t)ld_out;
+#pragma unroll
+        for (int it = 0; it < COT; ++it) {
+            const int co0 = (tile0 + ch * COT + it) * 16 + 4 * g;
+            f32x4 v = acc[it][r] + *(const f32x4*)(bias + co0);
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *(f32x4*)(op + co0) = v;
+        }
+    }
+}
+
+// The row-group lists of one layer: block = one image; lists[img][0 .. n_act) = ids (v * n_tu + u_tile) of the groups that hold a
+// non-constant site (the predicate of k_bev_conv3x3<SKIP>), ascending; lists[img][G - 1 - k] = the k-th inactive group.
+__global__ void __launch_bounds__(1024) k_bev_group_lists(const uint8_t* __restrict__ dist, int H, int W, int ym, int reach, int breach,
+                                                          int n_tu, int G, int32_t* __restrict__ lists, int32_t* __restrict__ n_act) {
+    __shared__ int wsum[16];
+    __shared__ int s_tot;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int U = ym ? H : W;
+    int32_t* __restrict__ L = lists + (size_t)img * G;
+    int off_act = 0, off_in = 0;
+    for (int base = 0; base < G; base += 1024) {
+        const int gid = base + tid;
+        bool on = false;
+        if (gid < G) {
+            const int v = gid / n_tu, u0 = (gid % n_tu) * BEV_TW;
+            for (int jj = 0; jj < BEV_TW; ++jj) {
+                const int u = u0 + jj;
+                if (u >= U) break;
+                const int gy = ym ? u : v, gx = ym ? v : u;
+                const int bd = min(min(gy, H - 1 - gy), min(gx, W - 1 - gx));
+                on = on || (int)dist[((size_t)img * H + gy) * W + gx] <= reach || bd <= breach;
+            }
+        }
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int q = 0; q < 16; ++q) { const int t = wsum[q]; wsum[q] = run; run += t; }
+            s_tot = run;
+        }
+        __syncthreads();
+        if (gid < G) {
+            const int pos = wsum[wv] + before;            // active groups of this pass before this one
+            if (on) L[off_act + pos] = gid;
+            else L[G - 1 - (off_in + (tid - pos))] = gid;
+        }
+        const int tot = s_tot, cnt = min(1024, G - base);
+        off_act += tot;
+        off_in += cnt - tot;
+        __syncthreads();
+    }
+    if (tid == 0) n_act[img] = off_act;
+}
+
 // ---- Chebyshev distance of every BEV site to the nearest occupied site (bytes, capped at cap + 1), two separable passes
 __global__ void k_bev_occupancy(const int32_t* __restrict__ coords, int64_t n, int H, int W, uint8_t* __restrict__ occ) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,6 +625,53 @@ extern "C" int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int 
                                        void* stream) {
     if (!dist || !cvec || layer < 0 || layer > 200) return INSMOS_EINVAL;
     return bev_conv3x3_impl(x, B, H, W, ld_x, cin, wpacked, bias, out, ld_out, cout, relu, dist, layer + 1, layer - 1, cvec, stream);
+}
+
+// scratch of insmos_bev_conv3x3_skip_ws: one layer's row-group lists and per-image counts
+extern "C" size_t insmos_bev_skip_ws_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t gmax = (int64_t)std::max(H, W) * ((std::max(H, W) + 15) / 16);
+    return pad256((size_t)B * (size_t)gmax * 4) + pad256((size_t)B * 4) + 256;
+}
+
+// insmos_bev_conv3x3_skip over COMPACTED row groups (k_bev_conv3x3_list): the layer's active 16-site row groups are listed per image
+// (ws) and the workgroups walk the list, TH = 4 groups each; the inactive groups get the constant.  Output bits == insmos_bev_conv3x3's.
+extern "C" int insmos_bev_conv3x3_skip_ws(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
+                                          float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
+    if (!x || !wpacked || !bias || !out || !dist || !cvec || !ws || layer < 0 || layer > 200 || cin <= 0 || cin % 16 != 0 || ld_x < cin ||
+        (ld_x & 3) || (cout != 128 && cout != 64) || ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
+        (int64_t)B * H * W * ld_x * 4 >= (1ll << 31))
+        return INSMOS_EINVAL;
+    if (ws_bytes < insmos_bev_skip_ws_bytes(B, H, W)) return INSMOS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int th = 0, ym = 0;
+    bev_choose_patch(B, H, W, &th, &ym, 4);   // (the orientation of the patch kernel's skipping launches: the accounting is shared)
+    const int U = ym ? H : W, V = ym ? W : H;
+    const int n_tu = (U + BEV_TW - 1) / BEV_TW, G = V * n_tu;
+    // groups per workgroup: 4 (41 KB of halo, three workgroups per CU) or 6 (62 KB, two per CU, each weight fragment feeds three
+    // row groups per wave instead of two); INSMOS_BEV_LIST_TH, measured default below
+    static const int TH = [] { const char* e = getenv("INSMOS_BEV_LIST_TH"); const int v = e ? atoi(e) : 4; return v == 6 ? 6 : 4; }();
+    const int n_chunk = (G + TH - 1) / TH + 1;   // ceil(active / TH) + ceil(inactive / TH) <= ceil(G / TH) + 1
+    int32_t* lists = (int32_t*)ws;
+    int32_t* n_act = (int32_t*)((char*)ws + pad256((size_t)B * (size_t)G * 4));
+    const int n16 = cin / 16, ntile_all = cout / 16;
+    const unsigned grid = (unsigned)((int64_t)B * n_chunk);
+    const int cosplit = (cout == 128 && (int64_t)grid < (int64_t)bev_cosplit_max_wgs()) ? 2 : 1;
+    ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = 9; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = (int64_t)B * H * W;
+    INSMOS_LAUNCH(k_bev_group_lists, dim3(B), dim3(1024), 0, s, dist, H, W, ym, layer + 1, layer - 1, n_tu, G, lists, n_act);
+#define BEV_LIST_GO_(TH_, NCG_, YM_)                                                                                                   \
+    INSMOS_LAUNCH((k_bev_conv3x3_list<TH_, 2, NCG_, YM_>), dim3(grid, cosplit), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, \
+                  out, ld_out, relu, lists, n_act, G, n_chunk, n_tu, cvec, ntile_all)
+#define BEV_LIST_GO(NCG_, YM_) do { if (TH == 6) BEV_LIST_GO_(6, NCG_, YM_); else BEV_LIST_GO_(4, NCG_, YM_); } while (0)
+    if (cout == 128 && cosplit == 1) { if (ym) BEV_LIST_GO(4, true); else BEV_LIST_GO(4, false); }
+    else                             { if (ym) BEV_LIST_GO(2, true); else BEV_LIST_GO(2, false); }
+#undef BEV_LIST_GO
+#undef BEV_LIST_GO_
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
 }
 
 extern "C" size_t insmos_bev_distance_map_ws_bytes(int B, int H, int W) { return 2 * pad256((size_t)B * H * W); }

@@ -12,6 +12,7 @@
 // produce identical bits.  All device memory comes from a caller-provided arena (bump-allocated per window).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -98,6 +99,10 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 }
 
 struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
+// launch sets of this many windows or more walk compacted row-group lists in the skipping BEV layers (measured on sets of 8: the six
+// layers 1 844 -> 1 676 us per set, bench 705-712 -> 714 scans/s; ONE window is 1.4 % slower that way -- few workgroups either way,
+// and the list kernel's are heavier: profiles/r04_bev_list_ab.txt)
+constexpr int kBevSkipListMinB = 4;
 int g_regroup = -1;                 // row regrouping modes of the 3D levels set by insmos_forward_regroup; -1 = the default
 constexpr int kRegroupDefault = 3553;   // 4096-row blocks; levels 2 and 3 with the parity class above the signature (their inverse maps feed 64- and 32-channel layers; measured)
 inline bool regroup_modes_ok(int v) {
@@ -207,6 +212,29 @@ int wait_stream(hipStream_t s) {
     return INSMOS_OK;
 }
 
+// Host timeline of the calling thread's last forward (INSMOS_HOST_MARKS=1; insmos_forward_host_marks): when the HOST passed each
+// stage -- enqueue done / read-back returned -- in microseconds since the call began.  A single window's latency is a chain of host
+// round trips and launch bursts; a GPU-side trace (tools/b1_trace.py) shows the gaps, this shows which side was waiting.
+struct HostMarks {
+    static constexpr int kMax = 40;
+    const char* name[kMax];
+    double us[kMax];
+    int n = 0;
+    std::chrono::steady_clock::time_point t0;
+};
+thread_local HostMarks tl_marks;
+static const bool kMarksOn = [] { const char* e = getenv("INSMOS_HOST_MARKS"); return e && e[0] == '1'; }();
+inline void host_mark(const char* what) {
+    if (!kMarksOn) return;
+    HostMarks& m = tl_marks;
+    if (m.n == 0) m.t0 = std::chrono::steady_clock::now();
+    if (m.n < HostMarks::kMax) {
+        m.name[m.n] = what;
+        m.us[m.n] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - m.t0).count();
+        ++m.n;
+    }
+}
+
 int read_counts(const int32_t* dev, int32_t* host, int n, hipStream_t s) {
     int32_t* pin = (size_t)n * sizeof(int32_t) <= 4096 ? tl_pinned.get() : nullptr;
     HIP_TRY(hipMemcpyAsync(pin ? pin : host, dev, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -276,6 +304,8 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     JoinGuard join_guard{s, s2};
     const hipStream_t s2_tab0 = (ts_mask & 1) ? s2 : s, s2_coords = (ts_mask & 2) ? s2 : s, s2_inv = (ts_mask & 4) ? s2 : s,
                       s2_oh = (ts_mask & 8) ? s2 : s;
+    tl_marks.n = 0;
+    host_mark("begin");
     memset(outs, 0, sizeof(*outs) * (size_t)B);
     InsmosForwardOut* out = outs;  // batch-wide figures and error details go to the first entry
     for (int b = 0; b < B; ++b) outs[b].batch = B;
@@ -332,7 +362,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         for (int mode = (packed_keys && !skip_packed && B <= 8 && N < (1ll << 24)) ? 2 : 1; mode >= 0; --mode) {
             CK(insmos_quantize4d_windows(pts_host, n_pts_host, B, ld, quant, keys[0], coords[0], inverse, cur_index, counts, ws, wsb,
                                          mode, s));
+            host_mark("quantize enqueued");
             CK(read_counts(counts, hc, 5 + B, s));
+            host_mark("quantize counts back");
             if (hc[3] == 0) break;
             if (mode == 2) C.packed_overflow.store(256, std::memory_order_relaxed);
         }
@@ -380,7 +412,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         NEED_ARENA();
         CK(insmos_level_down4d_chain(keys[0], n[0], 3, B, ok, oc, parent, cstart, cmask, chain, ws, wsb, s));
         int32_t hch[4 + 64];
+        host_mark("level chain enqueued");
         CK(read_counts(chain, hch, 4 + 64, s));
+        host_mark("level counts back");
         A.off = mark;
         for (int l = 1; l <= 3; ++l) n[l] = hch[l - 1];
         memcpy(&starts[0][0], hch + 4, sizeof(starts));
@@ -546,6 +580,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // branch's coordinate work -- voxel cells, strided coordinate sets, 13 kernel maps: sorts, scans and table kernels with five
     // count read-backs -- needs the current points' POSITIONS only, so it runs on the second stream while those convolutions
     // execute; the motion columns and the MeanVFE feature means follow on the caller's stream once both are done.
+    host_mark("MotionNet enqueued");
     hipStream_t sm = s;   // the stream the rest of the function calls `s`: swapped for the 3D coordinate phase below
     CK(insmos_build_current_points_part(pts_host, n_pts_host, B, ld, nullptr, 0, inverse, cur_index, ncur, cur, 8, 1, s2_coords));
 
@@ -565,7 +600,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     s = s2_coords;   // ---- from here to the join below every launch and read-back goes to the second stream
     CK(insmos_voxelize_windows_phased(cur, ncur, 8, g.in_ch, cur_start_dev, B, key_cells1, g.range, g.vs, g.max_voxels, g.max_points,
                                       feat, 8, coords1, num_points, pcid, ukeys, uperm, counts, vox_ws, vox_wsb, 1, s));
+    host_mark("voxeliser enqueued");
     CK(read_counts(counts, hc, 5 + B, s));
+    host_mark("voxel counts back");
     for (int b = 0; b < B; ++b) outs[b].unet_voxels[0] = hc[4 + b + 1] - hc[4 + b];
     int64_t nv[6] = {0}, nkeys[6] = {0};
     const int32_t* co[6] = {nullptr};       // a level's coordinates in the row order its features are stored in ...
@@ -671,6 +708,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         else
             CK(insmos_down_coords3d_b(co_ref[lvl_in], n_in, ks, st, pd, oshape, B, ok, oc, counts, ws, wsb, s));
         CK(read_counts(counts, hc, 1, s));
+        host_mark("strided level counts back");
         A.off = mark;
         nv[lvl_out] = nkeys[lvl_out] = hc[0];
         if (rank_tables && lvl_out <= 4 && regroup_on(lvl_out) && hc[0] > 0) {   // (level 5 feeds the dense BEV scatter only)
@@ -721,6 +759,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     for (int l = 2; l <= 4; ++l) CK(build(inv[l], l - 1, l, C.d_inv, one4, two3));
     CK(build(down5, 5, 4, C.d_down5, two1, one4));
     CK(build(inv5, 4, 5, C.d_inv5, one4, two1));
+    host_mark("3D kernel maps enqueued");
     // ---- join: the caller's stream (MotionNet done) fills in the motion columns, waits for the coordinate phase, and averages
     s = sm;
     CK(insmos_build_current_points_part(pts_host, n_pts_host, B, ld, motion, 4, inverse, cur_index, ncur, cur, 8, 2, s));
@@ -753,6 +792,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     float* enc = A.take<float>(std::max<int64_t>(nv[5], 1) * 128);
     NEED_ARENA();
     CK(conv("conv_out.0", xc[4], nv[4], 128, 0, &down5, nv[5], enc, 128, 0, nullptr, 0, 0, 0, 0, 1));
+    host_mark("encoder enqueued");
     CK(link_streams(s, s2_inv));   // (inv_conv_out reads `enc` only: it runs on the second stream beside the BEV head, see below)
 
     // ---- BEV detection head in NHWC (height_compression.py:24-31, base_bev_backbone.py:84-115)
@@ -789,6 +829,11 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     static const bool bev_skip = [] { const char* e = getenv("INSMOS_BEV_SKIP"); return !(e && e[0] == '0'); }();
     const uint8_t* bev_dist = nullptr;
     const float* bev_cv = nullptr;
+    void* bev_list_ws = nullptr;
+    size_t bev_list_wsb = 0;
+    // INSMOS_BEV_SKIP_LIST: 1 = the skipping layers walk compacted row-group lists (k_bev_conv3x3_list), 0 = fixed 16 x 4 patches
+    // (k_bev_conv3x3<SKIP>); same bits.  (Read per call: tools flip it inside one process.)
+    const bool bev_list = [&] { const char* e = getenv("INSMOS_BEV_SKIP_LIST"); return e ? e[0] != '0' : B >= kBevSkipListMinB; }();
     if (bev_kernel && bev_skip) {
         bool all_ok = true;
         for (int k = 0; k <= g.n_bev_layers; ++k) {
@@ -803,6 +848,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
             NEED_ARENA();
             CK(insmos_bev_distance_map(co[5], nv[5], B, g.bevH, g.bevW, g.n_bev_layers + 1, d, ws, wsb, s));
             bev_dist = d;
+            bev_list_wsb = insmos_bev_skip_ws_bytes(B, g.bevH, g.bevW);
+            bev_list_ws = A.take<char>(bev_list_wsb);   // (one layer's row-group lists: the layers run one after the other on this stream)
+            NEED_ARENA();
         }
     }
     int bev_layer = 0;
@@ -813,6 +861,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (the constant region shrinks by one ring per layer: past INSMOS_BEV_SKIP_LAYERS layers the skipped work no longer pays
         //  for the uneven workgroups; on the S0 windows it pays on all six layers, profiles/r04_bev_skip_layers.txt: default = all)
         static const int skip_layers = [] { const char* e = getenv("INSMOS_BEV_SKIP_LAYERS"); return e ? atoi(e) : 99; }();
+        if (bev_kernel && bev_dist && layer < skip_layers && bev_list)
+            return insmos_bev_conv3x3_skip_ws(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, bev_dist, layer,
+                                              bev_cv + (size_t)layer * 128, bev_list_ws, bev_list_wsb, s);
         if (bev_kernel && bev_dist && layer < skip_layers)
             return insmos_bev_conv3x3_skip(x, B, g.bevH, g.bevW, ld_in, w->cin, w->w, w->b, o, nf, w->cout, 1, bev_dist, layer,
                                            bev_cv + (size_t)layer * 128, s);
@@ -858,6 +909,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         // (the NMS workspace stays allocated: kernels below are stream-ordered after it, but keep it simple)
     }
     CK(insmos_gather_preds_b(cb, cs, cl, keep, cnt_k, g.pre_max, g.post_max, B, pb, psc, pl, s));
+    host_mark("BEV head + NMS enqueued");
 
     // ---- upsample fusion (spconv_unet.py:319-402)
     int64_t nvmax = 0;
@@ -952,7 +1004,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         int32_t* hc_dst = pin ? pin + 4 * INSMOS_MAX_BATCH : hcand;
         HIP_TRY(hipMemcpyAsync(hk_dst, cnt_k, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(hc_dst, cnt_c, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        host_mark("decoder enqueued");
         CK(wait_stream(s));
+        host_mark("box counts back (end)");
         if (pin) { memcpy(hk, hk_dst, (size_t)B * 16); memcpy(hcand, hc_dst, (size_t)B * 16); }
         for (int b = 0; b < B; ++b) {
             outs[b].n_boxes = hk[4 * b];
@@ -996,6 +1050,19 @@ extern "C" int insmos_forward_streams(int mask) {
 // The calling host thread's second stream and its events are released (a worker thread calls this before it ends; a thread that
 // moves to another device gets new ones on its own, see Aux::init).  Not done from a thread_local destructor: at process exit that
 // would run after the HIP runtime's own teardown.
+// The calling host thread's last forward as text, "stage:microseconds;..." (INSMOS_HOST_MARKS=1 in the environment, else empty).
+extern "C" int insmos_forward_host_marks(char* buf, size_t cap) {
+    if (!buf || cap == 0) return INSMOS_EINVAL;
+    size_t off = 0;
+    buf[0] = 0;
+    for (int i = 0; i < tl_marks.n; ++i) {
+        const int w = snprintf(buf + off, cap - off, "%s:%.1f;", tl_marks.name[i], tl_marks.us[i]);
+        if (w < 0 || (size_t)w >= cap - off) return INSMOS_EWORKSPACE;
+        off += (size_t)w;
+    }
+    return INSMOS_OK;
+}
+
 extern "C" int insmos_forward_thread_release(void) {
     if (tl_aux.s2) (void)hipStreamSynchronize(tl_aux.s2);
     tl_aux.release();

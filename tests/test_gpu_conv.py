@@ -647,6 +647,21 @@ def test_bev_constant_region_skipping_is_bitwise_the_dense_kernel(B, H, W, c0):
         finally:
             L.insmos_bev_cosplit(-1)
         assert torch.equal(oa, oc) and torch.equal(oa, od), (l, float((oa - oc).abs().max()), float((oa - od).abs().max()))
+        # ... and so does the skipping layer over compacted row-group lists (insmos_bev_conv3x3_skip_ws), split and unsplit
+        wsl = torch.empty(int(L.insmos_bev_skip_ws_bytes(B, H, W)), dtype=torch.uint8, device="cuda:0")
+        for split in (-1, 0):
+            try:
+                L.insmos_bev_cosplit(split)
+                oe = torch.full((B * H * W, 128), -9.0, device="cuda:0")
+                _lib.check(L.insmos_bev_conv3x3_skip_ws(xb.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(),
+                                                        oe.data_ptr(), 128, 128, 1, dist.data_ptr(), l, consts[l].data_ptr(), wsl.data_ptr(),
+                                                        wsl.numel(), st), "insmos_bev_conv3x3_skip_ws")
+                torch.cuda.synchronize()
+            finally:
+                L.insmos_bev_cosplit(-1)
+            assert torch.equal(oa, oe), (l, split, float((oa - oe).abs().max()))
+        assert L.insmos_bev_conv3x3_skip_ws(xb.data_ptr(), B, H, W, chans[l], chans[l], layers[l].w.data_ptr(), layers[l].b.data_ptr(), oe.data_ptr(),
+                                            128, 128, 1, dist.data_ptr(), l, consts[l].data_ptr(), wsl.data_ptr(), 16, st) == -3   # EWORKSPACE
         # the constant is what the kernel computes far from every voxel and from the border (when the map has such a site)
         far = (want > l + 1)
         far[:, :max(l, 0), :] = False; far[:, H - max(l, 0):, :] = False; far[:, :, :max(l, 0)] = False; far[:, :, W - max(l, 0):] = False
