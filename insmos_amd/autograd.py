@@ -101,44 +101,6 @@ def _zeros(n, device):
     return z
 
 
-class GatherRowsFunction(torch.autograd.Function):
-    """y = x[idx] (idx int64, rows may repeat).  The backward is the scatter-add of dy into the rows -- torch's own index backward
-    took 0.9 ms per call on the two point gathers of a training step (MotionNet's voxel -> current point slice, motionnet.py:36-48, and
-    the 3D branch's voxel -> point logits, spconv_unet.py:405-416).  Here: stable sort of idx, prefix sums of the re-ordered dy in
-    float64, one difference per distinct row -- deterministic (no atomics), error far below fp32 rounding of the sums."""
-
-    @staticmethod
-    def forward(ctx, x, idx):
-        ctx.save_for_backward(idx)
-        ctx.n = x.shape[0]
-        return x[idx]
-
-    @staticmethod
-    def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
-        N = idx.shape[0]
-        dx = torch.zeros((ctx.n, dy.shape[1]), dtype=dy.dtype, device=dy.device)
-        if N == 0:
-            return dx, None
-        sidx, order = torch.sort(idx, stable=True)
-        # (channel-major: the scan then runs along the contiguous axis -- torch scans an outer axis serially, 100 ms for 500 k x 3)
-        cs = torch.cumsum(dy[order].double().t().contiguous(), 1)
-        last = torch.ones(N, dtype=torch.bool, device=dy.device)
-        last[:-1] = sidx[1:] != sidx[:-1]
-        ends = torch.nonzero(last).flatten()
-        tot = cs[:, ends]
-        seg = tot.clone()
-        seg[:, 1:] -= tot[:, :-1]
-        dx[sidx[ends]] = seg.t().to(dy.dtype)      # distinct rows: a plain store
-        return dx, None
-
-
-def gather_rows(x, idx):
-    if os.environ.get("INSMOS_GATHER_TORCH", "0") == "1":   # A/B switch: torch's own index backward
-        return x[idx]
-    return GatherRowsFunction.apply(x, idx)
-
-
 def _pad_cols(x, c):
     """Rows padded to the channel widths the conv kernel accepts (4, 8, multiple of 16); zero columns are neutral."""
     if x.shape[1] == c and x.stride(1) == 1 and x.stride(0) % 4 == 0:

@@ -275,7 +275,11 @@ __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? (TH == 4 ? 6 : 4) : (TH 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rh = wave & 1, ch = wave >> 1;
     const int g = lane >> 4, j = lane & 15;
-    const int img = (int)blockIdx.x / n_chunk, c = (int)blockIdx.x % n_chunk;
+    // chunk-major over the images: the computing workgroups (low chunk numbers) of ALL images are dispatched before the constant
+    // fills (the lists' tails), so the launch ends on light workgroups; the image a workgroup takes rotates with the chunk number,
+    // so that an XCD (workgroup b -> XCD b % 8) sees every image of a set of 8 instead of one
+    const int c = (int)blockIdx.x / n_img;
+    const int img = ((int)blockIdx.x + c) % n_img;
     const int U = YM ? H : W, V = YM ? W : H;
     const int tile0 = (int)blockIdx.y * NCG * COT;
     const int32_t* __restrict__ L = lists + (size_t)img * G;
