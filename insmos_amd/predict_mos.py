@@ -151,12 +151,30 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
     mine = [jobs[idx] for idx in shard_indices(len(jobs), rank, world)]
     # batch items per forward(): the launch sets the model keeps in flight (windows_in_flight sets of windows_per_launch)
     group = max(1, int(getattr(model.model, "windows_in_flight", 1)) * int(getattr(model.model, "windows_per_launch", 1)))
-    for g0 in range(0, len(mine), group):
+    groups = [mine[g0:g0 + group] for g0 in range(0, len(mine), group)]
+    dev = torch.device(device)
+    # The NEXT group's windows are put together (scan cache, pose chain, ten stacking launches per window: ~0.3 ms of host time
+    # each) by one helper thread on its own stream WHILE the current group is in forward(): the main thread's forward() calls
+    # follow each other with only the output-stage launches in between (profiles/r04_driver_bench.txt: window() was 0.14 s of a
+    # 0.92 s run).  Every reader access happens on that thread; the main stream waits for the group's event, the host does not.
+    prep_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+
+    def prepare(gi):
+        if prep_stream is None:
+            return _prepare(gi)
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(prep_stream):
+            batch, metas = _prepare(gi)
+            ev = torch.cuda.Event()
+            ev.record(prep_stream)
+        return batch, metas, ev
+
+    def _prepare(gi):
         batch, metas = [], []
-        for n_past, j in mine[g0 + group:g0 + 2 * group]:  # read-ahead for the next group while this one computes
+        for n_past, j in (groups[gi + 1] if gi + 1 < len(groups) else []):  # read-ahead for the group after this one
             if n_past in readers:
                 readers[n_past].prefetch([j])
-        for n_past, j in mine[g0:g0 + group]:
+        for n_past, j in groups[gi]:
             if n_past not in readers:
                 c2 = copy.deepcopy(cfg)
                 c2["MODEL"]["DELTA_T_PREDICTION"] = 0.1  # predict_mos.py:311
@@ -167,14 +185,28 @@ def predict_sequence(model, cfg, seq_dir, seq, out_root, rank=0, world=1, device
             pts, meta = rd.window(j)
             batch.append({"past_point_clouds": pts, "meta": meta, "batch_size_npast": n_past})
             metas.append(meta)
-        if not batch:
-            continue
-        pred_list, _, logits_list = model.forward(batch, "test")
-        for meta, preds, logits in zip(metas, pred_list, logits_list):
-            labels, conf = output_stage(logits, ignore_index, sem["learning_map_inv"])
-            stem = str(meta[2][-1])[-10:-4]
-            writer.submit(out_root, exp_id, seq, stem, labels, conf, preds[0])
-            done += 1
+        return (batch, metas) if prep_stream is not None else (batch, metas, None)
+
+    prep_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="insmos-window-prep")
+    try:
+        fut = prep_pool.submit(prepare, 0) if groups else None
+        for gi in range(len(groups)):
+            batch, metas, ev = fut.result()
+            if gi + 1 < len(groups):
+                fut = prep_pool.submit(prepare, gi + 1)
+            if not batch:
+                continue
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
+            pred_list, _, logits_list = model.forward(batch, "test")
+            for meta, preds, logits in zip(metas, pred_list, logits_list):
+                labels, conf = output_stage(logits, ignore_index, sem["learning_map_inv"])
+                stem = str(meta[2][-1])[-10:-4]
+                writer.submit(out_root, exp_id, seq, stem, labels, conf, preds[0])
+                done += 1
+            del batch   # (the group's windows go back to the helper stream's pool: forward() has completed on the device)
+    finally:
+        prep_pool.shutdown(wait=True)
     writer.close()
     return done
 
