@@ -405,6 +405,20 @@ int insmos_bev_constant(const float* wpacked, const float* bias, int cin, int co
  * insmos_sparse_conv(deconv, relu) followed by insmos_sparse_conv(head). */
 int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd, int cup,
                        const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head, void* stream);
+/* ... with the constant-region skipping of the 3x3 stack carried one step further (round 4): behind n_stack skipping-capable 3x3
+ * layers (base_bev_backbone.py:33-61) a site further than n_stack from every occupied site (dist, insmos_bev_distance_map with cap >=
+ * n_stack) and further than n_stack - 2 from the image border carries the stack's constant, so its deblock + head result is ONE
+ * vector per sub-site: chead (4 x 16 floats, insmos_deconv_head_constant of the stack's last constant).  16-site groups of such
+ * sites store it instead of computing.  x = B images of H x W sites.  Output bits are insmos_deconv_head's (tests/test_gpu_conv.py). */
+int insmos_deconv_head_skip(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd, int cup,
+                            const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head, const uint8_t* dist,
+                            int H, int W, int n_stack, const float* chead, void* stream);
+size_t insmos_deconv_head_constant_ws_floats(int cin);
+int insmos_deconv_head_constant(const float* wd_packed, const float* bd, int cin, int cup, const float* wh_packed, const float* bh,
+                                int head_cout, const float* c_in, float* chead, float* ws, void* stream);
+/* Accounting (bench.py's executed-flop count): the sites insmos_deconv_head_skip computes; *sites_dev = 8 bytes of device memory. */
+int insmos_deconv_head_skip_active_sites(const uint8_t* dist, int64_t n_site, int H, int W, int n_stack, unsigned long long* sites_dev,
+                                         void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Reduced-precision convolution modes -- opt-in, process-wide, NEVER the default.  The inference path of this library is
  * exact fp32 (v_mfma_f32_16x16x4_f32) and every parity claim and benchmark line is made in mode 0.

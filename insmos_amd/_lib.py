@@ -102,6 +102,11 @@ SIGNATURES = {
     "insmos_bev_constant_ws_floats": (c_sz, [c_int, c_int]),
     "insmos_bev_constant": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "insmos_deconv_head": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
+    "insmos_deconv_head_skip": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int,
+                                        c_int, c_vp, c_vp]),
+    "insmos_deconv_head_constant_ws_floats": (c_sz, [c_int]),
+    "insmos_deconv_head_constant": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_deconv_head_skip_active_sites": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
     "insmos_debug_conv_rowlane": (c_int, [c_int, c_int]),

@@ -264,7 +264,7 @@ template <int TH, int COT, int NCG, bool YM>
 __global__ void __launch_bounds__(128 * NCG, NCG == 4 ? (TH == 4 ? 6 : 4) : (TH == 4 ? 3 : 2)) k_bev_conv3x3_list(
     const float* __restrict__ x, int H, int W, int n_img, int ld_x, int n16, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int ld_out, int relu, const int32_t* __restrict__ lists, const int32_t* __restrict__ n_act, int G,
-    int n_chunk, int n_tu, const float* __restrict__ cvec, int ntile) {
+    int n_tu, const float* __restrict__ cvec, int ntile) {
     constexpr int JT = TH / 2;                          // row groups per wave
     constexpr int GS = 3 * BEV_HW;                      // halo sites of one group
     constexpr int NSITE = TH * GS;
@@ -668,7 +668,7 @@ extern "C" int insmos_bev_conv3x3_skip_ws(const float* x, int B, int H, int W, i
     INSMOS_LAUNCH(k_bev_group_lists, dim3(B), dim3(1024), 0, s, dist, H, W, ym, layer + 1, layer - 1, n_tu, G, lists, n_act);
 #define BEV_LIST_GO_(TH_, NCG_, YM_)                                                                                                   \
     INSMOS_LAUNCH((k_bev_conv3x3_list<TH_, 2, NCG_, YM_>), dim3(grid, cosplit), dim3(128 * NCG_), 0, s, x, H, W, B, ld_x, n16, wpacked, bias, \
-                  out, ld_out, relu, lists, n_act, G, n_chunk, n_tu, cvec, ntile_all)
+                  out, ld_out, relu, lists, n_act, G, n_tu, cvec, ntile_all)
 #define BEV_LIST_GO(NCG_, YM_) do { if (TH == 6) BEV_LIST_GO_(6, NCG_, YM_); else BEV_LIST_GO_(4, NCG_, YM_); } while (0)
     if (cout == 128 && cosplit == 1) { if (ym) BEV_LIST_GO(4, true); else BEV_LIST_GO(4, false); }
     else                             { if (ym) BEV_LIST_GO(2, true); else BEV_LIST_GO(2, false); }

@@ -37,36 +37,49 @@ struct Ctx {
     // computed with the product kernel on the first forward of the context
     mutable std::mutex bev_mu;
     mutable float* bev_const = nullptr;
+    mutable bool bev_chead = false;   // the 64 floats behind the layer constants hold the deblock + head constant (insmos_deconv_head_constant)
     ~Ctx() {
         if (bev_const) (void)hipFree(bev_const);
     }
 };
 
 // c_0 = relu(bias_0), c_l = layer l applied to a neighbourhood that is c_{l-1} everywhere (insmos_bev_constant)
-int ensure_bev_constants(const Ctx& C, hipStream_t s, const float** out) {
+// *chead (optional): the fused deblock + heads applied to the last constant (4 x 16 floats), null when that layer pair is not the
+// fused kernel's shape
+int ensure_bev_constants(const Ctx& C, hipStream_t s, const float** out, const float** chead = nullptr) {
     std::lock_guard<std::mutex> lk(C.bev_mu);
     if (!C.bev_const) {
         const int L = C.cfg.n_bev_layers + 1;
         float* cv = nullptr;
         float* ws = nullptr;
-        HIP_TRY(hipMalloc(&cv, (size_t)L * 128 * sizeof(float)));
+        HIP_TRY(hipMalloc(&cv, ((size_t)L * 128 + 64) * sizeof(float)));
         size_t wsf = 0;
         for (int l = 0; l < L; ++l) {
             const InsmosConvW& w = C.L.at("bev" + std::to_string(l));
             wsf = std::max(wsf, insmos_bev_constant_ws_floats(w.cin, w.cout));
         }
+        const auto wd = C.L.find("deconv"), wh = C.L.find("head");
+        const InsmosConvW& wl = C.L.at("bev" + std::to_string(L - 1));
+        const bool fused = wd != C.L.end() && wh != C.L.end() && C.cfg.up_ch == 256 && wl.cout % 16 == 0 && wl.cout <= 128 &&
+                           C.cfg.head_ld <= 16 && wd->second.cin == wl.cout;
+        if (fused) wsf = std::max(wsf, insmos_deconv_head_constant_ws_floats(wl.cout));
         if (hipMalloc(&ws, wsf * sizeof(float)) != hipSuccess) { (void)hipFree(cv); return INSMOS_EHIP; }
         int rc = INSMOS_OK;
         for (int l = 0; l < L && rc == INSMOS_OK; ++l) {
             const InsmosConvW& w = C.L.at("bev" + std::to_string(l));
             rc = insmos_bev_constant(w.w, w.b, w.cin, w.cout, 1, l ? cv + (size_t)(l - 1) * 128 : nullptr, cv + (size_t)l * 128, ws, s);
         }
+        if (rc == INSMOS_OK && fused)
+            rc = insmos_deconv_head_constant(wd->second.w, wd->second.b, wl.cout, C.cfg.up_ch, wh->second.w, wh->second.b, C.cfg.head_ld,
+                                             cv + (size_t)(L - 1) * 128, cv + (size_t)L * 128, ws, s);
         if (rc == INSMOS_OK && hipStreamSynchronize(s) != hipSuccess) rc = INSMOS_EHIP;
         (void)hipFree(ws);
         if (rc != INSMOS_OK) { (void)hipFree(cv); return rc; }
+        C.bev_chead = fused;
         C.bev_const = cv;
     }
     *out = C.bev_const;
+    if (chead) *chead = C.bev_chead ? C.bev_const + (size_t)(C.cfg.n_bev_layers + 1) * 128 : nullptr;
     return INSMOS_OK;
 }
 
@@ -829,6 +842,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     static const bool bev_skip = [] { const char* e = getenv("INSMOS_BEV_SKIP"); return !(e && e[0] == '0'); }();
     const uint8_t* bev_dist = nullptr;
     const float* bev_cv = nullptr;
+    const float* bev_chead = nullptr;
     void* bev_list_ws = nullptr;
     size_t bev_list_wsb = 0;
     // INSMOS_BEV_SKIP_LIST: 1 = the skipping layers walk compacted row-group lists (k_bev_conv3x3_list), 0 = fixed 16 x 4 patches
@@ -841,7 +855,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
             all_ok = all_ok && w && w->K == 9 && w->cin % 16 == 0 && (w->cout == 64 || w->cout == 128);
         }
         if (all_ok) {
-            CK(ensure_bev_constants(C, s, &bev_cv));
+            CK(ensure_bev_constants(C, s, &bev_cv, &bev_chead));
             uint8_t* d = A.take<uint8_t>((size_t)nsite);
             const size_t wsb = insmos_bev_distance_map_ws_bytes(B, g.bevH, g.bevW);
             void* ws = A.take<char>(wsb);
@@ -886,7 +900,15 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         if (!wd || !wh) return INSMOS_EINVAL;
         if (upc == 256 && nf % 16 == 0 && g.head_ld <= 16) {
             // the 2x2 deconv output is read by the heads only: fused, it stays in the MFMA accumulators
-            CK(insmos_deconv_head(fa, nsite, nf, nf, wd->w, wd->b, upc, wh->w, wh->b, g.head_ld, head, g.head_ld, s));
+            // (behind a stack that ran with constant-region skipping the constant sites' result is one vector per sub-site:
+            //  INSMOS_DECONV_SKIP=0 computes every site; same bits)
+            static const bool dskip = [] { const char* e = getenv("INSMOS_DECONV_SKIP"); return !(e && e[0] == '0'); }();
+            static const int skip_layers = [] { const char* e = getenv("INSMOS_BEV_SKIP_LAYERS"); return e ? atoi(e) : 99; }();
+            if (dskip && bev_dist && bev_chead && skip_layers > g.n_bev_layers)
+                CK(insmos_deconv_head_skip(fa, nsite, nf, nf, wd->w, wd->b, upc, wh->w, wh->b, g.head_ld, head, g.head_ld, bev_dist, g.bevH,
+                                           g.bevW, g.n_bev_layers + 1, bev_chead, s));
+            else
+                CK(insmos_deconv_head(fa, nsite, nf, nf, wd->w, wd->b, upc, wh->w, wh->b, g.head_ld, head, g.head_ld, s));
         } else {
             CK(conv("deconv", fa, nsite, nf, 0, nullptr, nsite, upf, 4 * upc, 0, nullptr, 0, 0, 0, 0, 1));
             CK(conv("head", upf, ncell, upc, 0, nullptr, ncell, head, g.head_ld, 0, nullptr, 0, 0, 0, 0, 0));  // upf as (4*nsite, upc)

@@ -604,15 +604,45 @@ __global__ void __launch_bounds__(64) k_sparse_conv_q(ConvP P) {
 // accumulators, applies bias + ReLU, and -- because lane (g, j) of a D fragment holds channels 4g..4g+3 of row j, exactly
 // the B-fragment layout of a contraction over those channels -- feeds them straight into the head's MFMAs.
 // Same operation order as the two separate launches (chunks ascending, 4 steps each): identical bits.
-template <int NT>  // channel tiles of the deconv output per sub-site (CUP / 16)
+// SKIP (round 4): constant-region skipping carried past the 3x3 stack (csrc/bev.hip).  A site whose last-layer output is the
+// stack's constant c_last (dist > reach and further than breach from the image border: the predicate of k_bev_conv3x3<SKIP> for a
+// layer behind the last one) has ONE deconv + head result per sub-site, `chead` (4 x 16 floats, evaluated by this kernel on a
+// constant input: insmos_deconv_head_constant); a wave whose 16 sites are all such stores it and leaves.  Same bits.
+template <int NT, bool SKIP = false>  // NT: channel tiles of the deconv output per sub-site (CUP / 16)
 __global__ void __launch_bounds__(64) k_deconv_head(const float* __restrict__ x, uint32_t n_site, int ld_x, int n16_in,
                                                      const float* __restrict__ wd, const float* __restrict__ bd,
                                                      const float* __restrict__ wh, const float* __restrict__ bh,
-                                                     float* __restrict__ head, int ld_head, int head_cout) {
+                                                     float* __restrict__ head, int ld_head, int head_cout,
+                                                     const uint8_t* __restrict__ dist, int H, int W, int reach, int breach,
+                                                     const float* __restrict__ chead) {
     const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
     const uint32_t sub = blockIdx.x & 3u, rg = blockIdx.x >> 2;
     const uint32_t row = rg * 16u + (uint32_t)j;
     const uint32_t rowc = row < n_site ? row : n_site - 1;
+    auto store_head = [&](f32x4 o) {   // o = the lane's four head channels of its site, bias included
+        const uint32_t co0 = 4u * g;
+        if (row >= n_site || (int)co0 >= head_cout) return;
+        float* op = head + ((size_t)row * 4 + sub) * ld_head + co0;
+        if ((int)co0 + 3 < head_cout && (ld_head & 3) == 0) {
+            *(f32x4*)op = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((int)co0 + r < head_cout) op[r] = o[r];
+        }
+    };
+    if constexpr (SKIP) {
+        bool on = false;
+        if (row < n_site) {
+            const int gx = (int)(row % (uint32_t)W), gy = (int)((row / (uint32_t)W) % (uint32_t)H);
+            const int bd_ = min(min(gy, H - 1 - gy), min(gx, W - 1 - gx));
+            on = (int)dist[row] <= reach || bd_ <= breach;
+        }
+        if (__ballot(on) == 0ull) {   // (wave-uniform)
+            store_head(*(const f32x4*)(chead + sub * 16u + 4u * g));
+            return;
+        }
+    }
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)n_site * ld_x * 4), 0x00020000);
     const uint32_t ntile_d = 4u * NT;  // channel tiles of the packed deconv layer
     const __amdgpu_buffer_rsrc_t rs_wd =
@@ -648,18 +678,25 @@ __global__ void __launch_bounds__(64) k_deconv_head(const float* __restrict__ x,
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) o = MFMA(a2[s2], acc[t][s2], o);
     }
-    if (row >= n_site) return;
-    const uint32_t co0 = 4u * g;
-    if ((int)co0 >= head_cout) return;
-    o += *(const f32x4*)(bh + co0);
-    float* op = head + ((size_t)row * 4 + sub) * ld_head + co0;
-    if ((int)co0 + 3 < head_cout && (ld_head & 3) == 0) {
-        *(f32x4*)op = o;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if ((int)co0 + r < head_cout) op[r] = o[r];
+    if ((int)(4u * g) >= head_cout) return;   // (bh holds head_cout floats)
+    o += *(const f32x4*)(bh + 4u * g);
+    store_head(o);
+}
+
+// active sites of k_deconv_head<.., SKIP> (accounting, bench.py): sites of the 16-site groups that hold a non-constant site
+__global__ void k_deconv_head_active_sites(const uint8_t* __restrict__ dist, uint32_t n_site, int H, int W, int reach, int breach,
+                                           unsigned long long* __restrict__ out) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;   // (block = 256 = four waves of four 16-site groups)
+    bool on = false;
+    if (row < n_site) {
+        const int gx = (int)(row % (uint32_t)W), gy = (int)((row / (uint32_t)W) % (uint32_t)H);
+        const int bd_ = min(min(gy, H - 1 - gy), min(gx, W - 1 - gx));
+        on = (int)dist[row] <= reach || bd_ <= breach;
     }
+    const unsigned long long bal = __ballot(on);
+    const int sh = (threadIdx.x & 63) & ~15;
+    const unsigned long long counted = __ballot(((bal >> sh) & 0xFFFFull) != 0 && row < n_site);
+    if ((threadIdx.x & 63) == 0 && counted) atomicAdd(out, (unsigned long long)__popcll(counted));
 }
 
 // B images stacked along the row axis (site = (b*H + y)*W + x): a tap never leaves its image
@@ -1027,7 +1064,61 @@ extern "C" int insmos_deconv_head(const float* x, int64_t n_site, int ld_x, int 
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = 1; ps.meta[1] = cin; ps.meta[2] = 4 * cup; ps.meta[3] = n_site;
     INSMOS_LAUNCH(k_deconv_head<16>, dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed, bd,
-                  wh_packed, bh, head, ld_head, head_cout);
+                  wh_packed, bh, head, ld_head, head_cout, nullptr, 1, 1, 0, 0, nullptr);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// insmos_deconv_head behind a 3x3 stack of `n_stack` layers run on a map with distance map `dist` (insmos_bev_distance_map, cap >=
+// n_stack): 16-site groups whose sites all carry the stack's constant store `chead` (insmos_deconv_head_constant) instead of
+// computing.  x = B images of H x W sites (n_site = B * H * W).  Output bits == insmos_deconv_head's.
+extern "C" int insmos_deconv_head_skip(const float* x, int64_t n_site, int ld_x, int cin, const float* wd_packed, const float* bd,
+                                       int cup, const float* wh_packed, const float* bh, int head_cout, float* head, int ld_head,
+                                       const uint8_t* dist, int H, int W, int n_stack, const float* chead, void* stream) {
+    if (n_site <= 0) return INSMOS_OK;
+    if (!x || !wd_packed || !bd || !wh_packed || !bh || !head || cin % 16 != 0 || ld_x < cin || (ld_x & 3) || cup != 256 ||
+        head_cout <= 0 || head_cout > 16 || ld_head < head_cout || ((uintptr_t)x & 15) || n_site * (int64_t)ld_x * 4 >= (1ll << 31) ||
+        !dist || !chead || H <= 0 || W <= 0 || n_stack < 1 || n_stack > 200 || n_site % ((int64_t)H * W) != 0 || ((uintptr_t)chead & 15))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = (long)((n_site + 15) / 16);
+    ProfScope ps(KK_SPARSE_CONV, s);
+    ps.meta[0] = 1; ps.meta[1] = cin; ps.meta[2] = 4 * cup; ps.meta[3] = n_site;
+    INSMOS_LAUNCH((k_deconv_head<16, true>), dim3((unsigned)(groups * 4)), dim3(64), 0, s, x, (uint32_t)n_site, ld_x, cin / 16, wd_packed,
+                  bd, wh_packed, bh, head, ld_head, head_cout, dist, H, W, n_stack, n_stack - 2, chead);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+extern "C" size_t insmos_deconv_head_constant_ws_floats(int cin) { return (size_t)16 * (size_t)cin + (size_t)16 * 4 * 16 + 64; }
+
+// chead (4 x 16 floats: [sub-site][head channel], zero beyond head_cout) = what insmos_deconv_head produces at a site whose input
+// row is c_in (cin floats), evaluated by the kernel itself on 16 such sites (same bits).  Depends on the weights only.
+extern "C" int insmos_deconv_head_constant(const float* wd_packed, const float* bd, int cin, int cup, const float* wh_packed,
+                                           const float* bh, int head_cout, const float* c_in, float* chead, float* ws, void* stream) {
+    if (!wd_packed || !bd || !wh_packed || !bh || !c_in || !chead || !ws || cin <= 0 || cin % 16 != 0 || cup != 256 || head_cout <= 0 ||
+        head_cout > 16 || ((uintptr_t)ws & 15))
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* img = ws;                                            // (16, cin)
+    float* res = ws + (((size_t)16 * cin + 63) & ~(size_t)63);  // (16 sites x 4 sub-sites, 16)
+    for (int i = 0; i < 16; ++i)
+        HIP_TRY(hipMemcpyAsync(img + (size_t)i * cin, c_in, (size_t)cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(res, 0, (size_t)16 * 4 * 16 * sizeof(float), s));
+    int rc = insmos_deconv_head(img, 16, cin, cin, wd_packed, bd, cup, wh_packed, bh, head_cout, res, 16, stream);
+    if (rc != INSMOS_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(chead, res, (size_t)4 * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));   // site 0: rows 0..3
+    return INSMOS_OK;
+}
+
+// Accounting (bench.py): sites insmos_deconv_head_skip computes (16-site groups with a non-constant site); *sites_dev: 8 bytes.
+extern "C" int insmos_deconv_head_skip_active_sites(const uint8_t* dist, int64_t n_site, int H, int W, int n_stack,
+                                                    unsigned long long* sites_dev, void* stream) {
+    if (!dist || !sites_dev || n_site <= 0 || n_site >= (1ll << 31) || H <= 0 || W <= 0 || n_stack < 1) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(sites_dev, 0, sizeof(unsigned long long), s));
+    INSMOS_LAUNCH(k_deconv_head_active_sites, dim3((unsigned)((n_site + 255) / 256)), dim3(256), 0, s, dist, (uint32_t)n_site, H, W, n_stack,
+                  n_stack - 2, sites_dev);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -738,6 +738,15 @@ class Engine:
             self._conv_log.append((None, nsite, L["deconv"], 0))
             self._conv_log.append((None, ncell, L["head"], 0))
             self._conv_nin += [nsite, 0]  # fused: the deconv output feeds the heads from the accumulators
+            if (self._bev_dist is not None and os.environ.get("INSMOS_DECONV_SKIP", "1") != "0"
+                    and int(os.environ.get("INSMOS_BEV_SKIP_LAYERS", "99")) > self.n_bev_layers):
+                # accounting only (bench.py): the sites the native runner's insmos_deconv_head_skip computes behind the skipping stack
+                cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+                _lib.check(lib.insmos_deconv_head_skip_active_sites(self._bev_dist.data_ptr(), nsite, self.bevH, self.bevW,
+                                                                    self.n_bev_layers + 1, cnt.data_ptr(), st),
+                           "insmos_deconv_head_skip_active_sites")
+                self._bev_exec_pairs["deconv"] = int(cnt.item())
+                self._bev_exec_pairs["head"] = 4 * int(cnt.item())
         else:
             upf = E((nsite, 4 * upc))
             self.conv(L["deconv"], fa, nf, None, nsite, upf, 4 * upc, relu_post=1)
@@ -1066,7 +1075,7 @@ class Engine:
                     cache[key] = int((tab[:, row0:] >= 0).sum().item())
                 pairs = cache[key]
             cin = layer.flops_per_pair // (2 * layer.cout_real)
-            if nbr is self.nbr_bev and layer.name in getattr(self, "_bev_exec_pairs", {}):
+            if (nbr is self.nbr_bev or nbr is None) and layer.name in getattr(self, "_bev_exec_pairs", {}):
                 pairs = self._bev_exec_pairs[layer.name]   # executed by the runner's constant-region skipping (bev_skip_accounting)
             flops += pairs * layer.flops_per_pair
             gather += 4 * pairs * (cin + layer.cout_real) + 8 * pairs

@@ -669,3 +669,36 @@ def test_bev_constant_region_skipping_is_bitwise_the_dense_kernel(B, H, W, c0):
             rows = oa.reshape(B, H, W, 128)[torch.from_numpy(far).cuda()]
             assert torch.equal(rows, consts[l].expand_as(rows)), l
         xa, xb = oa, ob
+    # ---- behind the stack: the fused deblock + heads with the constant sites skipped (insmos_deconv_head_skip) == insmos_deconv_head
+    cup, hc = 256, 12
+    wd = (rng.normal(size=(1, 128, 4 * cup)) / np.sqrt(128)).astype(np.float32)
+    wh = (rng.normal(size=(1, cup, hc)) / np.sqrt(cup)).astype(np.float32)
+    ldl = pack_layer(wd, rng.normal(size=4 * cup).astype(np.float32), 128, 4 * cup)
+    lhl = pack_layer(wh, rng.normal(size=hc).astype(np.float32), cup, hc)
+    n_site = B * H * W
+    chead = torch.full((64,), 7.0, device="cuda:0")
+    wsc = torch.empty(int(L.insmos_deconv_head_constant_ws_floats(128)), device="cuda:0")
+    _lib.check(L.insmos_deconv_head_constant(ldl.w.data_ptr(), ldl.b.data_ptr(), 128, cup, lhl.w.data_ptr(), lhl.b.data_ptr(), hc,
+                                             consts[2].data_ptr(), chead.data_ptr(), wsc.data_ptr(), st), "insmos_deconv_head_constant")
+    ha = torch.full((4 * n_site, 16), 5.0, device="cuda:0")
+    hb = torch.full((4 * n_site, 16), 5.0, device="cuda:0")
+    _lib.check(L.insmos_deconv_head(xa.data_ptr(), n_site, 128, 128, ldl.w.data_ptr(), ldl.b.data_ptr(), cup, lhl.w.data_ptr(),
+                                    lhl.b.data_ptr(), hc, ha.data_ptr(), 16, st), "insmos_deconv_head")
+    _lib.check(L.insmos_deconv_head_skip(xa.data_ptr(), n_site, 128, 128, ldl.w.data_ptr(), ldl.b.data_ptr(), cup, lhl.w.data_ptr(),
+                                         lhl.b.data_ptr(), hc, hb.data_ptr(), 16, dist.data_ptr(), H, W, 3, chead.data_ptr(), st),
+               "insmos_deconv_head_skip")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    _lib.check(L.insmos_deconv_head_skip_active_sites(dist.data_ptr(), n_site, H, W, 3, cnt.data_ptr(), st), "insmos_deconv_head_skip_active_sites")
+    torch.cuda.synchronize()
+    assert torch.equal(ha, hb), float((ha - hb).abs().max())
+    # the count: sites of the 16-site (linear) groups that hold a site within 3 of a voxel or within 1 of the border
+    bd = np.minimum(np.minimum(np.arange(H)[:, None], H - 1 - np.arange(H)[:, None]), np.minimum(np.arange(W)[None, :], W - 1 - np.arange(W)[None, :]))
+    on = ((want <= 3) | (bd[None] <= 1)).reshape(-1)
+    pad = (-len(on)) % 16
+    grp = np.concatenate([on, np.zeros(pad, bool)]).reshape(-1, 16).any(1)
+    valid = np.concatenate([np.ones(len(on), bool), np.zeros(pad, bool)]).reshape(-1, 16)
+    assert int(cnt.item()) == int((valid & grp[:, None]).sum())
+    if not grp.all():   # (a skipped group really holds the constant head rows)
+        g0 = int(np.nonzero(~grp)[0][0])
+        rows = hb[4 * 16 * g0:4 * 16 * (g0 + 1), :hc].reshape(16, 4, hc)
+        assert torch.equal(rows, chead.reshape(4, 16)[:, :hc].expand(16, 4, hc))

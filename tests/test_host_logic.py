@@ -602,3 +602,16 @@ def test_thread_local_precision_override_is_validated_and_per_trainer_context():
     with pytest.raises(ValueError):
         with autograd.train_conv_precision(3):
             pass
+
+
+def test_forward_host_marks_entry_point_without_a_forward():
+    """insmos_forward_host_marks (include/insmos_hip.h): the calling thread's last forward as "stage:us;..." text -- empty when no
+    forward ran on this thread (or INSMOS_HOST_MARKS is off), INSMOS_EINVAL for a missing buffer; needs no GPU."""
+    import ctypes
+    from insmos_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    assert lib.insmos_forward_host_marks(buf, 256) == 0 and buf.value == b""
+    assert lib.insmos_forward_host_marks(None, 256) == -1 and lib.insmos_forward_host_marks(buf, 0) == -1
+    assert lib.insmos_bev_cosplit(-2) == -1 and lib.insmos_bev_cosplit(0) == 0 and lib.insmos_bev_cosplit(-1) == 0
+    assert lib.insmos_bev_skip_ws_bytes(8, 125, 150) >= 8 * 150 * 10 * 4 and lib.insmos_bev_skip_ws_bytes(0, 125, 150) == 0
