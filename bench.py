@@ -661,8 +661,8 @@ def main():
             "algorithmic_gflop_per_window": round(flops_w / 1e9, 3),
             "reference_gflop_per_window": round(flops_ref_w / 1e9, 3),
             "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed): MotionNet rows nothing "
-                         "consumes are skipped (DESIGN.md 3.3) and so are the BEV row groups that hold only the layer's constant "
-                         "(DESIGN.md 3.9); the reference computes reference_gflop_per_window",
+                         "consumes are skipped (DESIGN.md 3.3) and so are the BEV site groups -- 3x3 stack and fused deblock + heads -- "
+                         "that hold only the layer's constant (DESIGN.md 3.10); the reference computes reference_gflop_per_window",
             "method": f"one launch set of {wpl} windows at a time on one stream: achieved = algorithmic FLOP of the conv "
                       "launches / sum of their HIP-event durations (= rocprofv3 kernel stats of INSMOS_WINDOWS_IN_FLIGHT=1 "
                       "bench.py --timed-only, tools/roofline_from_rocprof.py)",
