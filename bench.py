@@ -133,16 +133,17 @@ def pin_host_threads(local_rank, local_world):
     return len(mine)
 
 
-def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync):
+def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync, force_collectives=False):
     """The timed region of the contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync
     on both sides, the per-rank confusion counters gathered inside the region (the path's only exchange), time = MAX over
     ranks.  Device-agnostic (tests run it on CPU over gloo with a stub model): `sync` is torch.cuda.synchronize or a no-op."""
     import torch.distributed as dist
     from insmos_amd.metrics import all_gather_confusion
-    for _ in range(warmup):
+    grouped = world > 1 or (force_collectives and dist.is_initialized())   # force: the one-rank RCCL self-check runs every
+    for _ in range(warmup):                                                # collective of the N-rank region (barrier, gather, MAX)
         forward(batch, "test")
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     cm = torch.zeros((3, 3), dtype=torch.int64, device=dev)
     t0 = time.perf_counter()
@@ -150,17 +151,109 @@ def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync):
         _, _, logits = forward(batch, "test")
         for lg, gt in zip(logits, gts):
             metrics.compute_confusion_matrix(lg, gt, out=cm)
-    cm_all = all_gather_confusion(cm)
+    cm_all = all_gather_confusion(cm, force=force_collectives)
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * steps * len(batch) / dt   # every rank runs the same number of windows per step (weak scaling)
     return dt, value, cm_all
+
+
+def rccl_world1_selfcheck(forward, batch, gts, metrics, dev, steps=2):
+    """The RCCL code of the N-rank job executed on the ONE GPU a bench box has: a process group of one rank over the `nccl`
+    backend (= RCCL on ROCm), the timed region with every collective forced (barrier, all_gather of the confusion counters on
+    the device tensor, MAX all-reduce of the time) and one 8 MB bucket through an async all-reduce, as insmos_amd/ddp.py sends
+    it.  A sum / gather over one rank is the identity, so both results are checked bit for bit.  Never raises: the line reports
+    ok / error (scripts/predict_mos.py:100-106, models/metrics.py:16-45 are what the exchange serves)."""
+    import datetime
+    import torch.distributed as dist
+    res = {"ok": False, "backend": None}
+    own = False
+    try:
+        if not dist.is_initialized():
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(free_port())
+            dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120),
+                                    device_id=torch.device(dev))
+            own = True
+        res["backend"] = dist.get_backend()
+        res["world_size"] = dist.get_world_size()
+        try:
+            res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        dt, value, cm_all = timed_steps(forward, batch, gts, metrics, steps, 1, 1, dev, torch.cuda.synchronize,
+                                        force_collectives=True)
+        exp = torch.zeros((3, 3), dtype=torch.int64, device=dev)
+        _, _, logits = forward(batch, "test")
+        for lg, gt in zip(logits, gts):
+            metrics.compute_confusion_matrix(lg, gt, out=exp)
+        res["all_gather_equals_local_counters"] = bool(cm_all.is_cuda and torch.equal(cm_all, exp * steps))
+        flat = torch.randn(2 << 20, dtype=torch.float32, device=dev)
+        want = flat.clone()
+        t1 = time.perf_counter()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True).wait()
+        torch.cuda.synchronize()
+        res["bucket_8mb_all_reduce_ms"] = round(1000.0 * (time.perf_counter() - t1), 3)
+        res["all_reduce_equals_input"] = bool(torch.equal(flat, want))
+        res["windows_per_s_inside_the_group"] = round(value, 2)
+        res["ok"] = bool(res["backend"] == "nccl" and res["all_gather_equals_local_counters"] and res["all_reduce_equals_input"])
+    except Exception as e:   # reported, not fatal: the headline above does not depend on it
+        res["error"] = repr(e)[:400]
+    finally:
+        if own:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    return res
+
+
+def run_extras(dev_index):
+    """BASELINE.json configs[3] and configs[4] inside the DEFAULT line, so that the driver's one `bench.py --gpus 1` run carries
+    numbers for them that the driver itself timed: each leg is this script run as its own process (own HIP context, own
+    environment defaults) with its own bracketed timed region, after the headline -- nothing of it is inside `value`.
+      cfg4: 4 steps of 4 windows of the dense stress scene (launch sets of 2), parity of one quarter-size window against the oracle;
+      cfg5: 4 training steps of B = 4 windows in fp32 (the reference's precision), and the bf16-operand opt-in as a second number."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extras", "--sustain-seconds", "0", "--device-index", str(dev_index)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+    def leg(argv, timeout):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(base + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{"metric"')]
+            if r.returncode != 0 or len(lines) != 1:
+                return None, {"error": "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])}
+            return json.loads(lines[0]), {"leg_wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            return None, {"error": repr(e)[:300]}
+
+    out = {}
+    j, meta = leg(["--config", "cfg4", "--steps", "4", "--warmup", "2"], 500)
+    out["cfg4"] = meta if j is None else dict(meta, **{
+        "value": j["value"], "unit": "scans/s", "steps": j["steps"], "windows_per_step": j["config"]["windows_per_step"],
+        "ms_per_window": j["ms_per_window"], "points_per_window": j["config"]["points_per_window"],
+        "frac": j.get("roofline", {}).get("frac"), "parity_on_sample": j.get("parity_on_sample"),
+        "workload": "BASELINE.json configs[3]: 300k pts/scan, N=10, voxel 0.05 m, 1 GPU"})
+    j, meta = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline"], 400)
+    out["cfg5"] = meta if j is None else dict(meta, **{
+        "ms_per_step": j["ms_per_step"], "value": j["value"], "unit": "windows trained / s", "steps": j["steps"],
+        "windows_per_step": j["config"]["windows_per_step_per_rank"], "dtype": j["dtype"], "frac": j.get("roofline", {}).get("frac"),
+        "loss": j.get("loss"),
+        "workload": "BASELINE.json configs[4] on ONE GPU: forward (train mode) + four losses + backward + Adam, B = 4, fp32"})
+    if j is not None:
+        jb, mb = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline", "--train-bf16"], 400)
+        out["cfg5"]["bf16_operands"] = mb if jb is None else dict(mb, ms_per_step=jb["ms_per_step"], dtype=jb["dtype"], loss=jb.get("loss"),
+                                                                  note="opt-in: bf16 operands in the convolutions' forward and d/dx, "
+                                                                       "fp32 accumulate; d/dW, BatchNorm and losses fp32")
+    return out
 
 
 def free_port():
@@ -396,6 +489,11 @@ def main():
                                                                "dry run of this script on a one-GPU box)")
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; the dry run puts "
                                                                     "every rank on GPU 0)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg4 / cfg5 legs (`extras`) of the default cfg2 line")
+    ap.add_argument("--rccl-selfcheck", action="store_true",
+                    help="one GPU: run the HEADLINE's timed region inside a one-rank `nccl` (RCCL) process group with every collective "
+                         "of the N-rank region forced (config.backend then says nccl); without the flag the default line still "
+                         "carries a short `rccl_world1` leg")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch check (no GPU needed with --backend gloo): start / join the ranks, all-reduce a counter, print the "
                          "world the backend saw and exit -- what tests/test_host_logic.py runs through `bench.py --gpus 2` here")
@@ -442,11 +540,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(gpu)
-        dist.init_process_group(args.backend, rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
+        # backend nccl == RCCL on ROCm; device_id binds the communicator to this rank's GPU at init (barriers then never guess)
+        kw = {"device_id": torch.device(f"cuda:{gpu}")} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     dev = f"cuda:{gpu}"
     torch.cuda.set_device(gpu)
+    forced = bool(args.rccl_selfcheck and world == 1)
+    if forced:
+        import datetime
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device(dev))
+        print(f"[bench] --rccl-selfcheck: backend {dist.get_backend()}, world {dist.get_world_size()}, device {dev}", file=sys.stderr, flush=True)
     host_cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     import __graft_entry__
@@ -497,14 +604,13 @@ def main():
     metrics = ClassificationMetrics(3, [0])
 
     dt, value, cm_all = timed_steps(model.forward, batch, gts, metrics, args.steps, args.warmup, world, dev,
-                                    torch.cuda.synchronize)
-    iou = metrics.getIoU(cm_all).cpu().numpy()
+                                    torch.cuda.synchronize, force_collectives=forced)
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"timed_only": True, "value": round(value, 3), "steps": args.steps, "warmup": args.warmup,
                               "windows_per_step": W, "windows_per_launch": wpl, "launch_sets_in_flight": in_flight,
                               "windows_total": (args.steps + args.warmup) * W}), flush=True)
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -544,13 +650,16 @@ def main():
                    "host_cores_per_rank": host_cores, "torch_threads": torch.get_num_threads(),
                    "weights": "seeded random (He-normal, occupancy-corrected), head bias calibrated to "
                               f"~{args.candidates} candidates", "parallelism": f"dp{world} (windows sharded by rank)",
-                   "backend": (dist.get_backend() if world > 1 else None)},
+                   "backend": (dist.get_backend() if (world > 1 or forced) else None)},
         "ms_per_window": round(1000.0 * dt / (args.steps * W), 3),
         "timed_region_s": round(dt, 3),
         "sustained_scans_per_sec": round(sustained, 3) if sustained is not None else None,
-        # (random weights against synthetic labels: the number only shows that the counters of every rank went through the gather)
-        "mos_iou_moving_vs_pseudo_gt": float(iou[2]),
+        # every rank's counters went through the gather: the sum holds all ranks' current points (weights are random and the
+        # labels synthetic, so an IoU of these counters would mean nothing and is not printed)
         "confusion_points": int(cm_all.sum().item()),
+        # what `value` is measured on, so that cross-round tooling never compares unlike figures: 1 = rounds 1-3 (slots hold
+        # seeds rank*W .. rank*W+W-1, today's value_mixed_seeds), 2 = round 4 on (every slot holds S0, seed = rank: SURVEY.md 8d)
+        "workload_version": 1 if args.mixed_seeds else 2,
     }
 
     if rank == 0:
@@ -589,6 +698,13 @@ def main():
             torch.cuda.synchronize()
             out["value_mixed_seeds"] = round(nmx * W / (time.perf_counter() - t1), 3)
             del mixed
+        # ---- the RCCL path of the N-rank job, executed on this one GPU (one launch set of windows, every collective forced)
+        if world == 1 and not forced:
+            out["rccl_world1"] = rccl_world1_selfcheck(model.forward, batch[:wpl], gts[:wpl], metrics, dev)
+        elif forced:
+            out["rccl_world1"] = {"ok": True, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "note": "the headline's own timed region ran inside this group with every collective forced"}
+        out["rccl_world1_ok"] = bool(out.get("rccl_world1", {}).get("ok", False)) if world == 1 else None
         # ---- roofline of the dominant kernel (k_sparse_conv), HIP events on the launch stream, same workload, ONE launch
         # set at a time (nothing else on the GPU): plain per-launch durations -- what `rocprofv3 --kernel-trace --stats` of
         # `INSMOS_WINDOWS_IN_FLIGHT=1 bench.py --timed-only` shows (profiles/, tools/roofline_from_rocprof.py)
@@ -720,8 +836,11 @@ def main():
                                        "labels_equal": bool((lab == lab_ref).all()),
                                        "label_mismatches": int((lab != lab_ref).sum()), "points": int(len(lab)),
                                        "boxes_oracle_gpu": [int(len(ref_pred["pred_boxes"])), int(len(pr[0][0]["pred_boxes"]))]}
+        if world == 1 and not (args.no_extras or cfg4 or args.mixed_seeds or args.conv_precision or args.n_az != 1886):
+            torch.cuda.empty_cache()
+            out["extras"] = run_extras(gpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,8 +34,10 @@ class _Staged:
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None, overlap=False):
-        """params: dict name -> tensor (requires_grad) or list of tensors; the bucket layout is fixed at construction and the
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, overlap=False, force_collective=False):
+        """force_collective: issue the all-reduce even in a world of one rank (the one-GPU RCCL self-check: the sum over one
+        rank is the gradient itself, so the result is checkable bit for bit).
+        params: dict name -> tensor (requires_grad) or list of tensors; the bucket layout is fixed at construction and the
         same on every rank: sorted names / list order, or -- overlap=True -- the reverse of the dict / list order (pass the
         parameters in forward order)."""
         if overlap:
@@ -44,6 +46,8 @@ class BucketedGradReducer:
             self.items = sorted(params.items()) if isinstance(params, dict) else list(enumerate(params))
         self.group = group
         self.overlap = bool(overlap)
+        self.force_collective = bool(force_collective)
+        self.collectives_issued = 0      # all-reduces handed to the backend since construction
         self.buckets = []  # list of (flat buffer, [(tensor, offset, numel)])
         cur, off, cap = [], 0, max(1, bucket_bytes // 4)
         for _, p in self.items:
@@ -91,7 +95,8 @@ class BucketedGradReducer:
                 flat[off:off + n].zero_()
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
-        if self._world() > 1:
+        if self._world() > 1 or (self.force_collective and dist.is_initialized()):
+            self.collectives_issued += 1
             if flat.is_cuda and dist.get_backend(self.group) == "gloo":
                 # two ranks on one GPU (the dry run RCCL refuses): gloo moves host memory -- stage the bucket through it
                 host = flat.cpu()

@@ -49,12 +49,17 @@ class ClassificationMetrics:
         return tp.sum() / (tp.sum() + fp.sum() + 1e-15)
 
 
-def all_gather_confusion(cm):
+def all_gather_confusion(cm, force=False):
     """Sequence-level data parallelism: every rank evaluates its own windows; the only
     exchange is an all_gather of the per-rank confusion counters (72 B/rank over RCCL/xGMI with the
-    `nccl` backend, gloo on CPU in the tests), summed locally -> global IoU on every rank."""
+    `nccl` backend, gloo on CPU in the tests), summed locally -> global IoU on every rank.
+    A world of one rank has nothing to exchange and returns `cm` as is -- unless `force`: the one-GPU self-check
+    (`bench.py --rccl-selfcheck`, tests/test_zz_gpu_rccl_world1.py) sends the device tensor through the backend's
+    all_gather anyway, so that the RCCL branch below has executed before an 8-GPU node sees it."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return cm
+    if dist.get_world_size() == 1 and not force:
         return cm
     src = cm.contiguous()
     if src.is_cuda and dist.get_backend() == "gloo":

@@ -337,13 +337,13 @@ class InsMOSTrainer:
         self.last_pred_dicts = [o["pred_dicts"] for o in outs]
         return loss / B, train_loss_dict, gt_list, pred_list
 
-    def make_reducer(self, bucket_bytes=8 << 20, overlap=True):
+    def make_reducer(self, bucket_bytes=8 << 20, overlap=True, force_collective=False):
         from .ddp import BucketedGradReducer
         # overlap: buckets are all-reduced while backward is still producing the earlier layers' gradients (the parameter
         # dict is in forward order: MotionNet first, the 3D branch's decoder last -- the reverse is the arrival order)
         if getattr(self, "_reducer", None) is not None:
             self._reducer.close()   # one live reducer per parameter set: its backward hooks would launch stray collectives
-        self._reducer = BucketedGradReducer(self.params, bucket_bytes, overlap=overlap)
+        self._reducer = BucketedGradReducer(self.params, bucket_bytes, overlap=overlap, force_collective=force_collective)
         return self._reducer
 
     def sgd_step(self, lr):

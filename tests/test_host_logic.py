@@ -615,3 +615,47 @@ def test_forward_host_marks_entry_point_without_a_forward():
     assert lib.insmos_forward_host_marks(None, 256) == -1 and lib.insmos_forward_host_marks(buf, 0) == -1
     assert lib.insmos_bev_cosplit(-2) == -1 and lib.insmos_bev_cosplit(0) == 0 and lib.insmos_bev_cosplit(-1) == 0
     assert lib.insmos_bev_skip_ws_bytes(8, 125, 150) >= 8 * 150 * 10 * 4 and lib.insmos_bev_skip_ws_bytes(0, 125, 150) == 0
+
+
+_FORCE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[2])
+import bench
+from insmos_amd.ddp import BucketedGradReducer
+from insmos_amd.metrics import all_gather_confusion
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[1]
+dist.init_process_group("gloo", rank=0, world_size=1)
+cm = torch.arange(9, dtype=torch.int64).reshape(3, 3)
+assert all_gather_confusion(cm) is cm                      # a world of one exchanges nothing ...
+got = all_gather_confusion(cm, force=True)                 # ... unless asked to: the collective runs, the result is the input
+assert got is not cm and torch.equal(got, cm)
+params = {"a": torch.zeros(5, 3, requires_grad=True), "b": torch.zeros(7, requires_grad=True)}
+for i, v in enumerate(params.values()):
+    v.grad = torch.full_like(v, float(i + 1))
+red = BucketedGradReducer(params, bucket_bytes=32)
+assert red.reduce() == 2 and red.collectives_issued == 0   # default: no collective in a world of one
+red = BucketedGradReducer(params, bucket_bytes=32, force_collective=True)
+assert red.reduce() == 2 and red.collectives_issued == 2
+assert torch.equal(params["a"].grad, torch.full((5, 3), 1.0)) and torch.equal(params["b"].grad, torch.full((7,), 2.0))
+
+class Stub:                                                # bench.timed_steps is device-agnostic
+    def __call__(self, batch, mode):
+        return None, None, [torch.zeros(4, 3) for _ in batch]
+class M:
+    def compute_confusion_matrix(self, lg, gt, out=None):
+        out[1, 1] += lg.shape[0]
+dt, value, cm_all = bench.timed_steps(Stub(), [0, 1], [None, None], M(), 3, 1, 1, "cpu", lambda: None, force_collectives=True)
+assert int(cm_all[1, 1]) == 3 * 2 * 4 and abs(value - 3 * 2 / dt) < 1e-9
+dist.destroy_process_group()
+print("OK")
+"""
+
+
+def test_forced_collectives_in_a_world_of_one_rank(tmp_path):
+    """What tests/test_zz_gpu_rccl_world1.py runs over RCCL on the GPU box, over gloo here: `force` makes a one-rank group
+    issue the N-rank code's collectives (metrics.all_gather_confusion, ddp.BucketedGradReducer, bench.timed_steps)."""
+    script = tmp_path / "force_worker.py"
+    script.write_text(_FORCE_WORKER)
+    r = subprocess.run([sys.executable, str(script), str(29300 + os.getpid() % 150), ROOT], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=180)
+    assert r.returncode == 0 and "OK" in r.stdout.decode(), r.stdout.decode()[-2000:]

@@ -139,7 +139,13 @@ def test_bench_gpus_2_dry_run_on_one_gpu():
     assert len(lines) == 1, out[-3000:]
     j = lines[0]
     assert j["n_gpus"] == 2 and j["config"]["parallelism"].startswith("dp2") and j["config"]["backend"] == "gloo"
-    assert j["confusion_points"] == 2 * 2 * 4 * j["config"]["current_points"] or j["confusion_points"] > 2 * 4 * j["config"]["current_points"]
+    # both ranks' counters are in the sum, exactly: 2 steps x 4 slots per rank, every slot holding the rank's own window
+    # (seed = rank), each contributing its current-scan points
+    sys.path.insert(0, ROOT)
+    import bench
+    ncur = [int((bench.load_window(r_, 320)[:, 4] == 0).sum()) for r_ in range(2)]
+    assert ncur[0] == j["config"]["current_points"]
+    assert j["confusion_points"] == 2 * 4 * (ncur[0] + ncur[1]), (j["confusion_points"], ncur)
     assert abs(j["value"] - 2 * 2 * 4 / j["timed_region_s"]) / j["value"] < 2e-2
 
 
