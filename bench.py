@@ -558,7 +558,7 @@ def main():
 
     import __graft_entry__
     if rank == 0:
-        __graft_entry__.build()
+        __graft_entry__.build_product()   # the HIP library only: the product build does not touch oracle/
     if world > 1:
         dist.barrier()
     from insmos_amd import _lib, params as P

@@ -113,7 +113,6 @@ def _pad_cols(x, c):
 # bench.py --config cfg5: executed flops of the convolution kernels of a training step (forward, d/dx, d/dW: 2 * pairs * Cin * Cout
 # each, pairs = valid entries of the layer's kernel map).  None = off (the default: counting costs a device reduction per table).
 WORK_COUNTER = None
-_pairs_cache = {}
 
 
 def _count_work(kind, nbr, n_rows, cin, cout):
@@ -122,10 +121,15 @@ def _count_work(kind, nbr, n_rows, cin, cout):
     if nbr is None:
         pairs = int(n_rows)
     else:
-        key = (nbr.data_ptr(), tuple(nbr.shape))
-        if key not in _pairs_cache:
-            _pairs_cache[key] = int((nbr >= 0).sum().item())
-        pairs = _pairs_cache[key]
+        # cached ON the table object (an address + shape key would be handed to another table by the caching allocator on the
+        # next step and silently reuse a stale count; an attribute dies with its tensor)
+        pairs = getattr(nbr, "_insmos_valid_pairs", None)
+        if pairs is None:
+            pairs = int((nbr >= 0).sum().item())
+            try:
+                nbr._insmos_valid_pairs = pairs
+            except AttributeError:
+                pass
     WORK_COUNTER[kind] = WORK_COUNTER.get(kind, 0) + 2 * pairs * cin * cout
     WORK_COUNTER["launches_" + kind] = WORK_COUNTER.get("launches_" + kind, 0) + 1
 

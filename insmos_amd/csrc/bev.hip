@@ -627,7 +627,7 @@ extern "C" int insmos_bev_conv3x3(const float* x, int B, int H, int W, int ld_x,
 extern "C" int insmos_bev_conv3x3_skip(const float* x, int B, int H, int W, int ld_x, int cin, const float* wpacked, const float* bias,
                                        float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
                                        void* stream) {
-    if (!dist || !cvec || layer < 0 || layer > 200) return INSMOS_EINVAL;
+    if (!dist || !cvec || ((uintptr_t)cvec & 15) || layer < 0 || layer > 200) return INSMOS_EINVAL;   // cvec is loaded as float4
     return bev_conv3x3_impl(x, B, H, W, ld_x, cin, wpacked, bias, out, ld_out, cout, relu, dist, layer + 1, layer - 1, cvec, stream);
 }
 
@@ -644,7 +644,7 @@ extern "C" int insmos_bev_conv3x3_skip_ws(const float* x, int B, int H, int W, i
                                           float* out, int ld_out, int cout, int relu, const uint8_t* dist, int layer, const float* cvec,
                                           void* ws, size_t ws_bytes, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return INSMOS_OK;
-    if (!x || !wpacked || !bias || !out || !dist || !cvec || !ws || layer < 0 || layer > 200 || cin <= 0 || cin % 16 != 0 || ld_x < cin ||
+    if (!x || !wpacked || !bias || !out || !dist || !cvec || ((uintptr_t)cvec & 15) || !ws || layer < 0 || layer > 200 || cin <= 0 || cin % 16 != 0 || ld_x < cin ||
         (ld_x & 3) || (cout != 128 && cout != 64) || ld_out < cout || (ld_out & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
         (int64_t)B * H * W * ld_x * 4 >= (1ll << 31))
         return INSMOS_EINVAL;

@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include "common.h"
+#include "prec.h"
 
 namespace {
 using namespace insmos;
@@ -65,6 +66,13 @@ int ensure_bev_constants(const Ctx& C, hipStream_t s, const float** out, const f
         if (fused) wsf = std::max(wsf, insmos_deconv_head_constant_ws_floats(wl.cout));
         if (hipMalloc(&ws, wsf * sizeof(float)) != hipSuccess) { (void)hipFree(cv); return INSMOS_EHIP; }
         int rc = INSMOS_OK;
+        // the constants are cached for the context's lifetime and must be the EXACT-fp32 kernel's: pin this thread to mode 0 while
+        // they are computed (a forward under the split-bf16 experiment does not use them: run_bev_stack skips nothing in mode 3)
+        struct PrecPin {
+            int saved;
+            PrecPin() : saved(insmos::conv_precision_thread_get()) { (void)insmos_conv_precision_thread(0); }
+            ~PrecPin() { (void)insmos_conv_precision_thread(saved); }
+        } pin;
         for (int l = 0; l < L && rc == INSMOS_OK; ++l) {
             const InsmosConvW& w = C.L.at("bev" + std::to_string(l));
             rc = insmos_bev_constant(w.w, w.b, w.cin, w.cout, 1, l ? cv + (size_t)(l - 1) * 128 : nullptr, cv + (size_t)l * 128, ws, s);
@@ -212,12 +220,22 @@ struct PinnedCounts {
 };
 thread_local PinnedCounts tl_pinned;
 thread_local bool tl_spin = false;
+static const int kSpinBudgetUs = [] { const char* e = getenv("INSMOS_READBACK_SPIN_US"); return e ? std::max(0, atoi(e)) : 300; }();
 static const bool kSpinEnv = [] { const char* e = getenv("INSMOS_READBACK_SPIN"); return !(e && e[0] == '0'); }();
 
 int wait_stream(hipStream_t s) {
     if (tl_spin && kSpinEnv) {
+        // bounded: poll for ~300 us (INSMOS_READBACK_SPIN_US) (a latency-mode read-back returns within tens of us; the final wait for the box counts is the
+        // long one), then sleep in the runtime like everyone else -- a host thread per GPU must not burn a core for milliseconds
         hipError_t q;
-        while ((q = hipStreamQuery(s)) == hipErrorNotReady) {}
+        const auto t0 = std::chrono::steady_clock::now();
+        int polls = 0;
+        while ((q = hipStreamQuery(s)) == hipErrorNotReady) {
+            if ((++polls & 15) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinBudgetUs)) {
+                q = hipStreamSynchronize(s);
+                break;
+            }
+        }
         if (q != hipSuccess) { insmos::g_last_hip_error = (int)q; return INSMOS_EHIP; }
         return INSMOS_OK;
     }
@@ -848,7 +866,9 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     // INSMOS_BEV_SKIP_LIST: 1 = the skipping layers walk compacted row-group lists (k_bev_conv3x3_list), 0 = fixed 16 x 4 patches
     // (k_bev_conv3x3<SKIP>); same bits.  (Read per call: tools flip it inside one process.)
     const bool bev_list = [&] { const char* e = getenv("INSMOS_BEV_SKIP_LIST"); return e ? e[0] != '0' : B >= kBevSkipListMinB; }();
-    if (bev_kernel && bev_skip) {
+    // (under the split-bf16 experiment, mode 3, nothing is skipped: the cached constants are the exact-fp32 kernel's, and the
+    //  list / deblock skipping entry points have no reduced-precision form)
+    if (bev_kernel && bev_skip && insmos::conv_precision() != 3) {
         bool all_ok = true;
         for (int k = 0; k <= g.n_bev_layers; ++k) {
             const InsmosConvW* w = Lr("bev" + std::to_string(k));

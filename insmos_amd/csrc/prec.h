@@ -53,6 +53,7 @@ __device__ __forceinline__ pf32x4 pack_split(s16x4 hi, s16x4 lo) {
 
 // process-wide mode and the packed-fp32 -> split-weights table (spconv.hip)
 int conv_precision();
+int conv_precision_thread_get();   // this thread's override (-1 = none), for scoped pins
 const void* split_weights_of(const float* wpacked);
 
 }  // namespace insmos

@@ -874,6 +874,7 @@ int env_int(const char* name, int dflt) {
 
 namespace insmos {
 int conv_precision() { return cur_prec(); }
+int conv_precision_thread_get() { return tl_prec; }
 const void* split_weights_of(const float* wpacked) {
     std::lock_guard<std::mutex> lk(g_split_mu);
     auto it = g_split_weights.find(wpacked);

@@ -198,15 +198,22 @@ def test_batchnorm_train_vs_torch(relu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, "1024", "256"])
 @pytest.mark.parametrize("relu,S", [(False, 1), (True, 1), (True, 3), (False, 4)])
-def test_segmented_batchnorm_vs_torch_per_segment(relu, S):
-    """insmos_batchnorm_seg_*: every segment (one window of a training batch, here interleaved runs of rows like the 4D branch's
+def test_segmented_batchnorm_vs_torch_per_segment(relu, S, chunk, monkeypatch):
+    """(`chunk`: the adaptive chunk lengths of BnPlan.chunk_rows -- 2048 rows for this width -- and two pinned lengths,
+    INSMOS_BN_CHUNK, read on every call: the same float64 yardstick for every chunk table.)
+    insmos_batchnorm_seg_*: every segment (one window of a training batch, here interleaved runs of rows like the 4D branch's
     (t * B + b)-major order) is normalised with ITS OWN batch statistics, the running statistics move segment after segment, and
     the gradients are those of torch's batch_norm applied to each segment's rows on their own (float64 reference); S = 1 is the
     plain layer."""
     import torch
     import torch.nn.functional as F
     from insmos_amd.autograd import BnPlan, batch_norm_train_seg
+    if chunk is None:
+        monkeypatch.delenv("INSMOS_BN_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("INSMOS_BN_CHUNK", chunk)
     rng = np.random.default_rng(40 + S)
     c = 24
     run_len = [int(v) for v in rng.integers(1, 2600, size=7 * S)]

@@ -235,8 +235,12 @@ def test_insmos_trainer_train_mode_signature_and_descent():
     assert bool(torch.isfinite(logits[0]).all())
 
 
-def test_batched_training_step_equals_the_item_by_item_walk():
-    """cfg-5's batch dimension: B windows per training step in ONE set of launches per branch (window index folded into the 4D time
+@pytest.mark.parametrize("chunk", ["1024", None])
+def test_batched_training_step_equals_the_item_by_item_walk(chunk, monkeypatch):
+    """(`chunk` = INSMOS_BN_CHUNK: with ONE pinned chunk length the predictions of the two walks agree row for row to 1e-4 -- the
+    tight bound, which a regression in the segmented BatchNorm kernels or the chunk tables cannot pass; the adaptive lengths of
+    BnPlan.chunk_rows move one last-bit ReLU decision in window 0, see below, and get the documented loose bound.)
+    cfg-5's batch dimension: B windows per training step in ONE set of launches per branch (window index folded into the 4D time
     coordinate / spconv's batch column, per-window BatchNorm statistics, per-window losses) against the reference's walk over the
     batch list (models/models.py:313-345; here the same trainer with one window per call): the same per-item losses, the same
     predictions, the same gradient of the mean loss for every parameter (the sums run in another order: tolerance, not bits) and
@@ -245,6 +249,10 @@ def test_batched_training_step_equals_the_item_by_item_walk():
     from insmos_amd import params as P
     from insmos_amd.synth import make_labels, make_window
     from insmos_amd.train_unet import InsMOSTrainer
+    if chunk is None:
+        monkeypatch.delenv("INSMOS_BN_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("INSMOS_BN_CHUNK", chunk)
     rng = np.random.default_rng(21)
     cfg = copy.deepcopy(P.default_cfg())
     cfg["MODEL"]["USE_MOTION_LOSS"] = True
@@ -282,7 +290,10 @@ def test_batched_training_step_equals_the_item_by_item_walk():
         #  the flips few and small)
         assert a.shape == b.shape
         d = (a - b).abs().max(1).values
-        assert float(d.max()) < 2e-2 and int((d > 1e-4).sum()) <= max(1, len(d) // 200), (float(d.max()), int((d > 1e-4).sum()), len(d))
+        if chunk is not None:
+            assert float(d.max()) < 1e-4, (float(d.max()), int((d > 1e-4).sum()), len(d))
+        else:
+            assert float(d.max()) < 2e-2 and int((d > 1e-4).sum()) <= max(1, len(d) // 200), (float(d.max()), int((d > 1e-4).sum()), len(d))
     bad = []
     for k, v in tr_b.params.items():
         g, h = v.grad, tr_s.params[k].grad
