@@ -164,6 +164,25 @@ def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync, f
     return dt, value, cm_all
 
 
+def emit_result_line(out):
+    """Print the ONE JSON line as the LAST line of stdout.  RCCL writes a version banner through C stdio when a communicator is
+    created; on a pipe it sits in libc's buffer until exit and would land BEHIND the line (seen on the GPU box: `tail -1` of a run
+    with the rccl_world1 leg was "Librccl path : ..."): flush libc first, write the line, then point fd 1 at /dev/null so that
+    nothing a library flushes at teardown follows it."""
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.write(1, (json.dumps(out) + "\n").encode())
+    try:
+        dn = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(dn, 1)
+        os.close(dn)
+    except OSError:
+        pass
+
+
 def rccl_world1_selfcheck(forward, batch, gts, metrics, dev, steps=2):
     """The RCCL code of the N-rank job executed on the ONE GPU a bench box has: a process group of one rank over the `nccl`
     backend (= RCCL on ROCm), the timed region with every collective forced (barrier, all_gather of the confusion counters on
@@ -441,7 +460,7 @@ def main_cfg5(args, rank, world, gpu, dev, host_cores):
                           "backward, BatchNorm and losses not included (an upper bound of the CPU rate); CPU restatement, NOT the "
                           "reference's libraries",
                 "seconds": round(t_fwd + t_bwd, 2)}
-        print(json.dumps(out), flush=True)
+        emit_result_line(out)
     if red is not None:
         red.close()
     if world > 1:
@@ -518,6 +537,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     gpu = local_rank if args.device_index is None else args.device_index
+    if rank != 0:   # only rank 0 prints the result line; a library banner of another rank must not follow it on the shared pipe
+        try:
+            dn = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(dn, 1)
+            os.close(dn)
+        except OSError:
+            pass
     if args.rendezvous_only:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -839,7 +865,7 @@ def main():
         if world == 1 and not (args.no_extras or cfg4 or args.mixed_seeds or args.conv_precision or args.n_az != 1886):
             torch.cuda.empty_cache()
             out["extras"] = run_extras(gpu)
-        print(json.dumps(out), flush=True)
+        emit_result_line(out)
     if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()

@@ -853,6 +853,8 @@ ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
     if (ck == 0 && split == 4 && cot == 8 && by_chunk) return k_sparse_conv<8, 1, 0, false, 2, 4, true, DBG>;
     if (ck == 0 && split == 4 && cot == 4 && by_chunk) return k_sparse_conv<4, 1, 0, false, 2, 4, true, DBG>;    // C = 64 layers
     if (ck == 0 && split == 4 && cot == 2 && !by_chunk) return k_sparse_conv<2, 1, 0, false, 3, 4, false, DBG>;  // C = 32, tap split
+    if (ck == 0 && split == 4 && cot == 2 && by_chunk) return k_sparse_conv<2, 1, 0, false, 3, 4, true, DBG>;    // 64 -> 32, chunk split
+    if (ck == 0 && split == 4 && cot == 1 && !by_chunk) return k_sparse_conv<1, 1, 0, false, 3, 4, false, DBG>;  // 81 taps 32 -> 16
     return nullptr;
 }
 ConvKernel pick_forced(int cot, int jt, int ring) {
