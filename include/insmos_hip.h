@@ -310,6 +310,26 @@ int insmos_build_nbr_rank_sparse(const int32_t* out_coords, int64_t n_out, const
                                  const int32_t* in_perm, const int32_t* in_shape_host, const int32_t* delta_host, int K,
                                  const int32_t* mul_host, const int32_t* div_host, int32_t* nbr, uint32_t* mask16, void* stream);
                                  /* (sparse stores, see insmos_nbr81_from_coarse_rows_sparse; mask16 required) */
+/* Several kernel maps in ONE launch (round 5; the native runner builds the 13 maps of the 3D branch this way): every job is one
+ * insmos_build_nbr_rank call -- same entries, same masks.  All pointers of a job are device pointers except in_shape / delta / mul /
+ * div (host; mul / div may be null = ones).  <= 16 jobs, K <= 32, <= 4 distinct offset sets, |offset| <= 127; a job with
+ * n_out == 0 is skipped.  sparse_stores as insmos_build_nbr_rank_sparse (then every job needs mask16). */
+typedef struct InsmosRankJob {
+    const int32_t* out_coords;   /* (n_out, 4) [b, z, y, x] */
+    const uint64_t* bits;        /* the INPUT level's rank map */
+    const int32_t* blk_incl;
+    const int32_t* in_perm;      /* sorted position -> row of the input level, or null */
+    int32_t* nbr;                /* (K, n_out) */
+    uint32_t* mask16;            /* ((n_out + 15) / 16, 4) or null */
+    const int32_t* in_shape;     /* host, 3 */
+    const int32_t* delta;        /* host, (K, 4) */
+    const int32_t* mul;          /* host, 4, or null */
+    const int32_t* div;          /* host, 4, or null */
+    int64_t n_out;
+    int32_t K;
+    int32_t reserved;
+} InsmosRankJob;
+int insmos_build_nbr_rank_multi(const InsmosRankJob* jobs_host, int n_jobs, int sparse_stores, void* stream);
 /* Row regrouping (no reference counterpart: spconv's rulebooks are pair lists, the row order of a level is an implementation
  * detail there too -- spconv_unet.py:120-207 never looks at it).  The output-stationary kernels pay one 16-row MFMA pass per
  * (16-row group, tap) slot any row of the group uses; rows are re-ordered inside blocks of block_rows (256 / 1024 / 4096)

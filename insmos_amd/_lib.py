@@ -81,6 +81,7 @@ SIGNATURES = {
     "insmos_down_coords3d_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "insmos_build_nbr_rank": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_build_nbr_rank_sparse": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_build_nbr_rank_multi": (c_int, [c_vp, c_int, c_int, c_vp]),
     "insmos_forward_regroup": (c_int, [c_int]),
     "insmos_bev_cosplit": (c_int, [c_int]),
     "insmos_bev_skip_ws_bytes": (c_sz, [c_int, c_int, c_int]),
@@ -182,6 +183,12 @@ class NetCfg(ctypes.Structure):  # InsmosNetCfg
                 ("bevD", ctypes.c_int32), ("bevH", ctypes.c_int32), ("bevW", ctypes.c_int32), ("nbev", ctypes.c_int32),
                 ("n_bev_layers", ctypes.c_int32), ("up_ch", ctypes.c_int32), ("head_ld", ctypes.c_int32),
                 ("pre_max", ctypes.c_int32), ("post_max", ctypes.c_int32), ("quirk_exact", ctypes.c_int32)]
+
+
+class RankJob(ctypes.Structure):  # InsmosRankJob
+    _fields_ = [("out_coords", c_vp), ("bits", c_vp), ("blk_incl", c_vp), ("in_perm", c_vp), ("nbr", c_vp), ("mask16", c_vp),
+                ("in_shape", c_vp), ("delta", c_vp), ("mul", c_vp), ("div", c_vp), ("n_out", c_i64), ("K", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class ForwardOut(ctypes.Structure):  # InsmosForwardOut

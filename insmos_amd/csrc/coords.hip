@@ -889,6 +889,87 @@ __global__ void __launch_bounds__(256) k_build_nbr_rank(const int32_t* __restric
     if (mask16 && lane == 0) *(uint4*)(mask16 + grp * 4) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
 }
 
+// k_build_nbr_rank for SEVERAL tables in one launch (round 5: the 13 kernel maps of the 3D branch were 13 launches of 5-55 us, the
+// level-4 ones a few hundred blocks each): a block finds its job in a prefix table of block counts, then runs the body above --
+// same entries, same masks (tests/test_gpu_coords.py).  Tap offsets are int8 (|delta| <= 127) so that 16 jobs and 4 offset sets
+// fit the 4 KiB of kernel arguments.
+struct RankJobD {
+    const int32_t* out_coords;
+    const uint64_t* bits;
+    const int32_t* incl;
+    const int32_t* perm;
+    int32_t* nbr;
+    uint32_t* mask16;
+    int64_t n_out;
+    int shape[3], mul[4], dv[4];
+    int K, dset, blk_end, pad;
+};
+constexpr int kRankJobsMax = 16, kRankDsetsMax = 4, kRankDsetTaps = 32;
+struct RankJobs {
+    RankJobD job[kRankJobsMax];
+    int8_t delta[kRankDsetsMax][kRankDsetTaps][4];
+    int n_jobs, sparse;
+};
+__global__ void __launch_bounds__(256) k_build_nbr_rank_multi(RankJobs J) {
+    int ji = 0;
+    while (ji + 1 < J.n_jobs && (int)blockIdx.x >= J.job[ji].blk_end) ++ji;   // (block-uniform, <= 15 steps)
+    const RankJobD& Q = J.job[ji];
+    const int blk = (int)blockIdx.x - (ji ? J.job[ji - 1].blk_end : 0);
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int64_t grp = (int64_t)blk * 4 + (threadIdx.x >> 6);
+    const int64_t n_out = Q.n_out;
+    if (grp * 16 >= n_out) return;   // (wave-uniform)
+    const int64_t o = grp * 16 + j;
+    const bool row_ok = o < n_out;
+    const int4 c = *(const int4*)(Q.out_coords + (row_ok ? o : n_out - 1) * 4);
+    const int D = Q.shape[0], H = Q.shape[1], W = Q.shape[2], K = Q.K;
+    const uint64_t* __restrict__ bits = Q.bits;
+    const int32_t* __restrict__ incl = Q.incl;
+    const int32_t* __restrict__ perm = Q.perm;
+    int32_t* __restrict__ nbr = Q.nbr;
+    uint32_t mk[4] = {0u, 0u, 0u, 0u};
+    for (int kk = 0; kk < K; kk += 4) {
+        const int k = kk + g;
+        const bool k_ok = k < K;
+        const int kc = k_ok ? k : K - 1;
+        const int8_t* dl = J.delta[Q.dset][kc];
+        int q[4] = {c.x * Q.mul[0] + dl[0], c.y * Q.mul[1] + dl[1], c.z * Q.mul[2] + dl[2], c.w * Q.mul[3] + dl[3]};
+        bool ok = k_ok && row_ok;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int dv = Q.dv[d];
+            if (dv > 1) {
+                if (q[d] % dv != 0) ok = false;
+                q[d] = q[d] / dv;
+            }
+        }
+        int32_t r = -1;
+        if (ok) {
+            const uint64_t key = key3b_encode(q[0], q[1], q[2], q[3], D, H, W);
+            if (key != INSMOS_INVALID_KEY) {
+                const int64_t w = (int64_t)(key >> 6), bq = w >> 2;
+                const int jw = (int)(w & 3);
+                const ulonglong4 qq = *(const ulonglong4*)(bits + 4 * bq);
+                const uint64_t mine = jw == 0 ? qq.x : jw == 1 ? qq.y : jw == 2 ? qq.z : qq.w;
+                if ((mine >> (key & 63)) & 1ull) {
+                    int pos = bq ? incl[bq - 1] : 0;
+                    pos += (jw > 0 ? __popcll(qq.x) : 0) + (jw > 1 ? __popcll(qq.y) : 0) + (jw > 2 ? __popcll(qq.z) : 0);
+                    pos += __popcll(mine & ((1ull << (key & 63)) - 1ull));
+                    r = perm ? perm[pos] : pos;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(r >= 0);
+        if (k_ok && row_ok && (!J.sparse || ((bal >> (16 * g)) & 0xFFFFull))) nbr[(int64_t)k * n_out + o] = r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = kk + t;
+            if ((bal >> (16 * t)) & 0xFFFFull) mk[(kt >> 5) & 3] |= 1u << (kt & 31);
+        }
+    }
+    if (Q.mask16 && lane == 0) *(uint4*)(Q.mask16 + grp * 4) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-voxel tap resolver: one thread = one fine voxel.  The <= 27 coarse neighbour blocks a voxel's taps
 // can fall into are fetched ONCE (independent loads, entries cached in LDS as (child_start, child_mask)),
@@ -1788,6 +1869,60 @@ static int build_nbr_rank_impl(const int32_t* out_coords, int64_t n_out, const u
     ProfScope ps(KK_BUILD_NBR, s);
     INSMOS_LAUNCH(k_build_nbr_rank, dim3(cdiv((n_out + 15) / 16, 4)), dim3(256), 0, s, out_coords, n_out, bits, blk_incl, in_perm, P,
                   nbr, mask16, sparse_stores ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// Several kernel maps in ONE launch (k_build_nbr_rank_multi): what the native runner uses for the 13 maps of the 3D branch.
+// Jobs with n_out == 0 are skipped; <= 16 jobs, K <= 32 taps each, <= 4 distinct offset sets, |offset| <= 127.
+extern "C" int insmos_build_nbr_rank_multi(const InsmosRankJob* jobs_host, int n_jobs, int sparse_stores, void* stream) {
+    if (!jobs_host || n_jobs < 0 || n_jobs > kRankJobsMax) return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RankJobs J;
+    memset(&J, 0, sizeof(J));
+    int n_sets = 0, nj = 0;
+    long blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const InsmosRankJob& h = jobs_host[i];
+        if (h.n_out == 0) continue;
+        if (h.n_out < 0 || h.K <= 0 || h.K > kRankDsetTaps || !h.out_coords || !h.bits || !h.blk_incl || !h.in_shape || !h.delta || !h.nbr ||
+            (sparse_stores && !h.mask16))
+            return INSMOS_EINVAL;
+        int8_t d8[kRankDsetTaps][4];
+        memset(d8, 0, sizeof(d8));
+        for (int k = 0; k < h.K; ++k)
+            for (int d = 0; d < 4; ++d) {
+                const int v = h.delta[k * 4 + d];
+                if (v < -127 || v > 127) return INSMOS_EINVAL;
+                d8[k][d] = (int8_t)v;
+            }
+        int ds = -1;
+        for (int q = 0; q < n_sets && ds < 0; ++q)
+            if (memcmp(J.delta[q], d8, sizeof(d8)) == 0) ds = q;
+        if (ds < 0) {
+            if (n_sets == kRankDsetsMax) return INSMOS_EINVAL;
+            memcpy(J.delta[n_sets], d8, sizeof(d8));
+            ds = n_sets++;
+        }
+        RankJobD& Q = J.job[nj++];
+        Q.out_coords = h.out_coords; Q.bits = h.bits; Q.incl = h.blk_incl; Q.perm = h.in_perm; Q.nbr = h.nbr; Q.mask16 = h.mask16;
+        Q.n_out = h.n_out;
+        for (int d = 0; d < 3; ++d) Q.shape[d] = h.in_shape[d];
+        for (int d = 0; d < 4; ++d) {
+            Q.mul[d] = h.mul ? h.mul[d] : 1;
+            Q.dv[d] = h.div ? h.div[d] : 1;
+        }
+        Q.K = h.K;
+        Q.dset = ds;
+        blocks += (long)cdiv((h.n_out + 15) / 16, 4);
+        if (blocks >= (1l << 31)) return INSMOS_EINVAL;
+        Q.blk_end = (int)blocks;
+    }
+    if (nj == 0) return INSMOS_OK;
+    J.n_jobs = nj;
+    J.sparse = sparse_stores ? 1 : 0;
+    ProfScope ps(KK_BUILD_NBR, s);
+    INSMOS_LAUNCH(k_build_nbr_rank_multi, dim3((unsigned)blocks), dim3(256), 0, s, J);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

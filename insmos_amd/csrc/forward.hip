@@ -785,11 +785,39 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     };
     const int32_t one4[4] = {1, 1, 1, 1}, two3[4] = {1, 2, 2, 2}, two1[4] = {1, 2, 1, 1};
     Table subm[5], down[5], inv[5], down5, inv5;
-    for (int l = 1; l <= 4; ++l) CK(build(subm[l], l, l, C.d_subm, one4, one4));
-    for (int l = 2; l <= 4; ++l) CK(build(down[l], l, l - 1, C.d_subm, two3, one4));
-    for (int l = 2; l <= 4; ++l) CK(build(inv[l], l - 1, l, C.d_inv, one4, two3));
-    CK(build(down5, 5, 4, C.d_down5, two1, one4));
-    CK(build(inv5, 4, 5, C.d_inv5, one4, two1));
+    // the 13 kernel maps: ONE launch over all of them (insmos_build_nbr_rank_multi; INSMOS_TABLES3D_MULTI=0: a launch per map --
+    // same tables, tests/test_gpu_coords.py); the searched builder (INSMOS_TABLES3D_SEARCH=1) stays a launch per map
+    static const bool multi_tab = [] { const char* e = getenv("INSMOS_TABLES3D_MULTI"); return !(e && e[0] == '0'); }();
+    if (rank_tables && multi_tab) {
+        static const bool sparse_tab3 = [] {
+            const char* e = getenv("INSMOS_TABLES_DENSE");
+            const char* jt = getenv("INSMOS_CK_JT");
+            return !(e && e[0] == '1') && !(jt && atoi(jt) > 1);
+        }();
+        InsmosRankJob jobs[13];
+        int nj = 0;
+        auto add = [&](Table& t, int lvl_out, int lvl_in, const std::vector<int32_t>& delta, const int32_t* mul, const int32_t* div) {
+            const int K = (int)(delta.size() / 4);
+            t = table(K, nv[lvl_out]);
+            InsmosRankJob& j = jobs[nj++];
+            j.out_coords = co[lvl_out]; j.bits = rbits[lvl_in]; j.blk_incl = rincl[lvl_in]; j.in_perm = pm[lvl_in];
+            j.nbr = t.nbr; j.mask16 = t.mask; j.in_shape = g.shape[lvl_in]; j.delta = delta.data(); j.mul = mul; j.div = div;
+            j.n_out = nv[lvl_out]; j.K = K; j.reserved = 0;
+        };
+        for (int l = 1; l <= 4; ++l) add(subm[l], l, l, C.d_subm, one4, one4);
+        for (int l = 2; l <= 4; ++l) add(down[l], l, l - 1, C.d_subm, two3, one4);
+        for (int l = 2; l <= 4; ++l) add(inv[l], l - 1, l, C.d_inv, one4, two3);
+        add(down5, 5, 4, C.d_down5, two1, one4);
+        add(inv5, 4, 5, C.d_inv5, one4, two1);
+        NEED_ARENA();
+        CK(insmos_build_nbr_rank_multi(jobs, nj, sparse_tab3 ? 1 : 0, s));
+    } else {
+        for (int l = 1; l <= 4; ++l) CK(build(subm[l], l, l, C.d_subm, one4, one4));
+        for (int l = 2; l <= 4; ++l) CK(build(down[l], l, l - 1, C.d_subm, two3, one4));
+        for (int l = 2; l <= 4; ++l) CK(build(inv[l], l - 1, l, C.d_inv, one4, two3));
+        CK(build(down5, 5, 4, C.d_down5, two1, one4));
+        CK(build(inv5, 4, 5, C.d_inv5, one4, two1));
+    }
     host_mark("3D kernel maps enqueued");
     // ---- join: the caller's stream (MotionNet done) fills in the motion columns, waits for the coordinate phase, and averages
     s = sm;

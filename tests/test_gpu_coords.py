@@ -328,6 +328,57 @@ def test_rank_map_tables_match_the_oracle_and_the_searched_builder():
         ri = R.spconv_nbr_inverse(fine_b, (ref_k[sel_c] - np.uint64(b * ocells)), None, oshape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
         got = inv[:, coords[:, 0] == b]
         np.testing.assert_array_equal(np.where(got >= 0, got - off_c, -1), ri)
+    # ---- the same three tables (+ a 3-tap k311 one with an empty job in between) from ONE launch (insmos_build_nbr_rank_multi, what
+    # the native runner uses): entries and masks equal the per-table builder's, dense and with sparse stores
+    import ctypes
+    from insmos_amd import _lib
+    d_k3 = i32([[0, kz, 0, 0] for kz in range(3)])
+    two1 = i32([1, 2, 1, 1])
+    jobs_np = [(row_coords, perm_c, shape, d_subm, one, one, bits, incl), (ref_c, None, shape, d_subm, two, one, bits, incl),
+               (coords[:0], None, shape, d_subm, one, one, bits, incl),          # an empty level: skipped
+               (coords, None, oshape, d_inv, one, two, obits, oincl), (ref_c, None, shape, d_k3, two1, None, bits, incl)]
+    for sparse in (0, 1):
+        keep, outs = [], []
+        arr = (_lib.RankJob * len(jobs_np))()
+        for i, (oc_np, pm_np, shp_in, delta, mul, div, b_t, i_t) in enumerate(jobs_np):
+            no_ = len(oc_np)
+            oc_t = dev(oc_np) if no_ else torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+            pm_t = dev(pm_np) if pm_np is not None else None
+            nbr_t = torch.full((len(delta), max(no_, 1)), -7, dtype=torch.int32, device="cuda")
+            mk_t = torch.full(((max(no_, 1) + 15) // 16, 4), -1, dtype=torch.int32, device="cuda")
+            shp_h, keepalive = i32(shp_in), (oc_t, pm_t, delta, mul, div)
+            keep.append((keepalive, shp_h))
+            j = arr[i]
+            j.out_coords, j.bits, j.blk_incl = oc_t.data_ptr(), b_t.data_ptr(), i_t.data_ptr()
+            j.in_perm = pm_t.data_ptr() if pm_t is not None else None
+            j.nbr, j.mask16 = nbr_t.data_ptr(), mk_t.data_ptr()
+            j.in_shape, j.delta = hp(shp_h), hp(delta)
+            j.mul = hp(mul) if mul is not None else None
+            j.div = hp(div) if div is not None else None
+            j.n_out, j.K, j.reserved = no_, len(delta), 0
+            outs.append((nbr_t, mk_t, no_))
+        assert L.insmos_build_nbr_rank_multi(ctypes.byref(arr), len(jobs_np), sparse, stream()) == 0
+        torch.cuda.synchronize()
+        for (nbr_t, mk_t, no_), (oc_np, pm_np, shp_in, delta, mul, div, b_t, i_t) in zip(outs, jobs_np):
+            if no_ == 0:
+                assert (nbr_t.cpu().numpy() == -7).all()
+                continue
+            ref_n = torch.full((len(delta), no_), -7, dtype=torch.int32, device="cuda")
+            ref_m = torch.full(((no_ + 15) // 16, 4), -1, dtype=torch.int32, device="cuda")
+            oc_t = dev(oc_np)
+            pm_t = dev(pm_np) if pm_np is not None else None
+            fn = L.insmos_build_nbr_rank_sparse if sparse else L.insmos_build_nbr_rank
+            assert fn(oc_t.data_ptr(), no_, b_t.data_ptr(), i_t.data_ptr(), pm_t.data_ptr() if pm_t is not None else None, hp(i32(shp_in)),
+                      hp(delta), len(delta), hp(mul) if mul is not None else None, hp(div) if div is not None else None,
+                      ref_n.data_ptr(), ref_m.data_ptr(), stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(nbr_t, ref_n) and torch.equal(mk_t, ref_m)
+    # limits are refused, not truncated
+    bad = (_lib.RankJob * 1)()
+    bad[0] = arr[0]
+    bad[0].K = 33
+    assert L.insmos_build_nbr_rank_multi(ctypes.byref(bad), 1, 0, stream()) != 0
+    assert L.insmos_build_nbr_rank_multi(ctypes.byref(arr), 17, 0, stream()) != 0
 
 
 @pytest.mark.parametrize("n_per,B", [(700, 1), (40000, 2), (160000, 1), (260000, 3), (1300000, 1), (600000, 8)])

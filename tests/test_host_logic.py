@@ -312,7 +312,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import ctypes
     import subprocess
     from insmos_amd import _lib
-    pairs = {"InsmosConvW": _lib.ConvW, "InsmosNetCfg": _lib.NetCfg, "InsmosForwardOut": _lib.ForwardOut}
+    pairs = {"InsmosConvW": _lib.ConvW, "InsmosNetCfg": _lib.NetCfg, "InsmosForwardOut": _lib.ForwardOut, "InsmosRankJob": _lib.RankJob}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "insmos_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from insmos_amd.synth import make_window
 from oracle import ref_ops as R
 w = make_window(seed=0, n_scans=10, n_az=472)
