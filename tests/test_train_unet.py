@@ -289,7 +289,7 @@ def test_batched_training_step_equals_the_item_by_item_walk(chunk, monkeypatch):
         #  none with INSMOS_BN_CHUNK=1024, none in the 4D branch, none in windows 1 and 2 of the same launch).  So: the bulk tight,
         #  the flips few and small)
         assert a.shape == b.shape
-        d = (a - b).abs().max(1).values
+        d = (a - b).detach().abs().max(1).values
         if chunk is not None:
             assert float(d.max()) < 1e-4, (float(d.max()), int((d > 1e-4).sum()), len(d))
         else:

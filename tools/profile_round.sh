@@ -7,7 +7,7 @@
 R=$(pwd); TAG=${1:-r03}; WPL=${2:-8}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 2> $O/bench_profile.err | tail -1 > $O/bench_profile.json; cut -c1-300 $O/bench_profile.json
+python bench.py --steps 10 --warmup 3 --no-extras 2> $O/bench_profile.err | tail -1 > $O/bench_profile.json; cut -c1-300 $O/bench_profile.json
 for FL in 1 4; do
   rm -rf $O/prof_fl$FL
   ( cd /tmp && INSMOS_TWO_STREAMS=0 INSMOS_WINDOWS_IN_FLIGHT=$FL INSMOS_WINDOWS_PER_LAUNCH=$WPL timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_fl$FL -o prof --output-format csv -- \

@@ -2,7 +2,7 @@
 # Round-end evidence on the GPU box:  bash tools/round_end.sh r04 [suite|profile|all]  -> gpurun_out/<tag>/ (copy what is to be judged
 # into profiles/).  Two halves so that one gpurun call stays short: `suite` = whole GPU suite + smoke + the bench line;
 # `profile` = rocprofv3 kernel stats + PMC passes of the same workload, per-layer table, cfg-4, cfg-5, latency, driver.
-R=$(pwd); TAG=${1:-r04}; WHAT=${2:-all}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$(pwd); TAG=${1:-r05}; WHAT=${2:-all}; O=$R/gpurun_out/$TAG; mkdir -p $O
 if [ "$WHAT" = suite ] || [ "$WHAT" = all ]; then
   echo "== whole GPU suite"
   timeout 1200 python -m pytest tests -m gpu -q --timeout 400 > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log | cut -c1-300
