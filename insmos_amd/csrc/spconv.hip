@@ -802,7 +802,16 @@ ConvKernel pick_kernel(int cot, int jt) {
 }
 
 // split tiles: 4 waves per 16-row tile, all channel tiles per wave; contraction split by chunk (even) or by tap
-ConvKernel pick_split(int cot, int ck, bool by_chunk) {
+ConvKernel pick_split(int cot, int ck, bool by_chunk, int ring = 0) {
+    // (ring: INSMOS_CONV_RING = 4 / 5 -- a deeper operand ring for the small tap-split tiles, a tuning probe: same bits)
+    if (!ck && !by_chunk && ring == 4) {
+        if (cot == 1) return k_sparse_conv<1, 1, 0, false, 4, 4, false>;
+        if (cot == 2) return k_sparse_conv<2, 1, 0, false, 4, 4, false>;
+    }
+    if (!ck && !by_chunk && ring == 5) {
+        if (cot == 1) return k_sparse_conv<1, 1, 0, false, 5, 4, false>;
+        if (cot == 2) return k_sparse_conv<2, 1, 0, false, 5, 4, false>;
+    }
     if (ck == 8) {
         if (cot == 1) return k_sparse_conv<1, 1, 8, false, 3, 4, false>;
         if (cot == 2) return k_sparse_conv<2, 1, 8, false, 3, 4, false>;
@@ -965,13 +974,22 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
     if (split_env && !ident && co_ok && (ck == 0 || ck == 8) &&
         ((mask16 && K >= 16 && (wide || tile_work >= split_work)) || (!ck && wide && split_dense && P.n16 % 4 == 0 && K >= 3))) {
-        ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0);
+        static const int ring_env = env_int("INSMOS_CONV_RING", 0);
+        ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0, ring_env);
         int cot_split = P.ntile_co;
         // Few row groups (one window alone: the level-4 layers have ~420): the chunk-split tiles of a wide layer leave most CUs with
         // one or two 4-wave blocks, each latency-bound on its operand loads.  Two blocks per tile, half of the channel tiles each,
         // double the waves (the tile's rows are gathered twice; every output channel keeps its summation order: same bits).
-        static const int half_below = env_int("INSMOS_CONV_SPLIT_HALF", 1536);
-        if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
+        // (round 5: the threshold was 1536 -- single windows only; measured per layer on a launch set of 8 S0 windows, the C = 128
+        //  level-4 layers, 2 592 row groups: conv_up_m4.0 501 -> 467 us, conv_up_t4.* 243 / 256 -> 226 / 228, all convolutions
+        //  8 569 -> 8 474 us per set; the C = 64 level-3 layers, 5 056 groups, LOSE 18 % at half width: profiles/r05_knob_ab_layers.txt)
+        static const int half_wide = env_int("INSMOS_CONV_SPLIT_HALF", 4096), half_c64 = env_int("INSMOS_CONV_SPLIT_HALF_C64", 1536);
+        const int half_below = P.ntile_co >= 8 ? half_wide : half_c64;   // (Cout 64 keeps the single-window threshold)
+        static const int quarter_below = env_int("INSMOS_CONV_SPLIT_QUARTER", 0);   // (probe: four blocks per tile, C = 128 only)
+        if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 8 && groups < quarter_below) {
+            ConvKernel hk = pick_split(P.ntile_co / 4, ck, true);
+            if (hk) { sk = hk; cot_split = P.ntile_co / 4; }
+        } else if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
             ConvKernel hk = pick_split(P.ntile_co / 2, ck, true);
             if (hk) { sk = hk; cot_split = P.ntile_co / 2; }
         }
