@@ -114,7 +114,8 @@ def join(root, tag):
     out = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/pmc_gather_layers.sh); counter "
                      "unit KB; fetch factor = known read bytes / raw FETCH_SIZE of a launch of the SAME kernel over a shifted-identity "
                      "table (every table entry and every feature row needed once from HBM); layers of kernels without a "
-                     "calibration launch are reported at face value (see the comment in join())", "calibration": [], "layers": []}
+                     "calibration launch are reported at face value; row-lane layers as a range, face value .. x the coalesced-run "
+                     "scale of the kernel's clean launch (see the comment in join())", "calibration": [], "layers": []}
     factor = {}
     for i, cal in enumerate(wl["calibration"]):
         rec = res["FETCH_SIZE"]["cal"][2 * i + 1]
@@ -134,27 +135,36 @@ def join(root, tag):
     # 2 KiB run of rows, re-fetched per XCD), so its factor is NOT a counter scale; its layers are reported at face value like the
     # other gather kernels.  Kernels without a calibration launch (the >= 32-channel tiles, the dense BEV kernel, whose loads
     # are 64-B pieces as well) are reported at face value too, with the x2 figure next to it as an upper bound.
-    # Round 5: the row-lane kernel now HAS a clean launch ("rowlane 8->8 own rows": known bytes without a locality assumption); its
-    # factor is the counter scale of that kernel's loads, and the shifted-identity launch's factor, divided by it, is that access
-    # pattern's real re-fetch.
+    # Round 5: the row-lane kernel now HAS a clean launch ("rowlane 8->8 own rows": known bytes without a locality assumption).  What
+    # it says (profiles/r05_pmc_gather_layers.json): FETCH_SIZE reports HALF the known bytes there (factor 1.99) -- that launch is
+    # coalesced runs throughout (256-B index loads, 64 consecutive 32-B rows per gather = 2 KiB runs), i.e. the 128-B requests the
+    # guide's x2 is about -- while the MFMA gather kernels on the same tables come out at 1.00 (16 scattered rows x 64 B per
+    # instruction: 64-B requests at face value).  So the counter scale follows the REQUEST WIDTH, not the kernel, and a product
+    # row-lane layer mixes both kinds (coalesced index stream, scattered 32-B row gathers): its traffic is reported as a RANGE --
+    # face value (lower bound, `hbm_read_bytes`) to everything x 1.99 (upper bound, `hbm_read_bytes_upper`).  The shifted-identity
+    # launch's factor over the clean one is that access pattern's REAL re-fetch (6.7x: a 64-row tile walks 81 runs spread over 166 KB).
     f_mf = factor.get("mfma quad 8->8", 1.0)
-    f_rl = factor.get("rowlane 8->8 own rows", 1.0)
-    out["rowlane_counter_scale"] = round(f_rl, 3)
+    f_rl_up = max(1.0, factor.get("rowlane 8->8 own rows", 1.0))
+    out["rowlane_coalesced_run_counter_scale"] = round(f_rl_up, 3)
     if factor.get("rowlane 8->8"):
-        out["rowlane_shifted_identity_refetch"] = round(f_rl / factor["rowlane 8->8"], 2)
+        out["rowlane_shifted_identity_refetch"] = round(f_rl_up / factor["rowlane 8->8"], 2)
     for i, L in enumerate(wl["layers"]):
         rfr, rwr = res["FETCH_SIZE"]["set"][i], res["WRITE_SIZE"]["set"][i]
         kname = rfr["Kernel_Name"]
         us = dur.get(int(rfr["Dispatch_Id"]), 0.0)
-        calibrated = "k_sparse_conv_q" in kname or "k_conv_rowlane" in kname
-        f = f_rl if "k_conv_rowlane" in kname else f_mf if calibrated else 1.0
-        fetch = float(rfr["Counter_Value"]) * KB * f
+        rowlane = "k_conv_rowlane" in kname
+        calibrated = "k_sparse_conv_q" in kname or rowlane
+        f = f_mf if "k_sparse_conv_q" in kname else 1.0
+        raw = float(rfr["Counter_Value"]) * KB
+        fetch = raw * f
+        fetch_up = raw * (f_rl_up if rowlane else f)
         write = float(rwr["Counter_Value"]) * KB
         out["layers"].append({**L, "kernel": kname.split("(")[0][-48:], "us": round(us, 1), "fetch_factor": round(f, 3),
                               "fetch_calibrated_on_this_kernel": calibrated,
-                              "hbm_read_bytes": round(fetch), "hbm_write_bytes": round(write),
+                              "hbm_read_bytes": round(fetch), "hbm_read_bytes_upper": round(fetch_up), "hbm_write_bytes": round(write),
                               "hbm_gbs": round((fetch + write) / us / 1e3, 1) if us else None,
                               "frac_of_8tbs": round((fetch + write) / us / 1e3 / 8000.0, 4) if us else None,
+                              "frac_of_8tbs_upper": round((fetch_up + write) / us / 1e3 / 8000.0, 4) if us else None,
                               "tflops": round(L["flops"] / us / 1e6, 2) if us else None,
                               "frac_of_fp32_mfma_peak": round(L["flops"] / us / 1e6 / 157.3, 4) if us else None})
     over = [l["name"] for l in out["layers"] if (l.get("frac_of_fp32_mfma_peak") or 0) > 1.0]
@@ -162,9 +172,11 @@ def join(root, tag):
     sel = [l for l in out["layers"] if l["K"] == 81 and l["cin"] <= 16]
     sus = sum(l["us"] for l in sel)
     sb = sum(l["hbm_read_bytes"] + l["hbm_write_bytes"] for l in sel)
-    out["summary_81tap_small_channel"] = {"layers": [l["name"] for l in sel], "us": round(sus, 1), "hbm_bytes": sb,
+    sbu = sum(l["hbm_read_bytes_upper"] + l["hbm_write_bytes"] for l in sel)
+    out["summary_81tap_small_channel"] = {"layers": [l["name"] for l in sel], "us": round(sus, 1), "hbm_bytes": sb, "hbm_bytes_upper": sbu,
                                           "hbm_gbs": round(sb / max(sus, 1e-9) / 1e3, 1),
-                                          "frac_of_8tbs": round(sb / max(sus, 1e-9) / 1e3 / 8000.0, 4)}
+                                          "frac_of_8tbs": round(sb / max(sus, 1e-9) / 1e3 / 8000.0, 4),
+                                          "frac_of_8tbs_upper": round(sbu / max(sus, 1e-9) / 1e3 / 8000.0, 4)}
     tot_us = sum(l["us"] for l in out["layers"])
     tot_b = sum(l["hbm_read_bytes"] + l["hbm_write_bytes"] for l in out["layers"])
     tot_r = sum(l["hbm_read_bytes"] for l in out["layers"])
@@ -178,7 +190,7 @@ def join(root, tag):
         if l["K"] >= 8 and l["cin"] <= 16:
             print("%-28s K%3d %3d->%3d %9d rows %8.1f us  read %7.1f MB write %6.1f MB  %7.1f GB/s (%.3f of 8 TB/s) %s" % (
                 l["name"], l["K"], l["cin"], l["cout"], l["rows"], l["us"], l["hbm_read_bytes"] / 1e6, l["hbm_write_bytes"] / 1e6,
-                l["hbm_gbs"], l["frac_of_8tbs"], l["kernel"][-28:]))
+                l["hbm_gbs"], l["frac_of_8tbs"], l["kernel"][-28:]) + ("  [upper %.3f]" % l["frac_of_8tbs_upper"] if l["frac_of_8tbs_upper"] != l["frac_of_8tbs"] else ""))
     print(json.dumps(out["summary_81tap_small_channel"]), json.dumps(out["all_conv_launches"]))
 
 
