@@ -659,3 +659,30 @@ def test_forced_collectives_in_a_world_of_one_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script), str(29300 + os.getpid() % 150), ROOT], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=180)
     assert r.returncode == 0 and "OK" in r.stdout.decode(), r.stdout.decode()[-2000:]
+
+
+_EMIT_WORKER = r"""
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+libc = ctypes.CDLL(None)
+libc.printf(b"RCCL version : banner written through C stdio, still in libc's buffer on a pipe\n")
+print("python-level chatter before the result")
+bench.emit_result_line({"metric": "scans_per_sec", "value": 1.0})
+libc.printf(b"a library flushing at teardown\n")      # must not reach the pipe
+print("python-level chatter after the result")         # neither
+"""
+
+
+def test_bench_result_line_is_the_last_line_of_stdout(tmp_path):
+    """What first contact with RCCL found on the GPU box: a library banner written through C stdio sat in libc's pipe buffer until
+    exit and landed BEHIND the JSON line.  bench.emit_result_line flushes libc first, writes the line, and closes stdout behind it."""
+    import json
+    script = tmp_path / "emit_worker.py"
+    script.write_text(_EMIT_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    assert json.loads(lines[-1]) == {"metric": "scans_per_sec", "value": 1.0}, lines
+    assert any("banner" in l for l in lines[:-1]) and any("before the result" in l for l in lines[:-1])
+    assert not any("teardown" in l or "after the result" in l for l in lines)
