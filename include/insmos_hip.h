@@ -461,6 +461,10 @@ int insmos_debug_conv_force(int cot, int jt, int ring);
 /* test hook: single-chunk layers (Cin 8 / 16, unsplit) on the quad-index kernel (1, the default) or on the generic one (0);
  * both produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_quad(int on);
+/* test hook: row-group thresholds below which the chunk-split tiles of a wide layer run at HALF width (two blocks per tile, half of
+ * the channel tiles each) -- `wide` for Cout >= 128, `c64` for Cout 64; -1 = the environment / the defaults (4096, 1536), 0 = never.
+ * Every output channel keeps its summation chain: both widths produce the same bits (tests/test_gpu_conv.py). */
+int insmos_debug_conv_split_half(int wide, int c64);
 /* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
  * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =
  * 8 x 8 layers with K >= 16, bit 1 = K < 16 (Cin x Cout <= 128), bit 2 = 8 x 16 / 16 x 8 with K >= 16, bit 3 = 16 x 16; 0 = off

@@ -110,6 +110,7 @@ SIGNATURES = {
     "insmos_deconv_head_skip_active_sites": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
+    "insmos_debug_conv_split_half": (c_int, [c_int, c_int]),
     "insmos_debug_conv_rowlane": (c_int, [c_int, c_int]),
     "insmos_debug_conv_lds": (c_int, [c_int]),
     "insmos_debug_conv_lds_stats": (c_int, [c_vp, c_int]),

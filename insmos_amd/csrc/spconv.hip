@@ -852,6 +852,7 @@ std::mutex g_split_mu;
 // tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
 int g_quad = -1;  // quad-index kernel for single-chunk layers: -1 = read INSMOS_CONV_QUAD (default on)
+int g_half_wide = -1, g_half_c64 = -1;  // insmos_debug_conv_split_half: -1 = environment / defaults
 // probe variants of the kernel configurations the heavy S0 layers use (ring >= 16 selects dbg = ring / 16)
 template <int DBG>
 ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
@@ -983,7 +984,8 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         // (round 5: the threshold was 1536 -- single windows only; measured per layer on a launch set of 8 S0 windows, the C = 128
         //  level-4 layers, 2 592 row groups: conv_up_m4.0 501 -> 467 us, conv_up_t4.* 243 / 256 -> 226 / 228, all convolutions
         //  8 569 -> 8 474 us per set; the C = 64 level-3 layers, 5 056 groups, LOSE 18 % at half width: profiles/r05_knob_ab_layers.txt)
-        static const int half_wide = env_int("INSMOS_CONV_SPLIT_HALF", 4096), half_c64 = env_int("INSMOS_CONV_SPLIT_HALF_C64", 1536);
+        static const int half_wide_env = env_int("INSMOS_CONV_SPLIT_HALF", 4096), half_c64_env = env_int("INSMOS_CONV_SPLIT_HALF_C64", 1536);
+        const int half_wide = g_half_wide >= 0 ? g_half_wide : half_wide_env, half_c64 = g_half_c64 >= 0 ? g_half_c64 : half_c64_env;
         const int half_below = P.ntile_co >= 8 ? half_wide : half_c64;   // (Cout 64 keeps the single-window threshold)
         static const int quarter_below = env_int("INSMOS_CONV_SPLIT_QUARTER", 0);   // (probe: four blocks per tile, C = 128 only)
         if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 8 && groups < quarter_below) {
@@ -1186,6 +1188,13 @@ extern "C" int insmos_conv_precision(int mode) {
 extern "C" int insmos_conv_precision_thread(int mode) {
     if (mode != -1 && mode != 0 && mode != 1 && mode != 3) return INSMOS_EINVAL;
     tl_prec = mode;
+    return INSMOS_OK;
+}
+
+extern "C" int insmos_debug_conv_split_half(int wide, int c64) {
+    if (wide < -1 || c64 < -1) return INSMOS_EINVAL;
+    g_half_wide = wide;
+    g_half_c64 = c64;
     return INSMOS_OK;
 }
 

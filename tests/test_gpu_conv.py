@@ -202,6 +202,17 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
         ref = ref + res
     ref = np.maximum(ref, 0.0)
     np.testing.assert_allclose(full.cpu().numpy(), ref, **TOL)
+    # half-width tiles (two blocks per tile, half of the channel tiles each: what the launcher picks for few row groups -- single
+    # windows, and since round 5 the C = 128 level-4 layers of a launch set) against full-width ones: the same bits
+    if cout >= 64 and cin % 64 == 0:
+        try:
+            assert lib().insmos_debug_conv_split_half(0, 0) == 0
+            never = run(nbr)
+            assert lib().insmos_debug_conv_split_half(1 << 30, 1 << 30) == 0
+            always = run(nbr)
+        finally:
+            lib().insmos_debug_conv_split_half(-1, -1)
+        assert torch.equal(never, always) and torch.equal(never, full)
     tail_a = run(nbr, row0=16 * 1000)                                 # a row suffix: 17000 rows, then 2600
     tail_b = run(nbr, row0=16 * 1900)
     assert torch.equal(full[16000:], tail_a[16000:]) and torch.equal(full[30400:], tail_b[30400:])
