@@ -2200,6 +2200,26 @@ extern "C" int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, c
         !child_mask || !delta_host || !nbr || fine_shift < 0 || fine_shift > 14)
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    // The 5^3 table of the stride-2^fine_shift level (x fastest, no time extent) -- what the TRAINING step needs for the first
+    // layer's d/dW -- through the per-voxel resolver (k_resolve_taps: the 27 coarse neighbour blocks fetched once per voxel, every
+    // tap by bit arithmetic) instead of one thread per (voxel, tap): the same entries and masks (tests/test_gpu_coords.py), the
+    // 785 MB table of a four-window step in a third of the time.  INSMOS_NBR125_RESOLVER=0 keeps the generic kernel.
+    static const bool fast125 = [] { const char* e = getenv("INSMOS_NBR125_RESOLVER"); return !(e && e[0] == '0'); }();
+    if (fast125 && K == 125 && n_f < (1ll << 31) - 256) {
+        bool is5 = true;
+        const int st = 1 << fine_shift;
+        for (int k = 0; k < 125 && is5; ++k)
+            is5 = delta_host[k * 4 + 0] == (k % 5 - 2) * st && delta_host[k * 4 + 1] == ((k / 5) % 5 - 2) * st &&
+                  delta_host[k * 4 + 2] == (k / 25 - 2) * st && delta_host[k * 4 + 3] == 0;
+        if (is5) {
+            ProfScope ps(KK_BUILD_NBR, s);
+            INSMOS_LAUNCH((k_resolve_taps<2, 1, 0>), dim3(cdiv(n_f, TPB)), dim3(TPB), 0, s, fine_coords, n_f, parent, fine_shift,
+                          coarse_nbr81, n_c, child_start, child_mask, nbr, mask16, (const float*)nullptr, (const float*)nullptr,
+                          (float*)nullptr, 0, 0, (int64_t)0, (const uint32_t*)nullptr);
+            HIP_TRY(hipGetLastError());
+            return INSMOS_OK;
+        }
+    }
     TapList T;
     memset(&T, 0, sizeof(T));
     for (int k = 0; k < K; ++k)
