@@ -812,6 +812,10 @@ ConvKernel pick_split(int cot, int ck, bool by_chunk, int ring = 0) {
         if (cot == 1) return k_sparse_conv<1, 1, 0, false, 5, 4, false>;
         if (cot == 2) return k_sparse_conv<2, 1, 0, false, 5, 4, false>;
     }
+    if (!ck && by_chunk && ring == 13) {   // (probe: ring 3 on the chunk-split tiles, INSMOS_CONV_RING=13)
+        if (cot == 8) return k_sparse_conv<8, 1, 0, false, 3, 4, true>;
+        if (cot == 4) return k_sparse_conv<4, 1, 0, false, 3, 4, true>;
+    }
     if (ck == 8) {
         if (cot == 1) return k_sparse_conv<1, 1, 8, false, 3, 4, false>;
         if (cot == 2) return k_sparse_conv<2, 1, 8, false, 3, 4, false>;
@@ -975,6 +979,11 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
     if (split_env && !ident && co_ok && (ck == 0 || ck == 8) &&
         ((mask16 && K >= 16 && (wide || tile_work >= split_work)) || (!ck && wide && split_dense && P.n16 % 4 == 0 && K >= 3))) {
+        // operand ring of the split tiles (INSMOS_CONV_RING, probes): 0 = the defaults (3 on the tap-split tiles, 2 on the chunk-split
+        // ones), 4 / 5 = deeper on the tap-split tiles, 13 = ring 3 on the chunk-split tiles.  Measured per layer on a launch set of
+        // 8 (round 5, profiles/r05_knob_ab_layers.txt): none pays -- ring 3 on the chunk-split tiles costs the Cin = 128 layers 12-17 %
+        // (one more operand set per wave, one wave less per SIMD); on conv_up_m4.0 (Cin = 256) it read -10 % in a run where the
+        // layers in front of it were slowed too and +3 % with only that layer switched: a clock / power artefact, not a gain.
         static const int ring_env = env_int("INSMOS_CONV_RING", 0);
         ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0, ring_env);
         int cot_split = P.ntile_co;
@@ -992,7 +1001,7 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
             ConvKernel hk = pick_split(P.ntile_co / 4, ck, true);
             if (hk) { sk = hk; cot_split = P.ntile_co / 4; }
         } else if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
-            ConvKernel hk = pick_split(P.ntile_co / 2, ck, true);
+            ConvKernel hk = pick_split(P.ntile_co / 2, ck, true, ring_env);
             if (hk) { sk = hk; cot_split = P.ntile_co / 2; }
         }
         if (sk) {
