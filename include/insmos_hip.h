@@ -465,6 +465,10 @@ int insmos_debug_conv_quad(int on);
  * the channel tiles each) -- `wide` for Cout >= 128, `c64` for Cout 64; -1 = the environment / the defaults (4096, 1536), 0 = never.
  * Every output channel keeps its summation chain: both widths produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_split_half(int wide, int c64);
+/* test hook: the Cin = 32 layers whose input rows are whole 128-byte lines on the whole-row gather kernel (csrc/spconv_row32.hip: 1, the
+ * default: where it pays, Cout <= 16 with K >= 16; 2: every shape it is built for; -1 = INSMOS_CONV_ROW32) or on the generic tiles (0);
+ * all produce the same bits (tests/test_gpu_conv.py). */
+int insmos_debug_conv_row32(int on);
 /* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
  * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =
  * 8 x 8 layers with K >= 16, bit 1 = K < 16 (Cin x Cout <= 128), bit 2 = 8 x 16 / 16 x 8 with K >= 16, bit 3 = 16 x 16; 0 = off

@@ -111,6 +111,7 @@ SIGNATURES = {
     "insmos_debug_conv_force": (c_int, [c_int, c_int, c_int]),
     "insmos_debug_conv_quad": (c_int, [c_int]),
     "insmos_debug_conv_split_half": (c_int, [c_int, c_int]),
+    "insmos_debug_conv_row32": (c_int, [c_int]),
     "insmos_debug_conv_rowlane": (c_int, [c_int, c_int]),
     "insmos_debug_conv_lds": (c_int, [c_int]),
     "insmos_debug_conv_lds_stats": (c_int, [c_vp, c_int]),

@@ -38,6 +38,10 @@ bool conv_lds_try(const ConvP& P, int ck, int cot, long n_rows, hipStream_t s, i
 size_t rowlane_tail_floats(int K, int cin, int cout);
 bool conv_rowlane_ok(const ConvP& P);
 bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc);
+// spconv_row32.hip: the Cin = 32 layers with whole-row gathers (one 128-byte line per row) staged through LDS -- the kernel for a
+// launch shape the dispatcher has already chosen (same tile -> block mapping, same bits), or null
+typedef void (*ConvKernelFn)(ConvP);
+ConvKernelFn conv_row32_pick(const ConvP& P, int cot, int jt, int split, bool by_chunk);
 // [tap][p][co] position -> (ci, co) of the layer: p = 4 s + g walks the input channels in the MFMA kernels' chain order
 __host__ __device__ inline int rowlane_ci(int cin, int p) { return (cin / 4) * (p & 3) + (p >> 2); }
 

@@ -1054,6 +1054,11 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         }
         if (pk) kern = pk;
     }
+    // Cin = 32 with rows that are whole 128-byte lines: the same tile on the whole-row gather kernel (spconv_row32.hip; same bits)
+    if (kern && !ident && !ck && !cur_prec() && !g_force_cot && !g_dbg) {
+        ConvKernelFn rk = conv_row32_pick(P, best.cot, best.jt, split, by_chunk);
+        if (rk) kern = rk;
+    }
     if (!kern) return INSMOS_EINVAL;
 
     // ---- launch shape: one ONE-WAVE block per tile (split: one 4-wave block per tile)

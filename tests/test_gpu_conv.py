@@ -278,6 +278,72 @@ def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_m
     assert torch.equal(run(1, True, r0)[r0:], run(0, True, r0)[r0:])
 
 
+@pytest.mark.parametrize("cout,K,n_out,res_mode", [
+    (16, 27, 40003, 0), (32, 27, 33333, 1), (32, 8, 9000, 0), (16, 81, 20011, 1), (32, 81, 12000, 2), (64, 27, 5000, 0), (16, 8, 777, 2),
+    (32, 27, 17, 0), (16, 1, 100, 0), (32, 3, 4100, 1), (64, 81, 3000, 0)])
+def test_whole_row_gather_kernel_is_bitwise_the_generic_one(cout, K, n_out, res_mode):
+    """The Cin = 32 layers whose input rows are whole 128-byte lines run on csrc/spconv_row32.hip (two whole-row gathers per tap, rows
+    turned into B fragments through a wave-private LDS buffer, three-stage pipeline over taps): the SAME bits as the generic tiles --
+    unsplit and tap-split, Cout 16 / 32 / 64, with and without active-tap masks, every epilogue, a row suffix, tap lists of every
+    length (the pipeline's prologue / tail), a table with garbage outside its masks (sparse stores) -- and the generic kernel is what
+    runs when the rows are NOT lines (a column slice of wider rows, a base off the 128-byte grid)."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    cin = 32
+    rng = np.random.default_rng(K * 100 + cout + 31)
+    n_in = max(n_out // 2, 40)
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    ngrp = (n_out + 15) // 16
+    n_act = rng.integers(0, K + 1, size=ngrp)                         # active taps per 16-row group: every count 0..K
+    grp = np.zeros((K, ngrp), bool)
+    for gi in range(ngrp):
+        grp[rng.permutation(K)[:n_act[gi]], gi] = True
+    slot_on = np.repeat(grp, 16, axis=1)[:, :n_out]
+    nbr[~(slot_on & (rng.uniform(size=(K, n_out)) < 0.7))] = -1
+    masks = tap_masks(nbr)
+    sparse = nbr.copy()                                                # what a sparse-storing table builder leaves outside the masks
+    sparse[~slot_on] = rng.integers(-5, n_in + 1000, size=int((~slot_on).sum()))
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.3)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    xd, nd, sd, md = dev(x), dev(nbr), dev(sparse), dev(masks.view(np.int32))
+    wide = torch.zeros((n_in, 48), device="cuda:0")                    # the same rows as a column slice of 192-byte rows: not lines
+    wide[:, 16:48] = xd
+
+    def run(on, table, masked, row0=0, xin=xd, ld=cin, col=0):
+        assert lib().insmos_debug_conv_row32(on) == 0
+        try:
+            out = torch.full((n_out, cout), -7.0, device="cuda:0")
+            _lib.check(lib().insmos_sparse_conv_rows(xin.data_ptr() + 4 * col, n_in, ld, layer.cin, table.data_ptr(),
+                                                     md.data_ptr() if masked else None, K, n_out, row0, layer.w.data_ptr(),
+                                                     layer.b.data_ptr(), out.data_ptr(), cout, layer.cout,
+                                                     res.data_ptr() if res is not None else None, ld_res if res_mode else 0, res_mode,
+                                                     1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib().insmos_debug_conv_row32(-1)
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    for masked in (True, False):
+        a, b = run(2, nd, masked), run(0, nd, masked)                  # (2: every shape the kernel is built for; 1 = the product rule)
+        assert torch.equal(a, b)
+        assert torch.equal(run(1, nd, masked), b)
+        np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    assert torch.equal(run(2, sd, True), run(0, nd, True))             # entries outside the masks are never read
+    r0 = 16 * (n_out // 48)
+    assert torch.equal(run(2, nd, True, r0)[r0:], run(0, nd, True, r0)[r0:])
+    assert torch.equal(run(2, nd, True, xin=wide, ld=48, col=16), run(0, nd, True))   # rows that are not lines: the generic tiles
+
+
 @pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
     (8, 8, 81, 40003, 1), (8, 16, 81, 5000, 0), (16, 16, 81, 33333, 1), (16, 8, 81, 2049, 0), (16, 16, 27, 40000, 2),
     (8, 16, 27, 777, 0), (8, 8, 8, 33000, 0), (16, 8, 8, 1000, 0), (16, 16, 3, 17, 0), (8, 8, 81, 63, 2), (8, 8, 99, 1300, 0)])
