@@ -466,8 +466,9 @@ int insmos_debug_conv_quad(int on);
  * Every output channel keeps its summation chain: both widths produce the same bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_split_half(int wide, int c64);
 /* test hook: the Cin = 32 layers whose input rows are whole 128-byte lines on the whole-row gather kernel (csrc/spconv_row32.hip: 1, the
- * default: where it pays, Cout <= 16 with K >= 16; 2: every shape it is built for; -1 = INSMOS_CONV_ROW32) or on the generic tiles (0);
- * all produce the same bits (tests/test_gpu_conv.py). */
+ * default: where it pays -- the LDS-staged form for Cout <= 16 with K >= 16, the half-swizzled form for the 27-tap Cout 32 layers; 2 / 3: the
+ * staged / the half-swizzled form on every shape it is built for; -1 = INSMOS_CONV_ROW32) or on the generic tiles (0); all produce the same
+ * bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_row32(int on);
 /* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
  * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =

@@ -40,12 +40,16 @@ __device__ __forceinline__ int r32_pop_or_keep(uint64_t& lo, uint64_t& hi, int k
 constexpr int kPitch = 160;               // bytes between rows of a staging buffer
 constexpr int kStageBytes = 16 * kPitch;  // one tap: 16 rows
 
-template <int COT, int SPLIT>
+// SWZ (second form, no LDS): the gathers stay 16 rows x 64 B, but the two of a tap are HALF-SWIZZLED -- in the first one even rows
+// read chunk 0 and odd rows chunk 1, in the second the other way round -- and a v_cndmask per register puts the chunks back.  The
+// same probe: 16 rows x 64 B that all take the SAME half of their lines cost 27 ns per CU (a conflict on address bit 6), with the
+// halves alternating 14 (L1) / 19 (L2) ns.  No staging, no second index load, the generic tiles' register footprint.
+template <int COT, int SPLIT, bool SWZ>
 __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
     static_assert(SPLIT == 1 || SPLIT == 4, "one wave per tile, or four waves sharing a tile's taps");
     constexpr int NW = SPLIT == 1 ? 1 : 4;
     // ONE staging buffer per wave: the LDS executes a wave's instructions in order, so tap t + 1's ds_writes cannot pass tap t's ds_reads
-    __shared__ __attribute__((aligned(16))) unsigned char stage[NW][kStageBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[SWZ ? 1 : NW][SWZ ? 16 : kStageBytes];
     const int lane = threadIdx.x & 63;
     const uint32_t wib = SPLIT == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ws = wib;
@@ -71,9 +75,12 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
     // output rows: j for the epilogue; (lane >> 3) and 8 + (lane >> 3) for the whole-row gathers
     const uint32_t row_base = P.row0 + ot * 16u;
     const uint32_t orow = row_base + (uint32_t)j;
-    const uint32_t ra = row_base + (uint32_t)(lane >> 3), rb = ra + 8u;
+    // (SWZ: both gathers read the neighbour of the lane's own row j, 16 B at 16 g inside the half picked by the row's parity)
+    const uint32_t ra = SWZ ? orow : row_base + (uint32_t)(lane >> 3), rb = SWZ ? orow : ra + 8u;
     const uint32_t roa = (ra < n_out ? ra : n_out - 1) * 4u, rob = (rb < n_out ? rb : n_out - 1) * 4u;
-    const uint32_t qoff = (uint32_t)(lane & 7) * 16u;
+    const bool odd = (j & 1) != 0;
+    const uint32_t qoff = SWZ ? (uint32_t)g * 16u + (odd ? 64u : 0u) : (uint32_t)(lane & 7) * 16u;
+    const uint32_t qoff_b = SWZ ? (uint32_t)g * 16u + (odd ? 0u : 64u) : qoff;
 
     // ---- active taps of the tile (SGPRs), the tap-split residue class of this wave
     uint64_t tlo, thi;
@@ -125,7 +132,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
         woffv[it] = co < cout ? ((cg * COT + it) * FR + lane * 4u) * 4u : 0x7FFFFFF0u;
     }
 
-    unsigned char* const my_stage = &stage[wib][0];
+    unsigned char* const my_stage = &stage[SWZ ? 0 : wib][0];
     const uint32_t wr_a = (uint32_t)(lane >> 3) * kPitch + qoff;             // bytes: row (lane >> 3), piece q
     const uint32_t wr_b = wr_a + 8u * kPitch;                                // row 8 + (lane >> 3)
     const uint32_t rd_0 = (uint32_t)j * kPitch + (uint32_t)g * 16u;          // chunk 0 of row j; chunk 1 is 64 B further
@@ -138,7 +145,8 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
         int kNN = next_tap(kN);
         auto load_idx = [&](int k, uint32_t& ia, uint32_t& ib) {
             ia = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, roa, (uint32_t)k * n_out * 4u, 0);
-            ib = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rob, (uint32_t)k * n_out * 4u, 0);
+            if constexpr (SWZ) ib = ia;
+            else ib = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_nb, rob, (uint32_t)k * n_out * 4u, 0);
         };
         uint32_t offLa, offLb, offNa, offNb, idxNNa, idxNNb;
         {
@@ -146,8 +154,8 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
             load_idx(kL, i0a, i0b);
             load_idx(kN, i1a, i1b);
             load_idx(kNN, idxNNa, idxNNb);
-            offLa = i0a * 128u + qoff; offLb = i0b * 128u + qoff;     // (-1 wraps past the end of the buffer: the load returns 0)
-            offNa = i1a * 128u + qoff; offNb = i1b * 128u + qoff;
+            offLa = i0a * 128u + qoff; offLb = i0b * 128u + qoff_b;   // (-1 wraps past the end of the buffer: the load returns 0)
+            offNa = i1a * 128u + qoff; offNb = i1b * 128u + qoff_b;
         }
         f32x4 ga[3], gb[3];            // gathered row pieces of taps in flight
         f32x4 as[3][2][COT];           // weight fragments [slot][chunk][channel tile]
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
         kW = kL;                                                                                                            \
         kL = kN; kN = kNN;                                                                                                  \
         offLa = offNa; offLb = offNb;                                                                                       \
-        offNa = idxNNa * 128u + qoff; offNb = idxNNb * 128u + qoff;                                                         \
+        offNa = idxNNa * 128u + qoff; offNb = idxNNb * 128u + qoff_b;                                                       \
         kNN = next_tap(kNN);                                                                                                \
         load_idx(kNN, idxNNa, idxNNb);                                                                                      \
     }
@@ -172,7 +180,7 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
                 as[slot][c][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw + (uint32_t)c * blk_stride * 4u, 0)); \
     }
 #define R32_STAGE(slot)                                                                                                     \
-    {                                                                                                                       \
+    if constexpr (!SWZ) {                                                                                                   \
         unsigned char* sb = my_stage;                                                                                       \
         __builtin_amdgcn_wave_barrier();   /* (scheduling only: the reads below are other lanes' writes) */                 \
         *(f32x4*)(sb + wr_a) = ga[slot];                                                                                    \
@@ -184,6 +192,12 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
     }
 #define R32_MMA(slot)                                                                                                       \
     {                                                                                                                       \
+        if constexpr (SWZ) {   /* un-swizzle: even rows hold (chunk 0, chunk 1) in (ga, gb), odd rows the other way round */ \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                 \
+                fr[slot][0][e] = odd ? gb[slot][e] : ga[slot][e];                                                           \
+                fr[slot][1][e] = odd ? ga[slot][e] : gb[slot][e];                                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                       \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                   \
                 _Pragma("unroll") for (int it = 0; it < COT; ++it)                                                          \
@@ -275,15 +289,16 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_conv_row32(ConvP P) {
 }
 
 typedef void (*R32Kernel)(ConvP);
+template <bool SWZ>
 R32Kernel pick_row32(int cot, int split) {
     if (split == 1) {
-        if (cot == 1) return k_conv_row32<1, 1>;
-        if (cot == 2) return k_conv_row32<2, 1>;
-        if (cot == 4) return k_conv_row32<4, 1>;
+        if (cot == 1) return k_conv_row32<1, 1, SWZ>;
+        if (cot == 2) return k_conv_row32<2, 1, SWZ>;
+        if (cot == 4) return k_conv_row32<4, 1, SWZ>;
     } else if (split == 4) {
-        if (cot == 1) return k_conv_row32<1, 4>;
-        if (cot == 2) return k_conv_row32<2, 4>;
-        if (cot == 4) return k_conv_row32<4, 4>;
+        if (cot == 1) return k_conv_row32<1, 4, SWZ>;
+        if (cot == 2) return k_conv_row32<2, 4, SWZ>;
+        if (cot == 4) return k_conv_row32<4, 4, SWZ>;
     }
     return nullptr;
 }
@@ -294,22 +309,28 @@ int g_row32 = -1;   // insmos_debug_conv_row32: -1 = INSMOS_CONV_ROW32 (default 
 // the kernel for this launch shape, or null: Cin = 32 with rows that ARE 128-byte lines (pitch 32 floats, 128-byte aligned base), a
 // neighbour table, 16-row tiles (one wave, or four tap-split waves) of 1 / 2 / 4 channel tiles
 ConvKernelFn conv_row32_pick(const ConvP& P, int cot, int jt, int split, bool by_chunk) {
-    if (g_row32 < 0) { const char* e = getenv("INSMOS_CONV_ROW32"); g_row32 = (e && e[0] == '0') ? 0 : 1; }
+    if (g_row32 < 0) { const char* e = getenv("INSMOS_CONV_ROW32"); g_row32 = e ? atoi(e) : 1; if (g_row32 < 0 || g_row32 > 3) g_row32 = 1; }
     if (!g_row32 || !P.nbr || P.cin != 32 || P.n16 != 2 || P.has8 || P.has4 || P.ld_in != 32 || ((uintptr_t)P.in & 127) || jt != 1 || by_chunk)
         return nullptr;
     // Where it pays (per layer on a launch set of 8, profiles/r05_row32_layers.txt): the Cout = 16 layers with a real tap list --
     // block7.0.conv1 284 -> 241 us, conv_up_instance_block_up2 / up1 71 / 60 -> 57 / 47, conv_up_m1.0 68 -> 52, inv_conv2.0 53 -> 49:
     // one channel tile per gathered row, the L1 was their bound.  With two channel tiles (Cout 32) the MFMA time per tap equals the
     // L1 time even on the generic tiles and the kernel's larger register footprint buys nothing (+-2 %); the 8-tap k2s2 maps (one
-    // or two active taps per group: all prologue) and Cout 64 lose 10-25 %.  g_row32 == 2 (test hook) lifts the restriction.
-    if (g_row32 != 2 && !(cot == 1 && P.K >= 16)) return nullptr;
-    return pick_row32(cot, split);
+    // or two active taps per group: all prologue) and Cout 64 lose 10-25 %.
+    // The half-swizzled form (no LDS, the generic footprint) on the same table: Cout 16 layers 250 / 59 / 57 / 50 -- behind the staged
+    // form --, the 27-tap Cout 32 layers 86.7 / 80.3 / 82.5 / 81.5 -> 81.2 / 76.2 / 78.7 / 76.7 (-5 %), the 81-tap ones +-2 %.
+    // g_row32: 1 = this rule, 2 = the staged form on every shape, 3 = the half-swizzled form on every shape (test hooks), 0 = off.
+    if (g_row32 == 3) return pick_row32<true>(cot, split);
+    if (g_row32 == 2) return pick_row32<false>(cot, split);
+    if (cot == 1 && P.K >= 16) return pick_row32<false>(cot, split);
+    if (cot == 2 && P.K >= 16 && P.K <= 32) return pick_row32<true>(cot, split);
+    return nullptr;
 }
 
 }  // namespace insmos
 
 extern "C" int insmos_debug_conv_row32(int on) {
-    if (on < -1 || on > 2) return INSMOS_EINVAL;   // (2: every shape the kernel is built for, not only the ones it pays on)
+    if (on < -1 || on > 3) return INSMOS_EINVAL;   // (2 / 3: the staged / the half-swizzled form on every shape the kernel is built for)
     insmos::g_row32 = on;
     return INSMOS_OK;
 }

@@ -337,10 +337,12 @@ def test_whole_row_gather_kernel_is_bitwise_the_generic_one(cout, K, n_out, res_
         a, b = run(2, nd, masked), run(0, nd, masked)                  # (2: every shape the kernel is built for; 1 = the product rule)
         assert torch.equal(a, b)
         assert torch.equal(run(1, nd, masked), b)
+        assert torch.equal(run(3, nd, masked), b)                      # (3: the half-swizzled form of the same kernel, every shape)
         np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
     assert torch.equal(run(2, sd, True), run(0, nd, True))             # entries outside the masks are never read
     r0 = 16 * (n_out // 48)
     assert torch.equal(run(2, nd, True, r0)[r0:], run(0, nd, True, r0)[r0:])
+    assert torch.equal(run(3, nd, True, r0)[r0:], run(0, nd, True, r0)[r0:]) and torch.equal(run(3, sd, True), run(0, nd, True))
     assert torch.equal(run(2, nd, True, xin=wide, ld=48, col=16), run(0, nd, True))   # rows that are not lines: the generic tiles
 
 

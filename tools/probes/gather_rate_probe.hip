@@ -24,11 +24,13 @@ __global__ void __launch_bounds__(64) k_probe(const float* __restrict__ base, ui
             if (KIND == 0) r = (state >> 8) + (uint32_t)j * 2246822519u;          // 16 distinct rows per instruction
             else if (KIND == 1) r = (state >> 8) + (uint32_t)lane * 2246822519u;  // 64 distinct rows
             else if (KIND == 3) r = (state >> 8) + (uint32_t)(lane >> 3) * 2246822519u;   // 8 distinct rows, whole 128-B lines
+            else if (KIND == 5) r = (state >> 8) + (uint32_t)j * 2246822519u;             // 16 rows, alternating halves of their lines
             else r = (state >> 8);                                                 // one 1 KiB run
             r %= n_rows;
             const float* p = KIND == 0 ? base + (size_t)r * pitch_f + 4 * g
                            : KIND == 1 ? base + (size_t)r * pitch_f + 4 * (u & 1)
                            : KIND == 3 ? base + (size_t)r * pitch_f + 4 * (lane & 7)
+                           : KIND == 5 ? base + (size_t)r * pitch_f + 4 * g + 16 * (j & 1)
                                        : base + (size_t)(r & ~15u) * pitch_f + 4 * lane;   // (pitch 16 floats: 16 rows = 1 KiB)
             v[u] = *(const f32x4*)p;
         }
@@ -44,12 +46,12 @@ int main() {
     hipMalloc(&buf, max_bytes + 4096); hipMalloc(&out, 1 << 20);
     hipMemset(buf, 0, max_bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* kinds[5] = {"gather16x64 (MFMA B fragment)", "gather64x16 (row-lane, 32-B rows)", "stream 1 KiB (weight fragment)",
-                            "gather8x128 (whole 128-B rows)", "gather16x64 of 128-B rows"};
+    const char* kinds[6] = {"gather16x64 (MFMA B fragment)", "gather64x16 (row-lane, 32-B rows)", "stream 1 KiB (weight fragment)",
+                            "gather8x128 (whole 128-B rows)", "gather16x64 of 128-B rows", "16x64, odd rows the other half"};
     const size_t sets[4] = {16 << 10, 1 << 20, 64 << 20, max_bytes};
     const char* where[4] = {"16 KiB (L1)", "1 MiB (L2)", "64 MiB (MALL)", "2 GiB (HBM)"};
     const int blocks = 256 * 16;   // 16 one-wave workgroups per CU
-    for (int kind = 0; kind < 5; ++kind)
+    for (int kind = 0; kind < 6; ++kind)
         for (int sidx = 0; sidx < 4; ++sidx) {
             const uint32_t pitch_f = kind == 1 ? 8 : kind >= 3 ? 32 : 16;   // floats per row: 32-B rows (row-lane), 128-B rows, else 64 B
             const uint32_t n_rows = (uint32_t)(sets[sidx] / (pitch_f * 4));
@@ -62,6 +64,7 @@ int main() {
                 if (kind == 2) hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(64), 0, 0, buf, n_rows, pitch_f, iters, out);
                 if (kind == 3) hipLaunchKernelGGL(k_probe<3>, dim3(blocks), dim3(64), 0, 0, buf, n_rows, pitch_f, iters, out);
                 if (kind == 4) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(64), 0, 0, buf, n_rows, pitch_f, iters, out);
+                if (kind == 5) hipLaunchKernelGGL(k_probe<5>, dim3(blocks), dim3(64), 0, 0, buf, n_rows, pitch_f, iters, out);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms, e0, e1);
             }
