@@ -239,6 +239,28 @@ int insmos_sparse_conv_rows(const float* in, int64_t n_in, int ld_in, int cin, c
                             int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre, int relu_post,
                             void* stream);
 int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* starts, void* stream);
+/* ---- tap-compacted form of the 81-tap 4D layers (csrc/spconv_tapc.hip; MinkowskiConvolution kernel_size 3, dimension 4:
+ * models/MinkowskiEngine/minkunet.py:63-124, resnet.py:110-119).  The 16-row tiles of insmos_sparse_conv pay a full MFMA pass
+ * for every (16-row group, tap) slot ANY row of the group uses -- about twice the useful passes on the 4D levels.  Here the rows of
+ * a 128-row block that HAVE a tap are packed into dense groups of 16 per tap ("items"), built once per neighbour table:
+ *   insmos_tapc_blocks(n_out)        128-row blocks of a table
+ *   insmos_tapc_words(K, n_out, c)   uint32 words of the item table for c tap classes (its counts: blocks * c int32)
+ *   insmos_tapc_build                the item table of a DENSE (every entry written) K x n_out neighbour table
+ *   insmos_conv_tap_classes          the partial chains insmos_sparse_conv sums a layer's taps in: 1 = one chain over all taps,
+ *                                    4 = tap-split tiles (taps k % 4 == 0..3, summed ((c0 + c1) + c2) + c3), 0 = neither (chunk-split
+ *                                    tiles, probe settings); a function of the layer's shape only.  The item table must be built
+ *                                    with that class count: the class count IS the summation order.
+ *   insmos_sparse_conv_tapc_rows     insmos_sparse_conv_rows on the item table: the SAME BITS (accumulators parked in LDS between
+ *                                    taps, the same fmaf chain per output element).  Cin in {8, 16, 32, 48}, Cout <= 32,
+ *                                    n_in < 2^23 - 1; EINVAL otherwise (the caller stays on insmos_sparse_conv_rows). */
+int64_t insmos_tapc_blocks(int64_t n_out);
+size_t insmos_tapc_words(int K, int64_t n_out, int n_classes);
+int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int n_classes, uint32_t* items, int32_t* n_items, void* stream);
+int insmos_conv_tap_classes(int K, int cin, int cout, int masked);
+int insmos_sparse_conv_tapc_rows(const float* in, int64_t n_in, int ld_in, int cin, const uint32_t* items, const int32_t* n_items,
+                                 int n_classes, int K, int64_t n_out, int64_t row0, const float* wpacked, const float* bias,
+                                 float* out, int ld_out, int cout, const float* res, int ld_res, int res_mode, int relu_pre,
+                                 int relu_post, void* stream);
 /* ---- B windows in ONE set of launches (replaces the per-item loop of InsMOS_Model.forward, models/models.py:313) -------
  * The batch entry points below (suffix _windows / _b) are the single-window ones with a leading window dimension; B = 1
  * gives exactly the single-window results, and every window of a batch gets the bits it gets alone.  B <= 16.

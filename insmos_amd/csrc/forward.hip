@@ -119,7 +119,8 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
     return o;
 }
 
-struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; };
+// tc / ni: the table's tap-compacted item lists (csrc/spconv_tapc.hip) for one chain ([0]) and for four tap classes ([1]), or null
+struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; uint32_t* tc[2] = {nullptr, nullptr}; int32_t* ni[2] = {nullptr, nullptr}; };
 // launch sets of this many windows or more walk compacted row-group lists in the skipping BEV layers (measured on sets of 8: the six
 // layers 1 844 -> 1 676 us per set, bench 705-712 -> 714 scans/s; ONE window is 1.4 % slower that way -- few workgroups either way,
 // and the list kernel's are heavier: profiles/r04_bev_list_ab.txt)
@@ -341,6 +342,10 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     InsmosForwardOut* out = outs;  // batch-wide figures and error details go to the first entry
     for (int b = 0; b < B; ++b) outs[b].batch = B;
     Arena A{(char*)arena, arena_bytes};
+    // INSMOS_CONV_TAPC (read per call: tools flip it inside one process): which 81-tap layers of MotionNet's levels 1..3 run in their
+    // tap-compacted form (csrc/spconv_tapc.hip; same bits): bit 0 = the tap-split layers (block3.*, block6.*, block7.conv1), bit 1 = the
+    // one-chain 16-channel layers (block2.conv2, block7.conv2), bit 2 = the one-chain 8-channel layers (block1.*, block2.conv1); 0 = off
+    const int tapc_mode = [] { const char* e = getenv("INSMOS_CONV_TAPC"); return e ? atoi(e) : 1; }();
     auto Lr = [&](const std::string& name) -> const InsmosConvW* {
         auto it = C.L.find(name);
         return it == C.L.end() ? nullptr : &it->second;
@@ -353,6 +358,17 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         if (!w) return INSMOS_EINVAL;
         if (n_out == 0) return INSMOS_OK;
         if (t && (t->K != w->K || t->n != n_out)) return INSMOS_EINVAL;
+        if (t && (t->tc[0] || t->tc[1]) && insmos::conv_precision() == 0) {
+            // the tap-compacted form of the layer, when the table carries the item lists of the layer's summation order (same bits)
+            const int ncls = insmos_conv_tap_classes(w->K, w->cin, w->cout, t->mask ? 1 : 0);
+            const int slot = ncls == 4 ? 1 : 0;
+            const int bit = ncls == 4 ? 1 : w->cin == 8 ? 4 : 2;
+            if ((ncls == 1 || ncls == 4) && (tapc_mode & bit) && t->tc[slot] && w->cout <= 32 && (w->cin == 8 || (w->cin % 16 == 0 && w->cin <= 48)) &&
+                n_in < (1ll << 23) - 1)
+                return insmos_sparse_conv_tapc_rows(x + col_in, n_in, ld_in, w->cin, t->tc[slot], t->ni[slot], ncls, w->K, n_out, row0, w->w,
+                                                    w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr, ld_res, res_mode,
+                                                    relu_pre, relu_post, cs ? cs : s);
+        }
         return insmos_sparse_conv_rows(x + col_in, n_in, ld_in, w->cin, t ? t->nbr : nullptr, t ? t->mask : nullptr, w->K,
                                        n_out, row0, w->w, w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr,
                                        ld_res, res_mode, relu_pre, relu_post, cs ? cs : s);
@@ -542,6 +558,24 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     if (s2_tab0 != s) {
         CK(tl_aux.next(&ev_tab0));
         HIP_TRY(hipEventRecord(ev_tab0, s2_tab0));
+    }
+    // Tap-compacted item lists of the level 1..3 tables (csrc/spconv_tapc.hip): the 81-tap layers of those levels run on dense
+    // per-tap groups of 16 rows instead of 16-row tiles (half of whose MFMA passes multiply absent rows) -- tapc_mode above.
+    {
+        const int tapc = tapc_mode;
+        for (int l = 1; l <= 3 && tapc; ++l) {
+            // classes the level's layers need (forward order below): [0] one chain, [1] four classes
+            const bool need[2] = {((tapc & 2) && (l == 1 || l == 2)) || ((tapc & 4) && (l == 1 || l == 2)), (tapc & 1) != 0};
+            if (n[l] >= (1ll << 23) - 1) continue;
+            for (int c = 0; c < 2; ++c) {
+                if (!need[c]) continue;
+                const int ncls = c ? 4 : 1;
+                nbr81[l].tc[c] = A.take<uint32_t>(insmos_tapc_words(81, n[l], ncls));
+                nbr81[l].ni[c] = A.take<int32_t>((size_t)insmos_tapc_blocks(n[l]) * ncls);
+                NEED_ARENA();
+                CK(insmos_tapc_build(nbr81[l].nbr, 81, n[l], ncls, nbr81[l].tc[c], nbr81[l].ni[c], s));
+            }
+        }
     }
     Table dn[3], up[3];
     for (int l = 0; l < 3; ++l) {

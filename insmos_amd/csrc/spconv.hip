@@ -886,6 +886,25 @@ int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// WHICH layers run on split tiles (four waves per 16-row tile) -- the rule is part of a layer's summation order, so it is a
+// function of the layer's shape alone (never of its row count): insmos_conv_tap_classes hands it to the tap-compacted kernel.
+// (measured on S0: splitting pays when a tile carries >= ~100 (tap, chunk, channel-tile) MFMA groups -- the
+// 81-tap C >= 32 4D layers gain 20-30 % -- and costs 30-50 % on the small-C layers that already have 10k+ tiles)
+struct SplitRule { int split_env, split_dense, split_work, tap_mod; };
+const SplitRule& split_rule() {
+    static const SplitRule r = {env_int("INSMOS_CONV_SPLIT", 1), env_int("INSMOS_CONV_SPLIT_DENSE", 1), env_int("INSMOS_CONV_SPLIT_WORK", 100),
+                                env_int("INSMOS_SPLIT_TAP_MOD", 1)};
+    return r;
+}
+bool wants_split(int K, int ck, int n16, int ntile_co, bool masked) {
+    const SplitRule& r = split_rule();
+    const bool co_ok = ntile_co == 1 || ntile_co == 2 || ntile_co == 4 || ntile_co == 8;
+    const bool wide = ntile_co >= 4;
+    const long tile_work = (long)K * (ck ? 1 : n16) * ntile_co;
+    return r.split_env && co_ok && (ck == 0 || ck == 8) &&
+           ((masked && K >= 16 && (wide || tile_work >= r.split_work)) || (!ck && wide && r.split_dense && n16 % 4 == 0 && K >= 3));
+}
+
 }  // namespace
 
 namespace insmos {
@@ -967,18 +986,8 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     // chunk is gathered once per tile instead of once per channel group, and the layer gets 4x the waves.
     int split = 1;
     bool by_chunk = false;
-    static int split_env = -1, split_dense = -1;
-    if (split_env < 0) { split_env = env_int("INSMOS_CONV_SPLIT", 1); split_dense = env_int("INSMOS_CONV_SPLIT_DENSE", 1); }
-    // (measured on S0: splitting pays when a tile carries >= ~100 (tap, chunk, channel-tile) MFMA groups -- the
-    // 81-tap C >= 32 4D layers gain 20-30 % -- and costs 30-50 % on the small-C layers that already have 10k+ tiles)
-    static int split_work = -1, tap_mod = -1;
-    if (split_work < 0) { split_work = env_int("INSMOS_CONV_SPLIT_WORK", 100); tap_mod = env_int("INSMOS_SPLIT_TAP_MOD", 1); }
-    P.tap_mod = tap_mod;
-    const bool co_ok = P.ntile_co == 1 || P.ntile_co == 2 || P.ntile_co == 4 || P.ntile_co == 8;
-    const bool wide = P.ntile_co >= 4;
-    const long tile_work = (long)K * (ck ? 1 : P.n16) * P.ntile_co;
-    if (split_env && !ident && co_ok && (ck == 0 || ck == 8) &&
-        ((mask16 && K >= 16 && (wide || tile_work >= split_work)) || (!ck && wide && split_dense && P.n16 % 4 == 0 && K >= 3))) {
+    P.tap_mod = split_rule().tap_mod;
+    if (!ident && wants_split(K, ck, P.n16, P.ntile_co, mask16 != nullptr)) {
         // operand ring of the split tiles (INSMOS_CONV_RING, probes): 0 = the defaults (3 on the tap-split tiles, 2 on the chunk-split
         // ones), 4 / 5 = deeper on the tap-split tiles, 13 = ring 3 on the chunk-split tiles.  Measured per layer on a launch set of
         // 8 (round 5, profiles/r05_knob_ab_layers.txt): none pays -- ring 3 on the chunk-split tiles costs the Cin = 128 layers 12-17 %
@@ -1210,6 +1219,20 @@ extern "C" int insmos_debug_conv_split_half(int wide, int c64) {
     g_half_wide = wide;
     g_half_c64 = c64;
     return INSMOS_OK;
+}
+
+// Partial chains a layer's output sums are made of on the tile kernels: 1 = one chain over the taps in ascending order (unsplit
+// tiles, the quad-index / row-lane / whole-row forms of them), 4 = tap-split tiles (chains over the taps k % 4 == 0..3, summed
+// ((c0 + c1) + c2) + c3), 0 = chunk-split tiles or a probe setting (no tap-compacted form).  `masked`: the table has a mask16 array.
+extern "C" int insmos_conv_tap_classes(int K, int cin, int cout, int masked) {
+    if (K <= 0 || cin <= 0 || cout <= 0) return 0;
+    const int ck = (cin == 4 || cin == 8) ? cin : 0;
+    if (!ck && cin % 16 != 0) return 0;
+    const int n16 = cin / 16, ntile_co = (cout + 15) / 16;
+    if (!wants_split(K, ck, n16, ntile_co, masked != 0)) return 1;
+    if (!ck && n16 % 4 == 0) return 0;                  // chunk-split
+    if (!pick_split(ntile_co, ck, false)) return 1;     // (no split kernel for the shape: the dispatcher stays unsplit)
+    return split_rule().tap_mod ? 4 : 0;
 }
 
 extern "C" int insmos_debug_conv_quad(int on) {

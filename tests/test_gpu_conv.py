@@ -224,6 +224,96 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
 
 
 @pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
+    (48, 32, 81, 1000, 1), (32, 32, 81, 3001, 0), (16, 32, 81, 777, 2), (32, 16, 81, 2049, 1), (16, 16, 81, 5000, 0),
+    (8, 8, 81, 4000, 1), (8, 16, 81, 300, 0), (16, 8, 81, 513, 0), (16, 16, 27, 700, 2), (32, 32, 27, 1500, 0), (48, 32, 81, 100, 0),
+    (32, 32, 81, 40000, 1)])
+def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, res_mode):
+    """csrc/spconv_tapc.hip: the rows of a 128-row block that HAVE a tap packed into dense groups of 16 per tap, accumulators parked
+    in LDS between taps -- against the 16-row tiles of insmos_sparse_conv_rows: the SAME bits for the tap-split shapes (four class
+    chains) and the one-chain shapes, every epilogue, a row suffix, row counts that are not multiples of 128, blocks in which a class
+    has no pair at all; the item table is what the oracle's compaction of the same table gives; a class count that is not the
+    layer's summation order is refused."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(K * 100 + cin + cout + 11)
+    n_in = max(n_out // 2, 40)
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    # clustered occupancy: per 64-row stretch a random set of live taps at a random density; a few stretches with no tap at all
+    nstr = (n_out + 63) // 64
+    live = rng.uniform(size=(K, nstr)) < rng.uniform(0.05, 0.9, size=(1, nstr))
+    live[:, rng.integers(0, nstr, size=max(1, nstr // 9))] = False
+    dens = rng.uniform(0.05, 1.0, size=(K, nstr))
+    on = np.repeat(live, 64, axis=1)[:, :n_out] & (rng.uniform(size=(K, n_out)) < np.repeat(dens, 64, axis=1)[:, :n_out])
+    nbr[~on] = -1
+    masks = tap_masks(nbr)
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.3)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    xd, nd, md = dev(x), dev(nbr), dev(masks.view(np.int32))
+    L = lib()
+    ncls = L.insmos_conv_tap_classes(K, layer.cin, layer.cout, 1)
+    assert ncls == (4 if K * max(layer.cin // 16, 1) * ((layer.cout + 15) // 16) >= 100 else 1)
+    nblk = L.insmos_tapc_blocks(n_out)
+    assert nblk == (n_out + 127) // 128
+    words = L.insmos_tapc_words(K, n_out, ncls)
+    tc = torch.zeros(words, dtype=torch.int32, device="cuda:0")
+    ni = torch.zeros(nblk * ncls, dtype=torch.int32, device="cuda:0")
+    _lib.check(L.insmos_tapc_build(nd.data_ptr(), K, n_out, ncls, tc.data_ptr(), ni.data_ptr(), stream()), "insmos_tapc_build")
+    torch.cuda.synchronize()
+    # the item table against a numpy compaction of the same table
+    cap = words // (nblk * ncls * 16)
+    tcn = tc.cpu().numpy().view(np.uint32).reshape(nblk, ncls, cap, 16)
+    nin = ni.cpu().numpy().reshape(nblk, ncls)
+    for b in rng.choice(nblk, size=min(nblk, 6), replace=False):
+        for c in range(ncls):
+            items = []
+            for k in range(c, K, ncls):
+                rows = np.nonzero(nbr[k, b * 128:(b + 1) * 128] >= 0)[0]
+                for g0 in range(0, len(rows), 16):
+                    grp = rows[g0:g0 + 16]
+                    ent = [(int(nbr[k, b * 128 + r]), int(r)) for r in grp] + [(0x7FFFFF, 128)] * (16 - len(grp))
+                    items.append([(e | (r << 23) | ((((k >> j) & 1) << 31) if j < 7 else 0)) for j, (e, r) in enumerate(ent)])
+            while len(items) % 3:
+                items.append([0x7FFFFF | (128 << 23)] * 16)
+            assert nin[b, c] == len(items)
+            assert np.array_equal(tcn[b, c, :len(items)], np.array(items, np.uint32).reshape(len(items), 16))
+
+    def run(tapc, row0=0):
+        out = torch.full((n_out, cout), -7.0, device="cuda:0")
+        common = (layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout, res.data_ptr() if res is not None else None,
+                  ld_res if res_mode else 0, res_mode, 1 if res_mode == 2 else 0, 1, stream())
+        if tapc:
+            _lib.check(L.insmos_sparse_conv_tapc_rows(xd.data_ptr(), n_in, cin, layer.cin, tc.data_ptr(), ni.data_ptr(), ncls, K, n_out, row0,
+                                                      *common), "insmos_sparse_conv_tapc_rows")
+        else:
+            _lib.check(L.insmos_sparse_conv_rows(xd.data_ptr(), n_in, cin, layer.cin, nd.data_ptr(), md.data_ptr(), K, n_out, row0, *common),
+                       "insmos_sparse_conv_rows")
+        torch.cuda.synchronize()
+        return out
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    a, b = run(True), run(False)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    r0 = 16 * (n_out // 37)                                            # a row suffix that starts inside a 128-row block
+    ar, br = run(True, r0), run(False, r0)
+    assert torch.equal(ar[r0:], br[r0:]) and bool((ar[:r0] == -7.0).all())   # rows below the start stay untouched
+    wrong = 1 if ncls == 4 else 4                                      # the class count is the summation order: not the caller's choice
+    out = torch.zeros((n_out, cout), device="cuda:0")
+    assert L.insmos_sparse_conv_tapc_rows(xd.data_ptr(), n_in, cin, layer.cin, tc.data_ptr(), ni.data_ptr(), wrong, K, n_out, 0,
+                                          layer.w.data_ptr(), layer.b.data_ptr(), out.data_ptr(), cout, layer.cout, None, 0, 0, 0, 1,
+                                          stream()) == -1
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
     (8, 8, 81, 40003, 1), (8, 16, 81, 5000, 0), (16, 16, 81, 33333, 1), (16, 8, 81, 2049, 0), (16, 16, 27, 40000, 2),
     (8, 16, 27, 777, 0), (16, 32, 27, 3000, 1), (8, 8, 8, 33000, 0), (16, 16, 8, 1000, 0), (16, 16, 3, 17, 0), (8, 32, 27, 4100, 0)])
 def test_quad_index_kernel_is_bitwise_the_generic_one(cin, cout, K, n_out, res_mode):
