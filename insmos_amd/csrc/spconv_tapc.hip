@@ -250,6 +250,207 @@ __global__ void __launch_bounds__(NCLS * 64) k_conv_tapc(TapcP Q) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cin = 32 -> Cout 16 with rows that ARE 128-byte lines (block7.conv1).  Probe builds of k_conv_tapc (profiles/r06_tapc_probe.txt: no
+// MFMAs / no gathers / no weight loads / accumulators in registers) all land within 15 % of the full kernel: it waits for the vector
+// memory path -- per item 2 chunk gathers of 16 rows x 64 B (a line each: 27 ns per CU) and a weight fragment per chunk and channel
+// tile -- with only the few waves per SIMD the accumulators' LDS leaves.  Two changes:
+//   * WHOLE-ROW gathers (spconv_row32.hip): lane (r = lane >> 3, q = lane & 7) reads piece q of the neighbour row of the item's row r,
+//     then of row 8 + r -- 8 lines per instruction; the neighbour indices reach those lanes by ds_bpermute from the lanes that hold
+//     the item's entries; the rows become B fragments through a wave-private 2 KiB staging buffer (rows of 128 B, 16-byte pieces
+//     XOR-swizzled by the row: conflict-free for both the writes and the fragment reads);
+//   * WEIGHT FRAGMENTS ONCE PER TAP: the items of a tap are consecutive, so an item LOADS its tap's fragments only when the tap id of
+//     the entry stream changes (a wave-uniform branch) and otherwise takes them over from the item before it (register moves).
+// Pipeline per item i: MFMAs of i | staging of i + 1 | gathers (+ weights) of i + 3 | entries of i + 6.  The accumulator rows in LDS
+// are 64 * COT bytes without padding, their 16-byte pieces XOR-swizzled by the row.  Same chain per output element: same bits.
+// Measured per layer, interleaved in one process on a launch set of 8 (profiles/r06_tapc_layers_ab.csv): block7.0.conv1 245 (tiles)
+// / 262 (k_conv_tapc) -> 185 us; with two channel tiles (Cout 32: block3.conv2, block6.conv2) the staging's extra LDS traffic and
+// the smaller occupancy lose against k_conv_tapc (119 / 193 vs 106 / 172 us), so the launcher takes it for Cout <= 16 only.
+template <int COT, int NCLS>
+__global__ void __launch_bounds__(NCLS * 64) k_conv_tapc32(TapcP Q) {
+    constexpr int AROW = COT * 64;
+    constexpr int REGION = (kRW + 1) * AROW;
+    __shared__ __attribute__((aligned(128))) unsigned char accs[NCLS][REGION];
+    __shared__ __attribute__((aligned(128))) unsigned char stg[NCLS][16 * 128];
+    const ConvP& P = Q.c;
+    const int lane = threadIdx.x & 63;
+    const uint32_t cls = NCLS == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const uint32_t blk = Q.blk0 + blockIdx.x;
+    const uint32_t n_out = P.n_out;
+    const uint32_t cout = P.cout;
+    auto aswz = [](uint32_t row, uint32_t piece) -> uint32_t {   // byte offset of 16-byte piece `piece` of accumulator row `row`
+        return COT == 2 ? row * 128u + ((piece ^ (row & 7u)) << 4) : row * 64u + ((piece ^ ((row >> 2) & 3u)) << 4);
+    };
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)P.in, 0, (int)P.in_bytes, 0x00020000);
+    constexpr uint32_t FR = 256u;
+    const uint32_t blk_stride = (uint32_t)COT * FR;
+    const uint32_t tap_stride = 2u * blk_stride;
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)((uint32_t)P.K * tap_stride * 4u), 0x00020000);
+    const size_t region = ((size_t)blk * NCLS + cls) * Q.items_cap;
+    const __amdgpu_buffer_rsrc_t rs_tc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Q.tc + region * 16u), 0, (int)(Q.items_cap * 64u), 0x00020000);
+    const uint32_t jo = (uint32_t)j * 4u;
+    // the first entries do not depend on the item count: requested before anything else (a list's capacity is >= 3 items)
+    uint32_t pr[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pr[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_tc, jo, (uint32_t)q * 64u, 0);
+    const int n_it = Q.n_items[(size_t)blk * NCLS + cls];
+
+    unsigned char* const my = &accs[cls][0];
+    unsigned char* const st = &stg[cls][0];
+    for (int o = lane * 16; o < REGION; o += 64 * 16) *(f32x4*)(my + o) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint32_t woffv[COT];
+#pragma unroll
+    for (int it = 0; it < COT; ++it) {
+        const uint32_t co = (uint32_t)it * 16u + (uint32_t)(lane & 15);
+        woffv[it] = co < cout ? ((uint32_t)it * FR + (uint32_t)lane * 4u) * 4u : 0x7FFFFFF0u;
+    }
+    // whole-row gather lanes: row r8 (then 8 + r8) of the item, piece q8; staging addresses
+    const uint32_t r8 = (uint32_t)lane >> 3, q8 = (uint32_t)lane & 7u;
+    const uint32_t st_wa = r8 * 128u + ((q8 ^ (r8 & 7u)) << 4), st_wb = (r8 + 8u) * 128u + ((q8 ^ (r8 & 7u)) << 4);   // ((r8 + 8) & 7 == r8 & 7)
+    const uint32_t st_r0 = (uint32_t)j * 128u + ((((uint32_t)g) ^ ((uint32_t)j & 7u)) << 4);
+    const uint32_t st_r1 = (uint32_t)j * 128u + ((((uint32_t)g + 4u) ^ ((uint32_t)j & 7u)) << 4);
+
+    if (n_it > 0) {
+        const int last = n_it - 1;
+        f32x4 ga[3], gb[3];          // raw row pieces of the items in flight
+        f32x4 fr[3][2];              // B fragments [slot][chunk]
+        // weight fragments [slot][chunk][channel tile]: an item either LOADS its tap's fragments (first item of a tap) or COPIES them
+        // from the item before it (register moves, no memory traffic).  (Rotating register SETS picked by a wave-uniform index were
+        // the first build: hipcc turns that into one load plus conditional copies behind an s_waitcnt vmcnt(0).)
+        f32x4 as[3][2][COT];
+        uint32_t la[3];              // LDS byte offset of the lane's first accumulator piece
+        uint32_t cur_tap = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int it = 0; it < COT; ++it) as[q][c][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define TAPC32_REQP(slot, item)                                                                                             \
+    {                                                                                                                       \
+        const int it_ = (item) < last ? (item) : last;                                                                      \
+        pr[slot] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_tc, jo, (uint32_t)it_ * 64u, 0);                       \
+    }
+#define TAPC32_LOADW(slot)                                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                           \
+        _Pragma("unroll") for (int it = 0; it < COT; ++it) {                                                                \
+            as[slot][c][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woffv[it], sw_ + (uint32_t)c * blk_stride * 4u, 0)); \
+        }
+#define TAPC32_REQAB(slot)                                                                                                  \
+    {                                                                                                                       \
+        const uint32_t p_ = pr[slot];                                                                                       \
+        const uint32_t tap_ = (uint32_t)__builtin_amdgcn_ballot_w64((p_ >> 31) != 0u) & 0x7Fu;                              \
+        const uint32_t idx_ = p_ & kNoNbr;                                                                                  \
+        const uint32_t ia_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r8 * 4u), (int)idx_);                             \
+        const uint32_t ib_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r8 + 8u) * 4u), (int)idx_);                      \
+        const uint32_t row_ = (p_ >> 23) & 0xFFu;                                                                           \
+        la[slot] = aswz(row_, (uint32_t)g);                                                                                 \
+        asm volatile("" : "+v"(la[slot]));                                                                                  \
+        if (tap_ != cur_tap) {   /* wave-uniform: the first item of a tap brings the tap's weight fragments ... */           \
+            cur_tap = tap_;                                                                                                 \
+            const uint32_t sw_ = tap_ * tap_stride * 4u;                                                                    \
+            TAPC32_LOADW(slot)                                                                                              \
+        } else {                 /* ... its other items take them over from the item before */                              \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                   \
+                _Pragma("unroll") for (int it = 0; it < COT; ++it) as[slot][c][it] = as[(slot + 2) % 3][c][it];             \
+        }                                                                                                                   \
+        const uint32_t oa_ = ia_ == kNoNbr ? 0x7FFFFFF0u : ia_ * 128u + q8 * 16u;                                           \
+        const uint32_t ob_ = ib_ == kNoNbr ? 0x7FFFFFF0u : ib_ * 128u + q8 * 16u;                                           \
+        ga[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, oa_, 0, 0));                      \
+        gb[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ob_, 0, 0));                      \
+    }
+#define TAPC32_STAGE(slot)                                                                                                  \
+    {                                                                                                                       \
+        __builtin_amdgcn_wave_barrier();   /* (scheduling only: the reads below are other lanes' writes) */                 \
+        *(f32x4*)(st + st_wa) = ga[slot];                                                                                   \
+        *(f32x4*)(st + st_wb) = gb[slot];                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                                    \
+        fr[slot][0] = *(const f32x4*)(st + st_r0);                                                                          \
+        fr[slot][1] = *(const f32x4*)(st + st_r1);                                                                          \
+        __builtin_amdgcn_wave_barrier();                                                                                    \
+    }
+#define TAPC32_MMA(slot)                                                                                                    \
+    {                                                                                                                       \
+        f32x4 acc_[COT];                                                                                                    \
+        /* channel tile 1 = pieces 4 + g: with the XOR swizzle that is the lane's address with bit 6 flipped */            \
+        _Pragma("unroll") for (int it = 0; it < COT; ++it) acc_[it] = *(const f32x4*)(my + (la[slot] ^ (uint32_t)(it * 64))); \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                       \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                   \
+                _Pragma("unroll") for (int it = 0; it < COT; ++it)                                                          \
+                    acc_[it] = MFMA(as[slot][c][it][s], fr[slot][c][s], acc_[it]);                                          \
+        _Pragma("unroll") for (int it = 0; it < COT; ++it) *(f32x4*)(my + (la[slot] ^ (uint32_t)(it * 64))) = acc_[it];    \
+    }
+        // prologue (entries of items 0..2 are in flight)
+        TAPC32_REQAB(0) TAPC32_REQP(0, 3)
+        TAPC32_REQAB(1) TAPC32_REQP(1, 4)
+        TAPC32_REQAB(2) TAPC32_REQP(2, 5)
+        TAPC32_STAGE(0)
+        int i = 0;
+        do {   // (no tail: item lists are closed with padding items up to a multiple of three)
+            TAPC32_MMA(0) TAPC32_STAGE(1) TAPC32_REQAB(0) TAPC32_REQP(0, i + 6) __builtin_amdgcn_sched_barrier(0);
+            TAPC32_MMA(1) TAPC32_STAGE(2) TAPC32_REQAB(1) TAPC32_REQP(1, i + 7) __builtin_amdgcn_sched_barrier(0);
+            TAPC32_MMA(2) TAPC32_STAGE(0) TAPC32_REQAB(2) TAPC32_REQP(2, i + 8) __builtin_amdgcn_sched_barrier(0);
+            i += 3;
+        } while (i < n_it);
+#undef TAPC32_REQP
+#undef TAPC32_LOADW
+#undef TAPC32_REQAB
+#undef TAPC32_STAGE
+#undef TAPC32_MMA
+    }
+    __syncthreads();
+
+    constexpr int QPR = COT * 4;
+    constexpr int RPP = NCLS * 64 / QPR;
+    const uint32_t q = threadIdx.x % QPR, co0 = q * 4u;
+#pragma unroll 1
+    for (int r = (int)(threadIdx.x / QPR); r < kRW; r += RPP) {
+        const uint32_t o = blk * (uint32_t)kRW + (uint32_t)r;
+        if (o >= n_out || o < Q.row_lo || co0 >= cout) continue;
+        const uint32_t ao = aswz((uint32_t)r, q);
+        f32x4 v = *(const f32x4*)(&accs[0][0] + ao);
+#pragma unroll
+        for (int p = 1; p < NCLS; ++p) v += *(const f32x4*)(&accs[p][0] + ao);
+        v += *(const f32x4*)(P.bias + co0);
+        if (P.relu_pre) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (P.res_mode == 1) {
+            const float* rp = P.res + (size_t)o * P.ld_res + co0;
+            if (P.vec_store && co0 + 3 < cout) {
+                v += *(const f32x4*)rp;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co0 + e < cout) v[e] += rp[e];
+            }
+        } else if (P.res_mode == 2) {
+            const float* rp = P.res + (size_t)o * P.ld_res + 2 * co0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co0 + e < cout) v[e] += rp[2 * e] + rp[2 * e + 1];
+        }
+        if (P.relu_post) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        float* op = P.out + (size_t)o * P.ld_out + co0;
+        if (P.vec_store && co0 + 3 < cout) {
+            *(f32x4*)op = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co0 + e < cout) op[e] = v[e];
+        }
+    }
+}
+
 typedef void (*TapcKernel)(TapcP);
 TapcKernel pick_tapc(int ck, int nch, int cot, int ncls) {
 #define CASE(NCH_, COT_, NCLS_, CK_) if (nch == NCH_ && cot == COT_ && ncls == NCLS_ && ck == CK_) return k_conv_tapc<NCH_, COT_, NCLS_, CK_>;
@@ -259,7 +460,6 @@ TapcKernel pick_tapc(int ck, int nch, int cot, int ncls) {
 #undef CASE
     return nullptr;
 }
-
 }  // namespace
 }  // namespace insmos
 
@@ -328,6 +528,14 @@ extern "C" int insmos_sparse_conv_tapc_rows(const float* in, int64_t n_in, int l
     Q.row_lo = (uint32_t)row0;
     TapcKernel kern = pick_tapc(ck, ck ? 1 : cin / 16, P.ntile_co, ncls);
     if (!kern) return INSMOS_EINVAL;
+    // Cin = 32 -> Cout <= 16 with rows that are whole 128-byte lines: whole-row gathers + weight fragments once per tap (same bits;
+    // INSMOS_TAPC_ROW32: 0 = the chunk-gather kernel, 2 = the whole-row kernel for Cout 32 too -- A/B runs; read per call)
+    const int row32 = [] { const char* e = getenv("INSMOS_TAPC_ROW32"); return e ? atoi(e) : 1; }();
+    const bool lines32 = cin == 32 && ld_in == 32 && ((uintptr_t)in & 127) == 0;
+    if (row32 && lines32 && (P.ntile_co == 1 || row32 == 2)) {
+        if (P.ntile_co == 1) kern = ncls == 4 ? k_conv_tapc32<1, 4> : k_conv_tapc32<1, 1>;
+        else kern = ncls == 4 ? k_conv_tapc32<2, 4> : k_conv_tapc32<2, 1>;
+    }
     const uint32_t n_blk = (uint32_t)insmos_tapc_blocks(n_out) - Q.blk0;
     ProfScope ps(KK_SPARSE_CONV, s);
     ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_out - row0;

@@ -226,7 +226,7 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
 @pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
     (48, 32, 81, 1000, 1), (32, 32, 81, 3001, 0), (16, 32, 81, 777, 2), (32, 16, 81, 2049, 1), (16, 16, 81, 5000, 0),
     (8, 8, 81, 4000, 1), (8, 16, 81, 300, 0), (16, 8, 81, 513, 0), (16, 16, 27, 700, 2), (32, 32, 27, 1500, 0), (48, 32, 81, 100, 0),
-    (32, 32, 81, 40000, 1)])
+    (32, 32, 81, 40000, 1), (32, 16, 81, 130, 0), (32, 8, 81, 5000, 2)])
 def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, res_mode):
     """csrc/spconv_tapc.hip: the rows of a 128-row block that HAVE a tap packed into dense groups of 16 per tap, accumulators parked
     in LDS between taps -- against the 16-row tiles of insmos_sparse_conv_rows: the SAME bits for the tap-split shapes (four class
@@ -303,6 +303,14 @@ def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, r
     a, b = run(True), run(False)
     assert torch.equal(a, b)
     np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    if cin == 32:                                                      # both gather forms of the Cin = 32 kernels (read per call)
+        import os
+        for form in ("0", "2"):
+            os.environ["INSMOS_TAPC_ROW32"] = form
+            try:
+                assert torch.equal(run(True), b), form
+            finally:
+                os.environ.pop("INSMOS_TAPC_ROW32", None)
     r0 = 16 * (n_out // 37)                                            # a row suffix that starts inside a 128-row block
     ar, br = run(True, r0), run(False, r0)
     assert torch.equal(ar[r0:], br[r0:]) and bool((ar[:r0] == -7.0).all())   # rows below the start stay untouched

@@ -110,6 +110,40 @@ def main():
                 f.write(txt + "\n")
         return
 
+    # BATCH_LAYERS_ENV="A=0;A=1,B=2;...": the same launch set under several ENVIRONMENT settings the library reads per call (e.g.
+    # INSMOS_CONV_TAPC, INSMOS_TAPC_DBG), in ONE process, interleaved BATCH_LAYERS_ROUNDS (3) times; per layer the minimum over the
+    # rounds -- box-to-box and run-to-run differences of +-20 % per layer make separate processes useless for an A/B
+    env_variants = os.environ.get("BATCH_LAYERS_ENV")
+    if env_variants:
+        vs = [v for v in env_variants.split(";") if v]
+        rounds = int(os.environ.get("BATCH_LAYERS_ROUNDS", "3"))
+        cols = {v: [] for v in vs}
+        keys = sorted({kv.split("=")[0] for v in vs for kv in v.split(",")})
+        for _ in range(rounds):
+            for v in vs:
+                for k in keys:
+                    os.environ.pop(k, None)
+                for kv in v.split(","):
+                    k, val = kv.split("=")
+                    os.environ[k] = val
+                cols[v].append(measure(2)[0])
+        for k in keys:
+            os.environ.pop(k, None)
+        tv = {v: np.min(np.stack(cols[v]), axis=0) for v in vs}
+        lines = ["layer,K,cin,cout,rows," + ",".join("us[%s]" % v.replace(",", "&") for v in vs)]
+        for i in range(n_layers):
+            name, K, cin, cout, _, _ = per_win[0][i]
+            rows = sum(pw[i][4] for pw in per_win)
+            lines.append("%s,%d,%d,%d,%d," % (name, K, cin, cout, rows) + ",".join("%.1f" % tv[v][i] for v in vs))
+        lines.append("TOTAL,,,,," + ",".join("%.1f" % float(tv[v].sum()) for v in vs))
+        txt = "\n".join(lines)
+        only = os.environ.get("BATCH_LAYERS_ONLY_K")
+        print("\n".join(l for l in lines if not only or l.split(",")[1] in ("K", only, "")))
+        if out_csv:
+            with open(out_csv, "w") as f:
+                f.write(txt + "\n")
+        return
+
     t, m = measure()
     lines = ["layer,K,cin,cout,rows,us,gflop,tflops,pct_time"]
     tot_us = float(t.sum())
