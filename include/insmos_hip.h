@@ -245,7 +245,8 @@ int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* st
  * a 128-row block that HAVE a tap are packed into dense groups of 16 per tap ("items"), built once per neighbour table:
  *   insmos_tapc_blocks(n_out)        128-row blocks of a table
  *   insmos_tapc_words(K, n_out, c)   uint32 words of the item table for c tap classes (its counts: blocks * c int32)
- *   insmos_tapc_build                the item table of a DENSE (every entry written) K x n_out neighbour table
+ *   insmos_tapc_build                the item table of a DENSE (every entry written) K x n_out neighbour table, blocks from row0 / 128
+ *                                    on (layers that run on a row suffix: the blocks below stay unwritten)
  *   insmos_conv_tap_classes          the partial chains insmos_sparse_conv sums a layer's taps in: 1 = one chain over all taps,
  *                                    4 = tap-split tiles (taps k % 4 == 0..3, summed ((c0 + c1) + c2) + c3), 0 = neither (chunk-split
  *                                    tiles, probe settings); a function of the layer's shape only.  The item table must be built
@@ -255,7 +256,8 @@ int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* st
  *                                    n_in < 2^23 - 1; EINVAL otherwise (the caller stays on insmos_sparse_conv_rows). */
 int64_t insmos_tapc_blocks(int64_t n_out);
 size_t insmos_tapc_words(int K, int64_t n_out, int n_classes);
-int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int n_classes, uint32_t* items, int32_t* n_items, void* stream);
+int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int n_classes, uint32_t* items, int32_t* n_items,
+                      void* stream);
 int insmos_conv_tap_classes(int K, int cin, int cout, int masked);
 int insmos_sparse_conv_tapc_rows(const float* in, int64_t n_in, int ld_in, int cin, const uint32_t* items, const int32_t* n_items,
                                  int n_classes, int K, int64_t n_out, int64_t row0, const float* wpacked, const float* bias,

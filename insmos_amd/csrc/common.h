@@ -67,6 +67,9 @@ int sort_pairs_u64_u32(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_
                        uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 int sort_keys_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit,
                   int end_bit, hipStream_t s);
+size_t sort_keys_u64_radix_temp(size_t n);   // ... never by merging: radix passes over [begin_bit, end_bit) only, stable
+int sort_keys_u64_radix(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, int begin_bit, int end_bit,
+                        hipStream_t s);
 int inclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t s);
 
 // ---- keys -------------------------------------------------------------------------------------------

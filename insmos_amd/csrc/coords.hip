@@ -45,6 +45,20 @@ int sort_keys_u64(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* ko
     HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, (unsigned)b0, (unsigned)b1, s));
     return INSMOS_OK;
 }
+// The same sort with rocPRIM's merge-sort path switched off: below 2^20 keys the default configuration sorts by merging -- a launch
+// per merge level (~40 for the voxeliser's ~1 M cell keys of a launch set, 260 + 50 us) over ALL 64 key bits, whatever bit range
+// was asked for -- where the radix (Onesweep) path makes one pass per 8 bits of [b0, b1) and is stable
+using radix_only_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+size_t sort_keys_u64_radix_temp(size_t n) {
+    size_t b = 0;
+    (void)rocprim::radix_sort_keys<radix_only_config>(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, n, 0, 64, (hipStream_t)0);
+    return pad256(b);
+}
+int sort_keys_u64_radix(void* tmp, size_t tmp_bytes, const uint64_t* kin, uint64_t* kout, size_t n, int b0, int b1, hipStream_t s) {
+    ProfScope ps(KK_SORT, s);
+    HIP_TRY(rocprim::radix_sort_keys<radix_only_config>(tmp, tmp_bytes, kin, kout, n, (unsigned)b0, (unsigned)b1, s));
+    return INSMOS_OK;
+}
 int inclusive_scan_i32(void* tmp, size_t tmp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t s) {
     ProfScope ps(KK_SCAN, s);
     HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::plus<int32_t>(), s));
@@ -1594,7 +1608,8 @@ extern "C" int insmos_build_nbr(const int32_t* out_coords, int64_t n_out, const 
 
 extern "C" size_t insmos_voxelize_mean_ws_bytes(int64_t n) {
     size_t N = (size_t)n;
-    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N), sr = sort_keys_u64_radix_temp(N);
+    if (sr > st) st = sr;
     return pad256(N * 8) * 2 + pad256((N + 1) * 4) * 6 + (st > sc ? st : sc) + 2048;
 }
 
@@ -1642,6 +1657,10 @@ extern "C" int insmos_voxelize_windows_phased(const float* points, int64_t n, in
     int32_t* woff = b.take<int32_t>(2 * (INSMOS_MAX_BATCH + 1) + 4);   // (+ [.. + 0] = occupied cells, kept for phase 2)
     int32_t* kept_state = woff + 2 * (INSMOS_MAX_BATCH + 1);
     size_t st = sort_keys_u64_temp(N), sc = scan_i32_temp(N);
+    {
+        const size_t sr = sort_keys_u64_radix_temp(N);
+        if (sr > st) st = sr;
+    }
     char* tmp = b.take<char>(st > sc ? st : sc);
     if (!b.ok) return INSMOS_EWORKSPACE;
     unsigned g = cdiv(n, TPB);
@@ -1659,8 +1678,12 @@ extern "C" int insmos_voxelize_windows_phased(const float* points, int64_t n, in
                       range_host[0], range_host[1], range_host[2], vsize_host[0], vsize_host[1], vsize_host[2], g3[0], g3[1],
                       g3[2], k_in, pc_voxel_id, mark, counts);
     }
-    // invalid keys are all-ones; they must sort last, so sort the full 64 bits when any may exist
-    int rc = sort_keys_u64(tmp, st, k_in, k_s, N, 0, 64, s);
+    // The keys come in point order with the point index in their low bits, so a STABLE sort of the cell field alone -- bits
+    // [VOX_IDX_BITS, end_bit): 4 radix passes for a launch set of 8 windows instead of 64 bits' worth of merging -- gives the same
+    // order as sorting whole keys.  Invalid keys are all-ones: their cell field, 2^bits - 1 >= max_lin, is above every valid cell
+    // (<= max_lin - 1), so they still sort last.  INSMOS_VOX_SORT_FULL=1: the whole-key sort (A/B; same result).
+    static const bool full_sort = [] { const char* e = getenv("INSMOS_VOX_SORT_FULL"); return e && e[0] == '1'; }();
+    int rc = full_sort ? sort_keys_u64(tmp, st, k_in, k_s, N, 0, 64, s) : sort_keys_u64_radix(tmp, st, k_in, k_s, N, VOX_IDX_BITS, end_bit, s);
     if (rc) return rc;
     {
         ProfScope ps(KK_VOX_SEGMENTS, s);
@@ -2205,7 +2228,9 @@ extern "C" int insmos_nbr_from_coarse(const int32_t* fine_coords, int64_t n_f, c
     // tap by bit arithmetic) instead of one thread per (voxel, tap): the same entries and masks (tests/test_gpu_coords.py), the
     // 785 MB table of a four-window step in a third of the time.  INSMOS_NBR125_RESOLVER=0 keeps the generic kernel.
     static const bool fast125 = [] { const char* e = getenv("INSMOS_NBR125_RESOLVER"); return !(e && e[0] == '0'); }();
-    if (fast125 && K == 125 && n_f < (1ll << 31) - 256) {
+    // (n_f < 2^24: the resolver reads the first child row out of bits 8..31 of child_mask -- the packed form k_level_down_scatter writes
+    //  only below that row count; larger sets take the generic kernel, which reads child_start itself and masks child_mask with 0xFF)
+    if (fast125 && K == 125 && n_f < (1ll << 24)) {
         bool is5 = true;
         const int st = 1 << fine_shift;
         for (int k = 0; k < 125 && is5; ++k)

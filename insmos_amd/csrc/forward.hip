@@ -120,7 +120,13 @@ std::vector<int32_t> me_offsets(const int ks[4], const int ts[4]) {
 }
 
 // tc / ni: the table's tap-compacted item lists (csrc/spconv_tapc.hip) for one chain ([0]) and for four tap classes ([1]), or null
-struct Table { int32_t* nbr; uint32_t* mask; int K; int64_t n; uint32_t* tc[2] = {nullptr, nullptr}; int32_t* ni[2] = {nullptr, nullptr}; };
+// (tc_row0: the first row the item lists are built from)
+struct Table {
+    int32_t* nbr; uint32_t* mask; int K; int64_t n;
+    uint32_t* tc[2] = {nullptr, nullptr};
+    int32_t* ni[2] = {nullptr, nullptr};
+    int64_t tc_row0[2] = {0, 0};
+};
 // launch sets of this many windows or more walk compacted row-group lists in the skipping BEV layers (measured on sets of 8: the six
 // layers 1 844 -> 1 676 us per set, bench 705-712 -> 714 scans/s; ONE window is 1.4 % slower that way -- few workgroups either way,
 // and the list kernel's are heavier: profiles/r04_bev_list_ab.txt)
@@ -363,7 +369,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
             const int ncls = insmos_conv_tap_classes(w->K, w->cin, w->cout, t->mask ? 1 : 0);
             const int slot = ncls == 4 ? 1 : 0;
             const int bit = ncls == 4 ? 1 : w->cin == 8 ? 4 : 2;
-            if ((ncls == 1 || ncls == 4) && (tapc_mode & bit) && t->tc[slot] && w->cout <= 32 && (w->cin == 8 || (w->cin % 16 == 0 && w->cin <= 48)) &&
+            if ((ncls == 1 || ncls == 4) && (tapc_mode & bit) && t->tc[slot] && row0 >= t->tc_row0[slot] && w->cout <= 32 && (w->cin == 8 || (w->cin % 16 == 0 && w->cin <= 48)) &&
                 n_in < (1ll << 23) - 1)
                 return insmos_sparse_conv_tapc_rows(x + col_in, n_in, ld_in, w->cin, t->tc[slot], t->ni[slot], ncls, w->K, n_out, row0, w->w,
                                                     w->b, o + col_out, ld_out, w->cout, res ? res + col_res : nullptr, ld_res, res_mode,
@@ -567,13 +573,17 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
             // classes the level's layers need (forward order below): [0] one chain, [1] four classes
             const bool need[2] = {((tapc & 2) && (l == 1 || l == 2)) || ((tapc & 4) && (l == 1 || l == 2)), (tapc & 1) != 0};
             if (n[l] >= (1ll << 23) - 1) continue;
+            // first row any tap-compacted layer of the level computes (the blocks below are not built): the one-chain layers are
+            // the encoder's (every row) and block7.conv2 (depth 2); the tap-split ones block3.conv1 (7), block6.conv1 (5), block7.conv1 (3)
+            const int64_t first_row[2] = {l == 1 && !(tapc & 4) ? row_from(1, 2) : 0, row_from(l, l == 3 ? 7 : l == 2 ? 5 : 3)};
             for (int c = 0; c < 2; ++c) {
                 if (!need[c]) continue;
                 const int ncls = c ? 4 : 1;
                 nbr81[l].tc[c] = A.take<uint32_t>(insmos_tapc_words(81, n[l], ncls));
                 nbr81[l].ni[c] = A.take<int32_t>((size_t)insmos_tapc_blocks(n[l]) * ncls);
+                nbr81[l].tc_row0[c] = first_row[c] & ~(int64_t)127;
                 NEED_ARENA();
-                CK(insmos_tapc_build(nbr81[l].nbr, 81, n[l], ncls, nbr81[l].tc[c], nbr81[l].ni[c], s));
+                CK(insmos_tapc_build(nbr81[l].nbr, 81, n[l], nbr81[l].tc_row0[c], ncls, nbr81[l].tc[c], nbr81[l].ni[c], s));
             }
         }
     }

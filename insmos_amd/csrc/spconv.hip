@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(SPLIT == 1 ? 64 : 256) k_sparse_conv(ConvP P) 
         // (workgroup b runs on XCD b % 8: consecutive tiles are dealt round-robin over the eight L2s.  Handing each XCD a
         //  contiguous run of tiles instead was measured: +4...29 % per layer -- the work per tile varies smoothly along the
         //  row order, so contiguous runs unbalance the XCDs; round-robin is also the better load balancer)
+        // (round 6: runs of S = 4 ... 256 consecutive units per XCD instead -- unit = ((b / 8 / S) * 8 + b % 8) * S + b / 8 % S, so that
+        //  neighbouring tiles' gathers meet in ONE L2 while the XCDs stay balanced -- measured per layer, interleaved in one process:
+        //  +-1 % on every layer, +2...30 % on the inverse maps at S = 16 / 64: the L2 is not what these kernels wait for.  Removed.)
         const uint32_t unit = blockIdx.x;
         const uint32_t tile_raw = SPLIT == 1 ? unit : unit * TPB + wib / SPLIT;
         const bool live = tile_raw < n_tiles;  // only split blocks can hold a dead tile (kept for the barriers)

@@ -48,11 +48,11 @@ struct TapcP {
 // ---------------------------------------------------------------------------------------------------------------------
 // builder: NCLS waves of a 256-thread block = the NCLS classes of one row block (NCLS = 4) or four row blocks (NCLS = 1)
 template <int NCLS>
-__global__ void __launch_bounds__(256) k_tapc_build(const int32_t* __restrict__ nbr, uint32_t n_out, int K, uint32_t n_blk,
+__global__ void __launch_bounds__(256) k_tapc_build(const int32_t* __restrict__ nbr, uint32_t n_out, int K, uint32_t blk0, uint32_t n_blk,
                                                     uint32_t items_cap, uint32_t* __restrict__ tc, int32_t* __restrict__ n_items) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t blk = NCLS == 4 ? blockIdx.x : blockIdx.x * 4u + w;
+    const uint32_t blk = blk0 + (NCLS == 4 ? blockIdx.x : blockIdx.x * 4u + w);
     const uint32_t cls = NCLS == 4 ? w : 0u;
     if (blk >= n_blk) return;   // (wave-uniform)
     const uint32_t r0 = blk * (uint32_t)kRW + (uint32_t)lane, r1 = r0 + 64u;
@@ -476,17 +476,23 @@ extern "C" size_t insmos_tapc_words(int K, int64_t n_out, int ncls) {
     return (size_t)insmos_tapc_blocks(n_out) * (size_t)ncls * tapc_items_cap(K, ncls) * 16u;
 }
 
-extern "C" int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int ncls, uint32_t* tc, int32_t* n_items, void* stream) {
-    if (!nbr || !tc || !n_items || K <= 0 || K > 128 || n_out <= 0 || (ncls != 1 && ncls != 4) || n_out * (int64_t)K * 4 >= (1ll << 31))
+// row0: only the blocks from row0 / 128 on are built (the rest of the item table stays unwritten) -- for layers that run on a row
+// suffix (insmos_sparse_conv_tapc_rows with that row0 or a later one)
+extern "C" int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int ncls, uint32_t* tc, int32_t* n_items,
+                                 void* stream) {
+    if (!nbr || !tc || !n_items || K <= 0 || K > 128 || n_out <= 0 || row0 < 0 || (ncls != 1 && ncls != 4) ||
+        n_out * (int64_t)K * 4 >= (1ll << 31))
         return INSMOS_EINVAL;
+    if (row0 >= n_out) return INSMOS_OK;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t n_blk = (uint32_t)insmos_tapc_blocks(n_out);
+    const uint32_t blk0 = (uint32_t)(row0 / kRW);
     const uint32_t cap = tapc_items_cap(K, ncls);
     ProfScope ps(KK_BUILD_NBR, s);
     if (ncls == 4)
-        INSMOS_LAUNCH(k_tapc_build<4>, dim3(n_blk), dim3(256), 0, s, nbr, (uint32_t)n_out, K, n_blk, cap, tc, n_items);
+        INSMOS_LAUNCH(k_tapc_build<4>, dim3(n_blk - blk0), dim3(256), 0, s, nbr, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
     else
-        INSMOS_LAUNCH(k_tapc_build<1>, dim3((n_blk + 3) / 4), dim3(256), 0, s, nbr, (uint32_t)n_out, K, n_blk, cap, tc, n_items);
+        INSMOS_LAUNCH(k_tapc_build<1>, dim3((n_blk - blk0 + 3) / 4), dim3(256), 0, s, nbr, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -261,7 +261,7 @@ def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, r
     words = L.insmos_tapc_words(K, n_out, ncls)
     tc = torch.zeros(words, dtype=torch.int32, device="cuda:0")
     ni = torch.zeros(nblk * ncls, dtype=torch.int32, device="cuda:0")
-    _lib.check(L.insmos_tapc_build(nd.data_ptr(), K, n_out, ncls, tc.data_ptr(), ni.data_ptr(), stream()), "insmos_tapc_build")
+    _lib.check(L.insmos_tapc_build(nd.data_ptr(), K, n_out, 0, ncls, tc.data_ptr(), ni.data_ptr(), stream()), "insmos_tapc_build")
     torch.cuda.synchronize()
     # the item table against a numpy compaction of the same table
     cap = words // (nblk * ncls * 16)
@@ -314,6 +314,12 @@ def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, r
     r0 = 16 * (n_out // 37)                                            # a row suffix that starts inside a 128-row block
     ar, br = run(True, r0), run(False, r0)
     assert torch.equal(ar[r0:], br[r0:]) and bool((ar[:r0] == -7.0).all())   # rows below the start stay untouched
+    tc2, ni2 = torch.full_like(tc, -1), torch.full_like(ni, -1)        # an item table built from that row on serves the suffix
+    _lib.check(L.insmos_tapc_build(nd.data_ptr(), K, n_out, r0, ncls, tc2.data_ptr(), ni2.data_ptr(), stream()), "insmos_tapc_build")
+    b0 = r0 // 128
+    assert torch.equal(ni2[b0 * ncls:], ni[b0 * ncls:]) and bool((ni2[:b0 * ncls] == -1).all())
+    tc, ni = tc2, ni2
+    assert torch.equal(run(True, r0)[r0:], br[r0:])
     wrong = 1 if ncls == 4 else 4                                      # the class count is the summation order: not the caller's choice
     out = torch.zeros((n_out, cout), device="cuda:0")
     assert L.insmos_sparse_conv_tapc_rows(xd.data_ptr(), n_in, cin, layer.cin, tc.data_ptr(), ni.data_ptr(), wrong, K, n_out, 0,
