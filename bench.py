@@ -97,20 +97,35 @@ def calibrate_head(model, pts, target, cache=None, tag="", load_only=False):
     eng._load_weights(sd)
 
 
-def pmc_traffic(args, wpl):
+def lib_source_hash():
+    """The content hash __graft_entry__.build_product() leaves next to the library it built (sources + headers + flags), 12 hex
+    digits: what ties a committed profile to the binary it was taken from."""
+    try:
+        with open(os.path.join(ROOT, "insmos_amd", "libinsmos_hip.so.srchash")) as f:
+            return f.read().strip()[:12]
+    except OSError:
+        return None
+
+
+def pmc_traffic(args, wpl, cfg="cfg2", profiles_dir=None, lib_hash=None):
     """HBM bytes of the conv launches from the rocprofv3 PMC passes of `bench.py --timed-only` at this configuration
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in separate passes, units and gfx950 corrections as the microarch guide
-    prescribes), committed under profiles/; null when the workload or the launch-set size differs from the profiled one."""
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")))
-    if args.n_az != 1886 or not cands:
-        return None
+    prescribes), committed under profiles/.  Returns (record, stale): record = None when there is no pass for this workload /
+    launch-set size; stale = True when the latest pass was taken from ANOTHER binary than the one loaded now (its `lib_source_hash`
+    differs from insmos_amd/libinsmos_hip.so.srchash, or it carries none) -- the line then prints traffic: null, traffic_stale: true."""
+    suffix = "" if cfg == "cfg2" else "_" + cfg
+    cands = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r0*_pmc_traffic%s.json" % suffix)))
+    if not cands or (cfg == "cfg2" and args.n_az != 1886):
+        return None, False
     path = cands[-1]   # the latest round's passes
     with open(path) as f:
         j = json.load(f)
     if int(j.get("windows_per_launch", -1)) != int(wpl):
-        return None
+        return None, False
     j["_path"] = path
-    return j
+    have = lib_hash if lib_hash is not None else lib_source_hash()
+    stale = not j.get("lib_source_hash") or j.get("lib_source_hash") != have
+    return j, stale
 
 
 def pin_host_threads(local_rank, local_world):
@@ -152,17 +167,30 @@ def timed_steps(forward, batch, gts, metrics, steps, warmup, world, dev, sync, f
         _, _, logits = forward(batch, "test")
         for lg, gt in zip(logits, gts):
             metrics.compute_confusion_matrix(lg, gt, out=cm)
+    if grouped:
+        sync()                          # (this rank's own steps done, before the gather makes it wait for the others)
+    dt_own = time.perf_counter() - t0   # ... a straggler shows in the spread of these (rank_ms_min / rank_ms_max)
     cm_all = all_gather_confusion(cm, force=force_collectives)
     sync()
+    if not grouped:
+        dt_own = time.perf_counter() - t0
     if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
+    timed_steps.last_rank_ms = (1000.0 * dt_own / steps, 1000.0 * dt_own / steps)
     if grouped:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        cdev = "cpu" if dist.get_backend() == "gloo" else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        own = torch.tensor([dt_own, -dt_own], dtype=torch.float64, device=cdev)   # one MAX all-reduce gives max and -min
+        dist.all_reduce(own, op=dist.ReduceOp.MAX)
+        timed_steps.last_rank_ms = (1000.0 * -float(own[1].item()) / steps, 1000.0 * float(own[0].item()) / steps)
     value = world * steps * len(batch) / dt   # every rank runs the same number of windows per step (weak scaling)
     return dt, value, cm_all
+
+
+timed_steps.last_rank_ms = (None, None)   # (min, max) over the ranks of a rank's OWN ms per step in the last timed region
 
 
 def emit_result_line(out):
@@ -256,20 +284,22 @@ def run_extras(dev_index):
             return None, {"error": repr(e)[:300]}
 
     out = {}
-    j, meta = leg(["--config", "cfg4", "--steps", "4", "--warmup", "2"], 500)
+    # (timeouts: a few times the legs' observed wall times -- 25 / 12 / 12 s on the round-5 driver run)
+    j, meta = leg(["--config", "cfg4", "--steps", "4", "--warmup", "2"], 150)
     out["cfg4"] = meta if j is None else dict(meta, **{
         "value": j["value"], "unit": "scans/s", "steps": j["steps"], "windows_per_step": j["config"]["windows_per_step"],
         "ms_per_window": j["ms_per_window"], "points_per_window": j["config"]["points_per_window"],
         "frac": j.get("roofline", {}).get("frac"), "parity_on_sample": j.get("parity_on_sample"),
+        "traffic": j.get("roofline", {}).get("traffic"), "traffic_stale": j.get("roofline", {}).get("traffic_stale"),
         "workload": "BASELINE.json configs[3]: 300k pts/scan, N=10, voxel 0.05 m, 1 GPU"})
-    j, meta = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline"], 400)
+    j, meta = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline"], 120)
     out["cfg5"] = meta if j is None else dict(meta, **{
         "ms_per_step": j["ms_per_step"], "value": j["value"], "unit": "windows trained / s", "steps": j["steps"],
         "windows_per_step": j["config"]["windows_per_step_per_rank"], "dtype": j["dtype"], "frac": j.get("roofline", {}).get("frac"),
         "loss": j.get("loss"),
         "workload": "BASELINE.json configs[4] on ONE GPU: forward (train mode) + four losses + backward + Adam, B = 4, fp32"})
     if j is not None:
-        jb, mb = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline", "--train-bf16"], 400)
+        jb, mb = leg(["--config", "cfg5", "--steps", "4", "--no-cpu-baseline", "--train-bf16"], 120)
         out["cfg5"]["bf16_operands"] = mb if jb is None else dict(mb, ms_per_step=jb["ms_per_step"], dtype=jb["dtype"], loss=jb.get("loss"),
                                                                   note="opt-in: bf16 operands in the convolutions' forward and d/dx, "
                                                                        "fp32 accumulate; d/dW, BatchNorm and losses fp32")
@@ -290,11 +320,26 @@ def spawn_command(n, argv, port=None):
             "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def check_enough_gpus(args, device_count=None):
+    """First contact with a node that has fewer GPUs than --gpus asks for must end at once with ONE clear line -- not in N ranks
+    that die on `invalid device ordinal`, and not in a rendezvous that waits for its timeout.  (A multi-rank dry run on one GPU
+    names the device itself: --device-index; gloo runs need no GPU.)"""
+    if args.gpus <= 1 or args.backend != "nccl" or args.device_index is not None:
+        return
+    if device_count is None:
+        device_count = torch.cuda.device_count()
+    if device_count < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {device_count} GPU(s) (torch.cuda.device_count()); "
+                         f"one rank per GPU over RCCL needs {args.gpus}.  Run --gpus {max(device_count, 1)}, or a dry run of the "
+                         "N-rank code on one GPU: --gpus N --device-index 0")
+
+
 def maybe_spawn_ranks(args, argv):
     """--gpus N > 1 without a launcher's environment: start the N ranks here and pass their output through.  Inside a launcher
     (WORLD_SIZE set) --gpus must agree with it: an 8-GPU line must never be a 1-GPU measurement in disguise."""
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None:
+        check_enough_gpus(args)
         if args.gpus > 1:
             import subprocess
             sys.stdout.flush()
@@ -303,6 +348,7 @@ def maybe_spawn_ranks(args, argv):
     if int(world_env) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks; pass --gpus {world_env} "
                          "(or run `python bench.py --gpus N` without a launcher: it starts the N ranks itself)")
+    check_enough_gpus(args)
 
 
 def read_profile(lib):
@@ -662,6 +708,8 @@ def main():
         "metric": "scans_per_sec", "value": round(value, 3), "unit": "scans/s (windows of N=10 scans, ~120k pts/scan)",
         "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "rank_ms_min": None if timed_steps.last_rank_ms[0] is None else round(timed_steps.last_rank_ms[0], 3),
+        "rank_ms_max": None if timed_steps.last_rank_ms[1] is None else round(timed_steps.last_rank_ms[1], 3),
         "dtype": "f32" if not args.conv_precision else "EXPERIMENT split-bf16x3 (NOT the product path, NOT a benchmark line)",
         "data": "synthetic",
         "config": {"workload": ("cfg-4 (BASELINE.json configs[3], NOT the headline): dense stress scene, 300k pts/scan, N=10 scans, voxel "
@@ -787,7 +835,10 @@ def main():
         total_ms = sum(v[0] for v in prof.values()) / n_win
         flops_w, flops_ref_w, gather_w = flops / W, flops_ref / W, gather / W
         ach = flops_w / (conv_ms_per_window * 1e-3) / 1e12 if conv_ms_per_window > 0 else 0.0
-        traffic = pmc_traffic(args, wpl)
+        traffic, traffic_stale = pmc_traffic(args, wpl, "cfg4" if cfg4 else "cfg2")
+        stale_path = os.path.relpath(traffic["_path"], ROOT) if traffic else None
+        if traffic_stale:
+            traffic = None
         out["roofline"] = {
             "kernel": "k_sparse_conv* / k_conv_rowlane / k_conv_row32 + k_bev_conv3x3(_list) + k_deconv_head + the constant-input first layer (the %d "
                       "convolution launches of a launch set)" % launches,
@@ -802,9 +853,13 @@ def main():
             "frac_reference_work": round(flops_ref_w / (conv_ms_per_window * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if conv_ms_per_window > 0 else 0.0,
             "traffic": round(traffic["hbm_bytes_per_launch"]) if traffic else None,
             "traffic_bytes_per_window": round(traffic["hbm_bytes_per_window"]) if traffic else None,
+            "traffic_stale": bool(traffic_stale),
             "traffic_source": ("NOT measured in this run: read from the committed %s (rocprofv3 --pmc passes of `bench.py "
-                               "--timed-only` at this configuration, tools/pmc_traffic.sh)" % os.path.relpath(traffic["_path"], ROOT))
-                              if traffic else None,
+                               "--timed-only` at this configuration, tools/pmc_traffic.sh), taken from the binary with source hash %s "
+                               "= the one loaded now" % (os.path.relpath(traffic["_path"], ROOT), traffic.get("lib_source_hash")))
+                              if traffic else
+                              ("%s was taken from another binary (its lib_source_hash != %s): re-run tools/pmc_traffic.sh"
+                               % (stale_path, lib_source_hash())) if traffic_stale else None,
             "algorithmic_gflop_per_window": round(flops_w / 1e9, 3),
             "reference_gflop_per_window": round(flops_ref_w / 1e9, 3),
             "work_note": "achieved uses the EXECUTED flops (2*pairs*Cin*Cout of the rows actually computed): MotionNet rows nothing "
@@ -869,6 +924,14 @@ def main():
                                        "boxes_oracle_gpu": [int(len(ref_pred["pred_boxes"])), int(len(pr[0][0]["pred_boxes"]))]}
         if world == 1 and not (args.no_extras or cfg4 or args.mixed_seeds or args.conv_precision or args.n_az != 1886):
             torch.cuda.empty_cache()
+            # (the headline is complete here: should a leg below hang past the caller's patience, it is already on stderr and in a file)
+            stash = json.dumps(out)
+            print("[bench] headline before the extras legs: " + stash, file=sys.stderr, flush=True)
+            try:
+                with open("/tmp/insmos_bench_headline.json", "w") as f:
+                    f.write(stash + "\n")
+            except OSError:
+                pass
             out["extras"] = run_extras(gpu)
         emit_result_line(out)
     if world > 1 or forced:

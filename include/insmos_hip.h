@@ -254,7 +254,7 @@ int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* st
  *   insmos_sparse_conv_tapc_rows     insmos_sparse_conv_rows on the item table: the SAME BITS (accumulators parked in LDS between
  *                                    taps, the same fmaf chain per output element).  Cin in {8, 16, 32, 48}, Cout <= 32,
  *                                    n_in < 2^23 - 1; EINVAL otherwise (the caller stays on insmos_sparse_conv_rows). */
-int64_t insmos_tapc_blocks(int64_t n_out);
+size_t insmos_tapc_blocks(int64_t n_out);
 size_t insmos_tapc_words(int K, int64_t n_out, int n_classes);
 int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int n_classes, uint32_t* items, int32_t* n_items,
                       void* stream);
@@ -494,6 +494,10 @@ int insmos_debug_conv_split_half(int wide, int c64);
  * staged / the half-swizzled form on every shape it is built for; -1 = INSMOS_CONV_ROW32) or on the generic tiles (0); all produce the same
  * bits (tests/test_gpu_conv.py). */
 int insmos_debug_conv_row32(int on);
+/* test / tuning hook: the chunk-split layers (Cin 64 / 128 / 256 -> Cout 64 / 128: spconv_unet.py:146-160, 181-200) on the staged
+ * 32-row kernel (csrc/spconv_wide.hip: 1 = on, the default; also INSMOS_CONV_WIDE) or on the chunk-split 16-row tiles (0); -1 = back to
+ * the environment / default.  Same bits (tests/test_gpu_conv.py). */
+int insmos_debug_conv_wide(int on);
 /* The small-channel layers (Cin, Cout in {8, 16}: MotionNet's 81-tap BasicBlocks at 8 / 16 channels, minkunet.py:55-69,
  * resnet.py:110-119, and the k2s2 maps between them) on the row-per-lane VALU kernel (csrc/spconv_rowlane.hip): mode bit 0 =
  * 8 x 8 layers with K >= 16, bit 1 = K < 16 (Cin x Cout <= 128), bit 2 = 8 x 16 / 16 x 8 with K >= 16, bit 3 = 16 x 16; 0 = off

@@ -51,7 +51,7 @@ SIGNATURES = {
     "insmos_sparse_conv_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_int,
                                         c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "insmos_tslice_starts": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
-    "insmos_tapc_blocks": (c_i64, [c_i64]),
+    "insmos_tapc_blocks": (c_sz, [c_i64]),
     "insmos_tapc_words": (c_sz, [c_int, c_i64, c_int]),
     "insmos_tapc_build": (c_int, [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "insmos_conv_tap_classes": (c_int, [c_int, c_int, c_int, c_int]),
@@ -118,6 +118,7 @@ SIGNATURES = {
     "insmos_debug_conv_quad": (c_int, [c_int]),
     "insmos_debug_conv_split_half": (c_int, [c_int, c_int]),
     "insmos_debug_conv_row32": (c_int, [c_int]),
+    "insmos_debug_conv_wide": (c_int, [c_int]),
     "insmos_debug_conv_rowlane": (c_int, [c_int, c_int]),
     "insmos_debug_conv_lds": (c_int, [c_int]),
     "insmos_debug_conv_lds_stats": (c_int, [c_vp, c_int]),

@@ -18,6 +18,7 @@
 // B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4) + reg][j = lane&15].  The contraction index of MFMA
 // step s inside a 16-channel chunk is channel c0 + 4*(lane>>4) + s (any assignment is legal as long
 // as A and B agree), which is what makes the gather a contiguous float4 per lane.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -805,20 +806,7 @@ ConvKernel pick_kernel(int cot, int jt) {
 }
 
 // split tiles: 4 waves per 16-row tile, all channel tiles per wave; contraction split by chunk (even) or by tap
-ConvKernel pick_split(int cot, int ck, bool by_chunk, int ring = 0) {
-    // (ring: INSMOS_CONV_RING = 4 / 5 -- a deeper operand ring for the small tap-split tiles, a tuning probe: same bits)
-    if (!ck && !by_chunk && ring == 4) {
-        if (cot == 1) return k_sparse_conv<1, 1, 0, false, 4, 4, false>;
-        if (cot == 2) return k_sparse_conv<2, 1, 0, false, 4, 4, false>;
-    }
-    if (!ck && !by_chunk && ring == 5) {
-        if (cot == 1) return k_sparse_conv<1, 1, 0, false, 5, 4, false>;
-        if (cot == 2) return k_sparse_conv<2, 1, 0, false, 5, 4, false>;
-    }
-    if (!ck && by_chunk && ring == 13) {   // (probe: ring 3 on the chunk-split tiles, INSMOS_CONV_RING=13)
-        if (cot == 8) return k_sparse_conv<8, 1, 0, false, 3, 4, true>;
-        if (cot == 4) return k_sparse_conv<4, 1, 0, false, 3, 4, true>;
-    }
+ConvKernel pick_split(int cot, int ck, bool by_chunk) {
     if (ck == 8) {
         if (cot == 1) return k_sparse_conv<1, 1, 8, false, 3, 4, false>;
         if (cot == 2) return k_sparse_conv<2, 1, 8, false, 3, 4, false>;
@@ -859,7 +847,8 @@ std::mutex g_split_mu;
 // tuning hooks (insmos_debug_conv_force): generic non-identity layers at an explicit (COT, JT, ring); probe builds
 int g_force_cot = 0, g_force_jt = 0, g_force_ring = 0, g_dbg = 0;
 int g_quad = -1;  // quad-index kernel for single-chunk layers: -1 = read INSMOS_CONV_QUAD (default on)
-int g_half_wide = -1, g_half_c64 = -1;  // insmos_debug_conv_split_half: -1 = environment / defaults
+// (atomics: the debug hooks may flip them while another host thread launches; every variant gives the same bits)
+std::atomic<int> g_half_wide{-1}, g_half_c64{-1};  // insmos_debug_conv_split_half: -1 = environment / defaults
 // probe variants of the kernel configurations the heavy S0 layers use (ring >= 16 selects dbg = ring / 16)
 template <int DBG>
 ConvKernel pick_probe(int cot, int jt, int ck, int split, bool by_chunk) {
@@ -991,13 +980,10 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
     bool by_chunk = false;
     P.tap_mod = split_rule().tap_mod;
     if (!ident && wants_split(K, ck, P.n16, P.ntile_co, mask16 != nullptr)) {
-        // operand ring of the split tiles (INSMOS_CONV_RING, probes): 0 = the defaults (3 on the tap-split tiles, 2 on the chunk-split
-        // ones), 4 / 5 = deeper on the tap-split tiles, 13 = ring 3 on the chunk-split tiles.  Measured per layer on a launch set of
-        // 8 (round 5, profiles/r05_knob_ab_layers.txt): none pays -- ring 3 on the chunk-split tiles costs the Cin = 128 layers 12-17 %
-        // (one more operand set per wave, one wave less per SIMD); on conv_up_m4.0 (Cin = 256) it read -10 % in a run where the
-        // layers in front of it were slowed too and +3 % with only that layer switched: a clock / power artefact, not a gain.
-        static const int ring_env = env_int("INSMOS_CONV_RING", 0);
-        ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0, ring_env);
+        // (probes of round 5, measured per layer on a launch set of 8 and REMOVED from the product dispatcher -- profiles/r05_knob_ab_layers.txt:
+        //  operand ring 4 / 5 on the tap-split tiles +0.7 / +1.9 %, ring 3 on the chunk-split tiles +12...17 % on the Cin = 128 layers,
+        //  four blocks per tile for C = 128 +3.7 %)
+        ConvKernel sk = pick_split(P.ntile_co, ck, !ck && P.n16 % 4 == 0);
         int cot_split = P.ntile_co;
         // Few row groups (one window alone: the level-4 layers have ~420): the chunk-split tiles of a wide layer leave most CUs with
         // one or two 4-wave blocks, each latency-bound on its operand loads.  Two blocks per tile, half of the channel tiles each,
@@ -1006,14 +992,11 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         //  level-4 layers, 2 592 row groups: conv_up_m4.0 501 -> 467 us, conv_up_t4.* 243 / 256 -> 226 / 228, all convolutions
         //  8 569 -> 8 474 us per set; the C = 64 level-3 layers, 5 056 groups, LOSE 18 % at half width: profiles/r05_knob_ab_layers.txt)
         static const int half_wide_env = env_int("INSMOS_CONV_SPLIT_HALF", 4096), half_c64_env = env_int("INSMOS_CONV_SPLIT_HALF_C64", 1536);
-        const int half_wide = g_half_wide >= 0 ? g_half_wide : half_wide_env, half_c64 = g_half_c64 >= 0 ? g_half_c64 : half_c64_env;
+        const int hw_ = g_half_wide.load(std::memory_order_relaxed), hc_ = g_half_c64.load(std::memory_order_relaxed);
+        const int half_wide = hw_ >= 0 ? hw_ : half_wide_env, half_c64 = hc_ >= 0 ? hc_ : half_c64_env;
         const int half_below = P.ntile_co >= 8 ? half_wide : half_c64;   // (Cout 64 keeps the single-window threshold)
-        static const int quarter_below = env_int("INSMOS_CONV_SPLIT_QUARTER", 0);   // (probe: four blocks per tile, C = 128 only)
-        if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 8 && groups < quarter_below) {
-            ConvKernel hk = pick_split(P.ntile_co / 4, ck, true);
-            if (hk) { sk = hk; cot_split = P.ntile_co / 4; }
-        } else if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
-            ConvKernel hk = pick_split(P.ntile_co / 2, ck, true, ring_env);
+        if (sk && !ck && P.n16 % 4 == 0 && P.ntile_co >= 4 && groups < half_below) {
+            ConvKernel hk = pick_split(P.ntile_co / 2, ck, true);
             if (hk) { sk = hk; cot_split = P.ntile_co / 2; }
         }
         if (sk) {
@@ -1072,6 +1055,18 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         if (rk) kern = rk;
     }
     if (!kern) return INSMOS_EINVAL;
+    // chunk-split layers with whole input rows: 32-row tiles with LDS-staged rows (spconv_wide.hip; same bits)
+    if (split == 4 && by_chunk && !ident && !cur_prec() && !g_force_cot && !g_dbg) {
+        long wb = 0;
+        ConvKernelFn wk = conv_wide_pick(P, &wb);
+        if (wk) {
+            ProfScope ps(KK_SPARSE_CONV, s);
+            ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
+            INSMOS_LAUNCH(wk, dim3((unsigned)wb), dim3(256), 0, s, P);
+            HIP_TRY(hipGetLastError());
+            return INSMOS_OK;
+        }
+    }
 
     // ---- launch shape: one ONE-WAVE block per tile (split: one 4-wave block per tile)
     const long tiles = (long)P.n_otiles * (P.ntile_co / best.cot);

@@ -19,6 +19,7 @@
 //     going through LDS, MFMAs of tap t.
 // Per output element the MFMA chain is unchanged (tap ascending, chunk 0 then 1, steps 0..3; tap-split waves own taps k % 4 == ws and
 // meet in LDS in wave order): the SAME BITS as spconv.hip (tests/test_gpu_conv.py::test_whole_row_gather_kernel_is_bitwise_the_generic_one).
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 #include "conv_common.h"
@@ -303,13 +304,15 @@ R32Kernel pick_row32(int cot, int split) {
     return nullptr;
 }
 
-int g_row32 = -1;   // insmos_debug_conv_row32: -1 = INSMOS_CONV_ROW32 (default on)
+std::atomic<int> g_row32_dbg{-1};   // insmos_debug_conv_row32 (test hook; atomic: may be flipped while another host thread launches): -1 = none
 }  // namespace
 
 // the kernel for this launch shape, or null: Cin = 32 with rows that ARE 128-byte lines (pitch 32 floats, 128-byte aligned base), a
 // neighbour table, 16-row tiles (one wave, or four tap-split waves) of 1 / 2 / 4 channel tiles
 ConvKernelFn conv_row32_pick(const ConvP& P, int cot, int jt, int split, bool by_chunk) {
-    if (g_row32 < 0) { const char* e = getenv("INSMOS_CONV_ROW32"); g_row32 = e ? atoi(e) : 1; if (g_row32 < 0 || g_row32 > 3) g_row32 = 1; }
+    static const int row32_env = [] { const char* e = getenv("INSMOS_CONV_ROW32"); const int v = e ? atoi(e) : 1; return (v < 0 || v > 3) ? 1 : v; }();
+    const int dbg = g_row32_dbg.load(std::memory_order_relaxed);
+    const int g_row32 = dbg >= 0 ? dbg : row32_env;
     if (!g_row32 || !P.nbr || P.cin != 32 || P.n16 != 2 || P.has8 || P.has4 || P.ld_in != 32 || ((uintptr_t)P.in & 127) || jt != 1 || by_chunk)
         return nullptr;
     // Where it pays (per layer on a launch set of 8, profiles/r05_row32_layers.txt): the Cout = 16 layers with a real tap list --
@@ -331,6 +334,6 @@ ConvKernelFn conv_row32_pick(const ConvP& P, int cot, int jt, int split, bool by
 
 extern "C" int insmos_debug_conv_row32(int on) {
     if (on < -1 || on > 3) return INSMOS_EINVAL;   // (2 / 3: the staged / the half-swizzled form on every shape the kernel is built for)
-    insmos::g_row32 = on;
+    insmos::g_row32_dbg.store(on, std::memory_order_relaxed);
     return INSMOS_OK;
 }

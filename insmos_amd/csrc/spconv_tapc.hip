@@ -465,7 +465,7 @@ TapcKernel pick_tapc(int ck, int nch, int cot, int ncls) {
 
 using namespace insmos;
 
-extern "C" int64_t insmos_tapc_blocks(int64_t n_out) { return n_out <= 0 ? 0 : (n_out + kRW - 1) / kRW; }
+extern "C" size_t insmos_tapc_blocks(int64_t n_out) { return n_out <= 0 ? 0 : (size_t)((n_out + kRW - 1) / kRW); }
 
 // items a (block, class) region holds: every tap of the class with all 128 rows, rounded up to the pipeline's multiple of three
 static uint32_t tapc_items_cap(int K, int ncls) { return ((uint32_t)((K + ncls - 1) / ncls) * (uint32_t)kItemsPerTap + 2u) / 3u * 3u; }

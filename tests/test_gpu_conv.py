@@ -224,6 +224,71 @@ def test_wide_masked_layers_vs_oracle_and_layout_independence(cin, cout, K, res_
 
 
 @pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
+    (128, 128, 27, 3000, 1), (64, 64, 27, 5001, 0), (256, 128, 27, 2000, 2), (128, 64, 27, 1000, 0), (64, 128, 27, 333, 0),
+    (128, 128, 3, 64, 0), (256, 64, 27, 40, 1), (64, 64, 27, 70000, 1), (128, 128, 9, 17, 0)])
+def test_wide_staged_kernel_is_bitwise_the_split_tiles(cin, cout, K, n_out, res_mode):
+    """csrc/spconv_wide.hip (32-row tiles, whole-row gathers staged once per tap in LDS, waves split by output-channel tile, four
+    chunk-class accumulators per wave) against the chunk-split 16-row tiles of spconv.hip: the SAME bits -- with and without
+    active-tap masks, a table with garbage outside its masks (sparse stores), every epilogue, a row suffix, row counts that are not
+    multiples of 32, an input view that is a column slice of wider rows, tap lists of every length."""
+    from gpu_util import dev, lib, pack_layer, stream, tap_masks
+    from insmos_amd import _lib
+    rng = np.random.default_rng(K * 100 + cin + cout + 5)
+    n_in = max(n_out // 2, 40)
+    nbr = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    ngrp = (n_out + 15) // 16
+    n_act = rng.integers(0, K + 1, size=ngrp)                         # active taps per 16-row group: every count 0..K
+    grp = np.zeros((K, ngrp), bool)
+    for gi in range(ngrp):
+        grp[rng.permutation(K)[:n_act[gi]], gi] = True
+    slot_on = np.repeat(grp, 16, axis=1)[:, :n_out]
+    nbr[~(slot_on & (rng.uniform(size=(K, n_out)) < 0.7))] = -1
+    masks = tap_masks(nbr)
+    sparse = nbr.copy()
+    sparse[~slot_on] = rng.integers(-5, n_in + 1000, size=int((~slot_on).sum()))
+    x = rng.normal(size=(n_in, cin)).astype(np.float32)
+    taps = (rng.normal(size=(K, cin, cout)) / np.sqrt(cin * K * 0.3)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    layer = pack_layer(taps, bias, cin, cout)
+    ld_res = cout if res_mode == 1 else 2 * cout
+    res = dev(rng.normal(size=(n_out, ld_res)).astype(np.float32)) if res_mode else None
+    xd, nd, sd, md = dev(x), dev(nbr), dev(sparse), dev(masks.view(np.int32))
+    wide = torch.zeros((n_in, cin + 32), device="cuda:0")             # the same rows as a column slice of wider rows
+    wide[:, 16:16 + cin] = xd
+    L = lib()
+    assert L.insmos_conv_tap_classes(K, layer.cin, layer.cout, 1) == (0 if K >= 3 else 1)   # chunk-split shapes (K >= 3)
+
+    def run(on, table, masked, row0=0, xin=xd, ld=cin, col=0):
+        assert L.insmos_debug_conv_wide(on) == 0
+        try:
+            out = torch.full((n_out, cout), -7.0, device="cuda:0")
+            _lib.check(L.insmos_sparse_conv_rows(xin.data_ptr() + 4 * col, n_in, ld, layer.cin, table.data_ptr(),
+                                                 md.data_ptr() if masked else None, K, n_out, row0, layer.w.data_ptr(),
+                                                 layer.b.data_ptr(), out.data_ptr(), cout, layer.cout,
+                                                 res.data_ptr() if res is not None else None, ld_res if res_mode else 0, res_mode,
+                                                 1 if res_mode == 2 else 0, 1, stream()), "insmos_sparse_conv_rows")
+            torch.cuda.synchronize()
+            return out
+        finally:
+            L.insmos_debug_conv_wide(-1)
+
+    ref = R.sparse_conv(x, nbr, taps) + bias
+    if res_mode == 2:
+        ref = np.maximum(ref, 0.0) + res.cpu().numpy()[:, 0::2] + res.cpu().numpy()[:, 1::2]
+    elif res_mode == 1:
+        ref = ref + res.cpu().numpy()
+    ref = np.maximum(ref, 0.0)
+    for masked in (True, False):
+        a, b = run(1, nd, masked), run(0, nd, masked)
+        assert torch.equal(a, b)
+        np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    assert torch.equal(run(1, sd, True), run(0, nd, True))            # entries outside the masks are never used
+    r0 = 16 * (n_out // 48)
+    assert torch.equal(run(1, nd, True, r0)[r0:], run(0, nd, True, r0)[r0:])
+    assert torch.equal(run(1, nd, True, xin=wide, ld=cin + 32, col=16), run(0, nd, True))
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out,res_mode", [
     (48, 32, 81, 1000, 1), (32, 32, 81, 3001, 0), (16, 32, 81, 777, 2), (32, 16, 81, 2049, 1), (16, 16, 81, 5000, 0),
     (8, 8, 81, 4000, 1), (8, 16, 81, 300, 0), (16, 8, 81, 513, 0), (16, 16, 27, 700, 2), (32, 32, 27, 1500, 0), (48, 32, 81, 100, 0),
     (32, 32, 81, 40000, 1), (32, 16, 81, 130, 0), (32, 8, 81, 5000, 2)])

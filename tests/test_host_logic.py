@@ -405,6 +405,8 @@ for r in range(world):
         for k in range(5):
             exp[(k + i + r) % 3, (k + i) % 3] += steps
 assert torch.equal(cm_all, exp), (cm_all, exp)             # counters of BOTH ranks, timed steps only
+lo, hi = bench.timed_steps.last_rank_ms                    # per-rank spread of a rank's OWN ms per step (rank_ms_min / rank_ms_max):
+assert 18.0 <= lo <= 45.0 and 58.0 <= hi <= 1000.0 * dt / steps + 1.0, (lo, hi, dt)   # the straggler (rank 1) is visible on both ranks
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank, round(dt, 3))
 """
@@ -686,3 +688,49 @@ def test_bench_result_line_is_the_last_line_of_stdout(tmp_path):
     assert json.loads(lines[-1]) == {"metric": "scans_per_sec", "value": 1.0}, lines
     assert any("banner" in l for l in lines[:-1]) and any("before the result" in l for l in lines[:-1])
     assert not any("teardown" in l or "after the result" in l for l in lines)
+
+
+def test_bench_refuses_more_ranks_than_gpus_in_one_line():
+    """First contact with a node that has fewer GPUs than --gpus: ONE clear line at once (no ranks spawned, no rendezvous timeout) --
+    the function on counts, and the real command on this GPU-less host; a one-GPU dry run (--device-index) and gloo are let through."""
+    import argparse
+    import time
+    import bench
+    ns = argparse.Namespace(gpus=8, backend="nccl", device_index=None)
+    with pytest.raises(SystemExit) as e:
+        bench.check_enough_gpus(ns, device_count=1)
+    assert "--gpus 8" in str(e.value) and "1 GPU(s)" in str(e.value) and "--device-index 0" in str(e.value)
+    bench.check_enough_gpus(ns, device_count=8)
+    bench.check_enough_gpus(argparse.Namespace(gpus=8, backend="gloo", device_index=None), device_count=0)
+    bench.check_enough_gpus(argparse.Namespace(gpus=2, backend="nccl", device_index=0), device_count=1)
+    bench.check_enough_gpus(argparse.Namespace(gpus=1, backend="nccl", device_index=None), device_count=0)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode != 0 and time.time() - t0 < 30.0, out[-1000:]
+    assert "--gpus 8 but this node shows" in out and "torch.distributed.run" not in out, out[-1000:]
+
+
+def test_bench_traffic_record_is_tied_to_the_binary(tmp_path):
+    """roofline.traffic comes from a committed PMC pass: it is only printed when that pass was taken from the binary loaded now
+    (lib_source_hash); another hash, or a record without one, reads as stale (traffic: null, traffic_stale: true)."""
+    import argparse
+    import json
+    import bench
+    args = argparse.Namespace(n_az=1886)
+    rec = {"windows_per_launch": 8, "hbm_bytes_per_launch": 1.0, "hbm_bytes_per_window": 2.0, "lib_source_hash": "abcdef012345"}
+    (tmp_path / "r06_pmc_traffic.json").write_text(json.dumps(rec))
+    j, stale = bench.pmc_traffic(args, 8, "cfg2", profiles_dir=str(tmp_path), lib_hash="abcdef012345")
+    assert j is not None and not stale and j["hbm_bytes_per_window"] == 2.0
+    j, stale = bench.pmc_traffic(args, 8, "cfg2", profiles_dir=str(tmp_path), lib_hash="0123456789ab")
+    assert j is not None and stale
+    (tmp_path / "r07_pmc_traffic.json").write_text(json.dumps({k: v for k, v in rec.items() if k != "lib_source_hash"}))
+    assert bench.pmc_traffic(args, 8, "cfg2", profiles_dir=str(tmp_path), lib_hash="abcdef012345")[1]      # latest record, no hash: stale
+    assert bench.pmc_traffic(args, 4, "cfg2", profiles_dir=str(tmp_path), lib_hash="abcdef012345") == (None, False)   # other set size
+    assert bench.pmc_traffic(args, 8, "cfg4", profiles_dir=str(tmp_path), lib_hash="abcdef012345") == (None, False)   # no cfg-4 pass
+    (tmp_path / "r06_pmc_traffic_cfg4.json").write_text(json.dumps(dict(rec, windows_per_launch=2)))
+    assert bench.pmc_traffic(args, 2, "cfg4", profiles_dir=str(tmp_path), lib_hash="abcdef012345")[1] is False
+    h = bench.lib_source_hash()
+    assert h is None or (len(h) == 12 and all(c in "0123456789abcdef" for c in h))
