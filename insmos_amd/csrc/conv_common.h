@@ -43,7 +43,7 @@ bool conv_rowlane_try(const ConvP& P, long n_rows, hipStream_t s, int* rc);
 typedef void (*ConvKernelFn)(ConvP);
 ConvKernelFn conv_row32_pick(const ConvP& P, int cot, int jt, int split, bool by_chunk);
 // spconv_wide.hip: the wide layers (Cin 64 / 128 / 256 -> Cout 64 / 128) the dispatcher would run on CHUNK-SPLIT tiles, on 32-row tiles
-// with the gathered rows staged once per tap in LDS (same bits); *blocks = 256-thread workgroups to launch; null = not applicable
+// with the gathered rows staged once per tap in LDS (same bits); *blocks = 320-thread workgroups to launch; null = not applicable
 ConvKernelFn conv_wide_pick(const ConvP& P, long* blocks);
 // [tap][p][co] position -> (ci, co) of the layer: p = 4 s + g walks the input channels in the MFMA kernels' chain order
 __host__ __device__ inline int rowlane_ci(int cin, int p) { return (cin / 4) * (p & 3) + (p >> 2); }

@@ -1062,7 +1062,7 @@ static int sparse_conv_impl(const float* in, int64_t n_in, int ld_in, int cin, c
         if (wk) {
             ProfScope ps(KK_SPARSE_CONV, s);
             ps.meta[0] = K; ps.meta[1] = cin; ps.meta[2] = cout; ps.meta[3] = n_rows;
-            INSMOS_LAUNCH(wk, dim3((unsigned)wb), dim3(256), 0, s, P);
+            INSMOS_LAUNCH(wk, dim3((unsigned)wb), dim3(320), 0, s, P);   // (four consumer waves + the producer)
             HIP_TRY(hipGetLastError());
             return INSMOS_OK;
         }
