@@ -247,6 +247,9 @@ int insmos_tslice_starts(const uint64_t* keys, int64_t n, int max_d, int32_t* st
  *   insmos_tapc_words(K, n_out, c)   uint32 words of the item table for c tap classes (its counts: blocks * c int32)
  *   insmos_tapc_build                the item table of a DENSE (every entry written) K x n_out neighbour table, blocks from row0 / 128
  *                                    on (layers that run on a row suffix: the blocks below stay unwritten)
+ *   insmos_tapc_build_masked         the same for a SPARSE table (mask16 = its active-tap bits per 16-row group, as insmos_build_nbr*
+ *                                    write them: entries outside a group's mask are unwritten memory and are not read) -- the 27-tap
+ *                                    SubMConv3d tables of the 3D UNet (models/backbones_3d/spconv_unet.py:120-207); mask16 NULL = dense
  *   insmos_conv_tap_classes          the partial chains insmos_sparse_conv sums a layer's taps in: 1 = one chain over all taps,
  *                                    4 = tap-split tiles (taps k % 4 == 0..3, summed ((c0 + c1) + c2) + c3), 0 = neither (chunk-split
  *                                    tiles, probe settings); a function of the layer's shape only.  The item table must be built
@@ -258,6 +261,8 @@ size_t insmos_tapc_blocks(int64_t n_out);
 size_t insmos_tapc_words(int K, int64_t n_out, int n_classes);
 int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int n_classes, uint32_t* items, int32_t* n_items,
                       void* stream);
+int insmos_tapc_build_masked(const int32_t* nbr, const uint32_t* mask16, int K, int64_t n_out, int64_t row0, int n_classes,
+                             uint32_t* items, int32_t* n_items, void* stream);
 int insmos_conv_tap_classes(int K, int cin, int cout, int masked);
 int insmos_sparse_conv_tapc_rows(const float* in, int64_t n_in, int ld_in, int cin, const uint32_t* items, const int32_t* n_items,
                                  int n_classes, int K, int64_t n_out, int64_t row0, const float* wpacked, const float* bias,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "insmos_tapc_blocks": (c_sz, [c_i64]),
     "insmos_tapc_words": (c_sz, [c_int, c_i64, c_int]),
     "insmos_tapc_build": (c_int, [c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "insmos_tapc_build_masked": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     "insmos_conv_tap_classes": (c_int, [c_int, c_int, c_int, c_int]),
     "insmos_sparse_conv_tapc_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int,
                                              c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),

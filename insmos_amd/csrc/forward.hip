@@ -350,7 +350,10 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
     Arena A{(char*)arena, arena_bytes};
     // INSMOS_CONV_TAPC (read per call: tools flip it inside one process): which 81-tap layers of MotionNet's levels 1..3 run in their
     // tap-compacted form (csrc/spconv_tapc.hip; same bits): bit 0 = the tap-split layers (block3.*, block6.*, block7.conv1), bit 1 = the
-    // one-chain 16-channel layers (block2.conv2, block7.conv2), bit 2 = the one-chain 8-channel layers (block1.*, block2.conv1); 0 = off
+    // one-chain 16-channel layers (block2.conv2, block7.conv2), bit 2 = the one-chain 8-channel layers (block1.*, block2.conv1); 0 = off;
+    // bit 3 (opt-in, NOT in the default: measured 81 -> 92 us per layer and set, bench +-0 -- 16-24 MFMAs per item do not carry the
+    // item pipeline's overhead; profiles/r06_tapc27_layers_ab.csv) = the 27-tap tap-split layers of the 3D UNet's level 2 (conv2.1 /
+    // conv2.2, conv_up_t2.*, conv_up_instance_block_up3: 32 / 48 -> 32 channels on the SubMConv3d table subm2, spconv_unet.py:138-144)
     const int tapc_mode = [] { const char* e = getenv("INSMOS_CONV_TAPC"); return e ? atoi(e) : 1; }();
     auto Lr = [&](const std::string& name) -> const InsmosConvW* {
         auto it = C.L.find(name);
@@ -368,7 +371,7 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
             // the tap-compacted form of the layer, when the table carries the item lists of the layer's summation order (same bits)
             const int ncls = insmos_conv_tap_classes(w->K, w->cin, w->cout, t->mask ? 1 : 0);
             const int slot = ncls == 4 ? 1 : 0;
-            const int bit = ncls == 4 ? 1 : w->cin == 8 ? 4 : 2;
+            const int bit = w->K == 27 ? 8 : ncls == 4 ? 1 : w->cin == 8 ? 4 : 2;
             if ((ncls == 1 || ncls == 4) && (tapc_mode & bit) && t->tc[slot] && row0 >= t->tc_row0[slot] && w->cout <= 32 && (w->cin == 8 || (w->cin % 16 == 0 && w->cin <= 48)) &&
                 n_in < (1ll << 23) - 1)
                 return insmos_sparse_conv_tapc_rows(x + col_in, n_in, ld_in, w->cin, t->tc[slot], t->ni[slot], ncls, w->K, n_out, row0, w->w,
@@ -861,6 +864,14 @@ static int forward_windows_impl(void* ctx, const float* const* pts_host, const i
         for (int l = 2; l <= 4; ++l) CK(build(inv[l], l - 1, l, C.d_inv, one4, two3));
         CK(build(down5, 5, 4, C.d_down5, two1, one4));
         CK(build(inv5, 4, 5, C.d_inv5, one4, two1));
+    }
+    if ((tapc_mode & 8) && nv[2] > 0 && insmos_conv_tap_classes(27, 32, 32, 1) == 4) {
+        // item lists of the level-2 SubMConv3d table for its four tap classes (csrc/spconv_tapc.hip; the table is sparse: mask16)
+        subm[2].tc[1] = A.take<uint32_t>(insmos_tapc_words(27, nv[2], 4));
+        subm[2].ni[1] = A.take<int32_t>((size_t)insmos_tapc_blocks(nv[2]) * 4);
+        subm[2].tc_row0[1] = 0;
+        NEED_ARENA();
+        CK(insmos_tapc_build_masked(subm[2].nbr, subm[2].mask, 27, nv[2], 0, 4, subm[2].tc[1], subm[2].ni[1], s));
     }
     host_mark("3D kernel maps enqueued");
     // ---- join: the caller's stream (MotionNet done) fills in the motion columns, waits for the coordinate phase, and averages

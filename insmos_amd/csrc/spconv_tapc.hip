@@ -48,8 +48,9 @@ struct TapcP {
 // ---------------------------------------------------------------------------------------------------------------------
 // builder: NCLS waves of a 256-thread block = the NCLS classes of one row block (NCLS = 4) or four row blocks (NCLS = 1)
 template <int NCLS>
-__global__ void __launch_bounds__(256) k_tapc_build(const int32_t* __restrict__ nbr, uint32_t n_out, int K, uint32_t blk0, uint32_t n_blk,
-                                                    uint32_t items_cap, uint32_t* __restrict__ tc, int32_t* __restrict__ n_items) {
+__global__ void __launch_bounds__(256) k_tapc_build(const int32_t* __restrict__ nbr, const uint32_t* __restrict__ mask16, uint32_t n_out,
+                                                    int K, uint32_t blk0, uint32_t n_blk, uint32_t items_cap, uint32_t* __restrict__ tc,
+                                                    int32_t* __restrict__ n_items) {
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t blk = blk0 + (NCLS == 4 ? blockIdx.x : blockIdx.x * 4u + w);
@@ -58,9 +59,20 @@ __global__ void __launch_bounds__(256) k_tapc_build(const int32_t* __restrict__ 
     const uint32_t r0 = blk * (uint32_t)kRW + (uint32_t)lane, r1 = r0 + 64u;
     uint32_t* out = tc + ((size_t)blk * NCLS + cls) * items_cap * 16u;
     uint32_t it_off = 0;
+    // a SPARSE table (mask16: the active-tap bits of every 16-row group) holds unwritten memory in the entries of (group, tap) pairs
+    // outside the group's mask: those are "no neighbour" and are not read
+    uint4 mk0 = make_uint4(~0u, ~0u, ~0u, ~0u), mk1 = mk0;
+    if (mask16) {
+        if (r0 < n_out) mk0 = *(const uint4*)(mask16 + (size_t)(r0 >> 4) * 4);
+        if (r1 < n_out) mk1 = *(const uint4*)(mask16 + (size_t)(r1 >> 4) * 4);
+    }
+    auto has = [](const uint4& m, int k) -> bool {
+        const uint32_t w = (k >> 5) == 0 ? m.x : (k >> 5) == 1 ? m.y : (k >> 5) == 2 ? m.z : m.w;
+        return ((w >> (k & 31)) & 1u) != 0;
+    };
     for (int k = (int)cls; k < K; k += NCLS) {
-        const int32_t e0 = r0 < n_out ? nbr[(size_t)k * n_out + r0] : -1;
-        const int32_t e1 = r1 < n_out ? nbr[(size_t)k * n_out + r1] : -1;
+        const int32_t e0 = (r0 < n_out && has(mk0, k)) ? nbr[(size_t)k * n_out + r0] : -1;
+        const int32_t e1 = (r1 < n_out && has(mk1, k)) ? nbr[(size_t)k * n_out + r1] : -1;
         const bool p0 = e0 >= 0, p1 = e1 >= 0;
         const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
         const uint32_t c0 = (uint32_t)__popcll(b0), cnt = c0 + (uint32_t)__popcll(b1);
@@ -478,8 +490,8 @@ extern "C" size_t insmos_tapc_words(int K, int64_t n_out, int ncls) {
 
 // row0: only the blocks from row0 / 128 on are built (the rest of the item table stays unwritten) -- for layers that run on a row
 // suffix (insmos_sparse_conv_tapc_rows with that row0 or a later one)
-extern "C" int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int ncls, uint32_t* tc, int32_t* n_items,
-                                 void* stream) {
+extern "C" int insmos_tapc_build_masked(const int32_t* nbr, const uint32_t* mask16, int K, int64_t n_out, int64_t row0, int ncls,
+                                        uint32_t* tc, int32_t* n_items, void* stream) {
     if (!nbr || !tc || !n_items || K <= 0 || K > 128 || n_out <= 0 || row0 < 0 || (ncls != 1 && ncls != 4) ||
         n_out * (int64_t)K * 4 >= (1ll << 31))
         return INSMOS_EINVAL;
@@ -490,11 +502,16 @@ extern "C" int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64
     const uint32_t cap = tapc_items_cap(K, ncls);
     ProfScope ps(KK_BUILD_NBR, s);
     if (ncls == 4)
-        INSMOS_LAUNCH(k_tapc_build<4>, dim3(n_blk - blk0), dim3(256), 0, s, nbr, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
+        INSMOS_LAUNCH(k_tapc_build<4>, dim3(n_blk - blk0), dim3(256), 0, s, nbr, mask16, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
     else
-        INSMOS_LAUNCH(k_tapc_build<1>, dim3((n_blk - blk0 + 3) / 4), dim3(256), 0, s, nbr, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
+        INSMOS_LAUNCH(k_tapc_build<1>, dim3((n_blk - blk0 + 3) / 4), dim3(256), 0, s, nbr, mask16, (uint32_t)n_out, K, blk0, n_blk, cap, tc, n_items);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
+}
+
+extern "C" int insmos_tapc_build(const int32_t* nbr, int K, int64_t n_out, int64_t row0, int ncls, uint32_t* tc, int32_t* n_items,
+                                 void* stream) {
+    return insmos_tapc_build_masked(nbr, nullptr, K, n_out, row0, ncls, tc, n_items, stream);
 }
 
 extern "C" int insmos_sparse_conv_tapc_rows(const float* in, int64_t n_in, int ld_in, int cin, const uint32_t* tc, const int32_t* n_items,

@@ -18,15 +18,15 @@
 //     adds them in that order in its epilogue: THE SAME BITS (tests/test_gpu_conv.py::test_wide_staged_kernel_is_bitwise_the_split_tiles).
 // Cin = 256 rows (1 KiB) are staged in two halves (chunks 0..7, then 8..15: the class chains' chunk order is kept).
 //
-// STATUS (round 6, measured: profiles/r06_wide_*.csv): OPT-IN (INSMOS_CONV_WIDE=1), the chunk-split tiles stay the default.  Same bits,
-// but 1.2-1.6x SLOWER on the 64 / 128-channel layers (conv4.1.0: 217 us split, 303 us here).  The probe builds (INSMOS_WIDE_PROBE) say
-// why: without gathers AND without weight loads the kernel still needs 230 us -- it is MFMA-bound, and so are the split tiles: in the
-// device's row order a 16-row group of these levels executes 1.41 (128 ch) / 1.54 (64 ch) passes per useful one (tools/wide_stats.py),
-// so the split tiles' 83 TFLOP/s useful are 117 TFLOP/s EXECUTED = 0.85 of the fp32 MFMA rate the chip sustains.  The load side this
-// kernel improves (half the fragment traffic, whole-line gathers) was never the limit; what it adds -- one barrier per tap for five
-// waves, 1 296 heavy workgroups for 256 CUs where the split tiles have 2 592 light ones -- costs.  The lever that is left on these
-// layers is the absent-row passes (per-tap compaction over 128-row blocks: 1.08 / 1.10 issued per useful), which needs accumulators
-// parked in LDS and therefore ONE summation chain per element -- not the split tiles' four class chains, i.e. different bits.
+// STATUS (round 6, measured: profiles/r06_wide_layers_ab.csv, r06_wide_probe_layers.csv): OPT-IN (INSMOS_CONV_WIDE=1), the chunk-split
+// tiles stay the default.  Same bits, but 1.2-1.6x SLOWER on the 64 / 128-channel layers (conv4.1.0: 217 us split, 303 us here).  The
+// probe builds (INSMOS_WIDE_PROBE) say where the time is: without gathers AND without weight loads the kernel still needs 230 us, and
+// without MFMAs 16 us -- the load side this kernel improves (half the fragment traffic, whole-line gathers) was not the limit of these
+// layers; what the kernel adds -- one barrier per tap for five waves, 1 296 heavy workgroups (three resident per CU) for 256 CUs
+// where the split tiles have 2 592 light ones -- costs MFMA issue slots.  The split tiles already run these layers at 94 TFLOP/s
+// useful x 1.14 issued / useful (regrouped row order, DESIGN.md 3.5: 17.5 active slots per group for 15.3 valid taps per row)
+// = 108 TFLOP/s executed = 0.78 of the fp32 MFMA rate the chip sustains (139 TFLOP/s).  (tools/wide_stats.py prints the issued /
+// useful ratios of the GENERATED row order -- the step path does not regroup: 1.41 at level 4, 1.54 at level 3.)
 #include <atomic>
 #include <cstdlib>
 #include "common.h"

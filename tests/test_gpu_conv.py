@@ -368,6 +368,25 @@ def test_tap_compacted_kernel_is_bitwise_the_tile_kernels(cin, cout, K, n_out, r
     a, b = run(True), run(False)
     assert torch.equal(a, b)
     np.testing.assert_allclose(a.cpu().numpy(), ref, **TOL)
+    # a SPARSE table (entries of (16-row group, tap) pairs outside the group's mask are unwritten: garbage here) through the masked
+    # builder: the same item table
+    group_has = ((masks.reshape(-1, 4)[:, np.arange(K) >> 5] >> (np.arange(K) & 31)) & 1).astype(bool).T    # (K, groups)
+    garbage = nbr.copy()
+    off_mask = ~np.repeat(group_has, 16, axis=1)[:, :n_out]
+    assert not (off_mask & (nbr >= 0)).any()
+    garbage[off_mask] = rng.integers(0, n_in, size=int(off_mask.sum()))
+    tc2 = torch.zeros(words, dtype=torch.int32, device="cuda:0")
+    ni2 = torch.zeros(nblk * ncls, dtype=torch.int32, device="cuda:0")
+    gd = dev(garbage)
+    _lib.check(L.insmos_tapc_build_masked(gd.data_ptr(), md.data_ptr(), K, n_out, 0, ncls, tc2.data_ptr(), ni2.data_ptr(), stream()),
+               "insmos_tapc_build_masked")
+    torch.cuda.synchronize()
+    assert torch.equal(ni2, ni)
+    t1 = tc.cpu().numpy().reshape(nblk, ncls, cap, 16)
+    t2 = tc2.cpu().numpy().reshape(nblk, ncls, cap, 16)
+    for b_ in range(nblk):
+        for c in range(ncls):
+            assert np.array_equal(t1[b_, c, :nin[b_, c]], t2[b_, c, :nin[b_, c]])
     if cin == 32:                                                      # both gather forms of the Cin = 32 kernels (read per call)
         import os
         for form in ("0", "2"):
