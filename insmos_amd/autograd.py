@@ -399,6 +399,33 @@ def batch_norm_train_seg(x, gamma, beta, plan, running_mean=None, running_var=No
     return BatchNormSegFunction.apply(x, gamma, beta, eps, relu, plan, running_mean, running_var, momentum)
 
 
+class GatherRowsFunction(torch.autograd.Function):
+    """y = x[index] for an (n, C) matrix and an int64 index whose rows may repeat (the point -> voxel gather of the two heads:
+    spconv_unet.py:408-410, motionnet.py:42-46).  torch's backward of advanced indexing sorts the index on every call
+    (indexing_backward_kernel: 0.9 ms per call on the 480 k points of a B = 4 step, profiles/r05_cfg5_host_profile.txt).  The
+    gradient of a gather is one scatter-add; to keep it DETERMINISTIC (the data-parallel tests compare two backward passes bit
+    for bit) the rows are added as 2^-40 fixed-point int64 -- integer atomics commute -- and converted back: the sum is exact to
+    9e-13 absolute, |row gradient sums| < 8e6."""
+    SCALE = float(1 << 40)
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.n = x.shape[0]
+        return x[index]
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        q = (g.double() * GatherRowsFunction.SCALE).round_().long()
+        acc = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=torch.int64, device=g.device).index_add_(0, index, q)
+        return (acc.double() / GatherRowsFunction.SCALE).to(g.dtype), None
+
+
+def gather_rows(x, index):
+    return GatherRowsFunction.apply(x, index)
+
+
 class MosLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, gt, class_weights, ignore_mask):

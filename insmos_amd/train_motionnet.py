@@ -12,7 +12,7 @@ transposed map of a strided layer is its transposed-conv twin, dn <-> up).  What
 import torch
 
 from . import params as P
-from .autograd import BnPlan, batch_norm_train_seg, mos_loss, sparse_conv
+from .autograd import BnPlan, batch_norm_train_seg, gather_rows, mos_loss, sparse_conv
 from .engine import Engine
 
 
@@ -120,7 +120,7 @@ class MotionNetTrainer:
         out = self._block("block8.0", torch.cat([out, out_p1], 1), n81[0], plans[0])
         motion = sparse_conv(out, p["final.kernel"], p["final.bias"], None)  # (n0, 3)
         cur = torch.nonzero((pts[:, 4] / self.dt) == 0).flatten()  # motionnet.py:42-46 (window-major, input order inside a window)
-        m = motion[T["inverse"].long()[cur]]
+        m = gather_rows(motion, T["inverse"].long()[cur])
         if B == 1:
             return [m]
         ncur = [int(((q[:, 4] / self.dt) == 0).sum()) for q in pts_list]

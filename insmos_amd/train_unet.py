@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import params as P
-from .autograd import BnPlan, batch_norm_train_seg, center_assign_targets, center_head_loss, mos_loss, sparse_conv
+from .autograd import BnPlan, batch_norm_train_seg, center_assign_targets, center_head_loss, gather_rows, mos_loss, sparse_conv
 from .engine import Engine
 
 
@@ -242,7 +242,7 @@ class UNetV2Trainer:
         seg = self._cbr_cat("conv_up_instance_block_up1.0", "conv_up_instance_block_up1.1", x, oh[1], subm[1], plan[1])
         vox = sparse_conv(seg, p["mos_seg_layer.weight"], p["mos_seg_layer.bias"], None)      # Linear(16 -> 3)
         pcid = T["pcid"][:cur.shape[0]]
-        point_logits = vox[pcid.clamp(min=0)] * (pcid >= 0)[:, None].float()  # dropped points get zeros (:410)
+        point_logits = gather_rows(vox, pcid.clamp(min=0)) * (pcid >= 0)[:, None].float()  # dropped points get zeros (:410)
         pl_split = torch.split(point_logits, n_cur, 0)
         outs = []
         for b in range(B):
