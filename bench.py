@@ -840,7 +840,7 @@ def main():
         if traffic_stale:
             traffic = None
         out["roofline"] = {
-            "kernel": "k_sparse_conv* / k_conv_rowlane / k_conv_row32 + k_bev_conv3x3(_list) + k_deconv_head + the constant-input first layer (the %d "
+            "kernel": "k_sparse_conv* / k_conv_rowlane / k_conv_row32 / k_conv_tapc* + k_bev_conv3x3(_list) + k_deconv_head + the constant-input first layer (the %d "
                       "convolution launches of a launch set)" % launches,
             "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),

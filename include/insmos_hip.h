@@ -685,9 +685,11 @@ int insmos_col_sum(const float* a, int ld, int c, int64_t n, float* out, int acc
  * models/models.py:313 walks the batch item by item, so a BatchNorm layer sees one window's rows at a time).  chunks: n_chunks x 4
  * int32 (row_start, row_end, segment, 0), <= 1024 rows of ONE segment each, sorted by segment; seg_first (S + 1): chunk ranges;
  * seg_rows (S): rows per segment; stats: S x 3c ([mean | invstd | biased var] per segment).  All device arrays.  S = 1 is the plain
- * layer.  ticket: one zero int32 on the device (the statistics kernels fold their partials in the block that finishes last; it is
- * left zero).  Forward = 2 launches: statistics (+ merge + running statistics, item after item), apply; backward = 2: both sums
- * (+ merge), dx. */
+ * layer.  ticket: one zero int32 on the device (the SCALAR statistics kernels -- widths the 16-byte kernels do not take -- fold their
+ * partials in the block that finishes last; it is left zero).  The 16-byte kernels (c / 4 a power of two <= 64: every layer of the two
+ * networks) run forward = 3 launches: statistics partials per chunk quarter, their merge (+ running statistics, item after item),
+ * apply; backward = 3: both sums' partials, merge, dx (round 6: the last-block ticket cost ~0.1 us per block, serialised, and the
+ * merge ran in one block: 58 -> 28 us for a 1.57 M x 8 layer's statistics, 430 -> 128 us for the 300 k x 256 deblock layer). */
 size_t insmos_batchnorm_seg_ws_floats(int n_chunks, int c, int S);
 int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int64_t n, const int32_t* chunks, int n_chunks,
                                  const int32_t* seg_first, const int32_t* seg_rows, int S, const float* gamma, const float* beta,
@@ -697,6 +699,16 @@ int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const float* y, in
                                   const int32_t* chunks, int n_chunks, const int32_t* seg_first, const int32_t* seg_rows, int S,
                                   const float* gamma, const float* stats, int relu, float* dx, int ld_dx, float* dgamma,
                                   float* dbeta, int32_t* ticket, float* ws, void* stream);
+/* The same layer WITHOUT the stored x^ (round 6): insmos_batchnorm_seg_forward accepts xhat = NULL when
+ * insmos_batchnorm_seg_recompute_ok(c, ld_x, ld_dy, ld_dx) (the 16-byte kernels: c / 4 a power of two <= 64, pitches multiples of 4
+ * floats, 16-byte aligned pointers); the caller keeps the layer's input x instead and calls insmos_batchnorm_seg_backward_x, which
+ * recomputes x^ = (x - mean) * invstd and the ReLU mask (gamma * x^ + beta > 0) from it: the same gradients bit for bit, 9 instead
+ * of 12 passes over the layer's elements per forward + backward. */
+int insmos_batchnorm_seg_recompute_ok(int c, int ld_x, int ld_dy, int ld_dx);
+int insmos_batchnorm_seg_backward_x(const float* dy, int ld_dy, const float* x, int ld_x, int c, int64_t n, const int32_t* chunks,
+                                    int n_chunks, const int32_t* seg_first, const int32_t* seg_rows, int S, const float* gamma,
+                                    const float* beta, const float* stats, int relu, float* dx, int ld_dx, float* dgamma,
+                                    float* dbeta, int32_t* ticket, float* ws, void* stream);
 size_t insmos_batchnorm_ws_floats(int64_t n, int c);
 int insmos_batchnorm_train_forward(const float* x, int ld_x, int c, int64_t n, const float* gamma, const float* beta, float eps,
                                    int relu, float* y, int ld_y, float* xhat, float* stats, float* ws, void* stream);

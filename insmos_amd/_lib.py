@@ -162,6 +162,9 @@ SIGNATURES = {
                                              c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "insmos_batchnorm_seg_backward": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp,
                                               c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "insmos_batchnorm_seg_recompute_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "insmos_batchnorm_seg_backward_x": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp,
+                                                c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "insmos_batchnorm_ws_floats": (c_sz, [c_i64, c_int]),
     "insmos_batchnorm_train_forward": (c_int, [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_f32, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "insmos_batchnorm_train_backward": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp, c_int, c_vp,

@@ -339,6 +339,10 @@ class BnPlan:
         return cls(zip(starts, ends, ids), n, n_seg, seg.device)
 
 
+# INSMOS_BN_RECOMPUTE=0: the segmented BatchNorm stores x^ again (12 passes over a layer's elements per step instead of 9)
+BN_RECOMPUTE = os.environ.get("INSMOS_BN_RECOMPUTE", "1") != "0"
+
+
 class BatchNormSegFunction(torch.autograd.Function):
     """BatchNorm1d in training mode with per-segment statistics (BnPlan), fused ReLU; forward and backward are HIP kernels."""
 
@@ -353,24 +357,30 @@ class BatchNormSegFunction(torch.autograd.Function):
         if n != plan.n_rows:
             raise ValueError(f"BatchNorm plan covers {plan.n_rows} rows, the input has {n}")
         y = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        xhat = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        # x^ is not stored when the 16-byte kernels apply: x is kept instead and the backward recomputes x^ and the ReLU mask from it
+        # (the same bits; one store pass and two read passes over the layer's elements fewer -- csrc/train.hip RECOMP)
+        recomp = (BN_RECOMPUTE and bool(lib.insmos_batchnorm_seg_recompute_ok(c, x.stride(0), c, c)) and x.data_ptr() % 16 == 0)
+        xhat = None if recomp else torch.empty((n, c), dtype=torch.float32, device=x.device)
         stats = torch.empty(plan.S * 3 * c, dtype=torch.float32, device=x.device)
         tab = plan.table(c)
         ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(tab.n_chunks, c, plan.S)), dtype=torch.float32, device=x.device)
         g32, b32 = gamma.contiguous().float(), beta.contiguous().float()
         _lib.check(lib.insmos_batchnorm_seg_forward(
             x.data_ptr(), x.stride(0), c, n, tab.chunks.data_ptr(), tab.n_chunks, tab.seg_first.data_ptr(), plan.seg_rows.data_ptr(),
-            plan.S, g32.data_ptr(), b32.data_ptr(), float(eps), 1 if relu else 0, y.data_ptr(), c, xhat.data_ptr(), stats.data_ptr(),
+            plan.S, g32.data_ptr(), b32.data_ptr(), float(eps), 1 if relu else 0, y.data_ptr(), c,
+            xhat.data_ptr() if xhat is not None else None, stats.data_ptr(),
             running_mean.data_ptr() if running_mean is not None else None, running_var.data_ptr() if running_var is not None else None,
             float(momentum), plan.ticket.data_ptr(), ws.data_ptr(), st), "insmos_batchnorm_seg_forward")
-        ctx.save_for_backward(y, xhat, g32, stats)
-        ctx.relu, ctx.plan = bool(relu), plan
+        if recomp:
+            ctx.save_for_backward(x, g32, b32, stats)
+        else:
+            ctx.save_for_backward(y, xhat, g32, stats)
+        ctx.relu, ctx.plan, ctx.recomp = bool(relu), plan, recomp
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        y, xhat, gamma, stats = ctx.saved_tensors
         plan = ctx.plan
         st = _stream(dy.device)
         dy = dy.contiguous().float()
@@ -380,6 +390,15 @@ class BatchNormSegFunction(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
         tab = plan.table(c)
         ws = torch.empty(int(lib.insmos_batchnorm_seg_ws_floats(tab.n_chunks, c, plan.S)), dtype=torch.float32, device=dy.device)
+        if ctx.recomp:   # (dy is a contiguous (n, c) fp32 matrix with c % 4 == 0: rows start on the 16-byte grid)
+            x, gamma, beta, stats = ctx.saved_tensors
+            _lib.check(lib.insmos_batchnorm_seg_backward_x(
+                dy.data_ptr(), c, x.data_ptr(), x.stride(0), c, n, tab.chunks.data_ptr(), tab.n_chunks, tab.seg_first.data_ptr(),
+                plan.seg_rows.data_ptr(), plan.S, gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), 1 if ctx.relu else 0,
+                dx.data_ptr(), c, dgamma.data_ptr(), dbeta.data_ptr(), plan.ticket.data_ptr(), ws.data_ptr(), st),
+                "insmos_batchnorm_seg_backward_x")
+            return dx, dgamma, dbeta, None, None, None, None, None, None
+        y, xhat, gamma, stats = ctx.saved_tensors
         _lib.check(lib.insmos_batchnorm_seg_backward(
             dy.data_ptr(), c, y.data_ptr(), c, xhat.data_ptr(), c, n, tab.chunks.data_ptr(), tab.n_chunks, tab.seg_first.data_ptr(),
             plan.seg_rows.data_ptr(), plan.S, gamma.data_ptr(), stats.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), c,

@@ -712,39 +712,59 @@ __device__ __forceinline__ void bn_reduce_rows(bn_f4 (&v)[NV], bn_f4* __restrict
     __syncthreads();
 }
 
-// grid (chunks); block 256; G = c / 4 = 1 << L4 channel groups (G <= 64)
+// rows [ra, rb) of quarter y of a chunk (the split of k_bnseg_apply_v4 / k_bnseg_bwd_dx_v4; a short chunk leaves quarters empty)
+__device__ __forceinline__ void bn_quarter(const BnChunk& ch, int y, int& ra, int& rb) {
+    const int rows = ch.r1 - ch.r0, q = (rows + 3) / 4;
+    ra = ch.r0 + y * q;
+    rb = min(ra + q, ch.r1);
+    if (rb < ra) rb = ra;
+}
+__device__ __forceinline__ int bn_quarter_rows(const BnChunk& ch, int y) {
+    int ra, rb;
+    bn_quarter(ch, y, ra, rb);
+    return rb - ra;
+}
+
+// Round 6: the two REDUCTION kernels (statistics, backward sums) no longer fold their partials in "the block that finishes last".
+// Measured (tools/bn_kernel_probe.sh, tools/bn_camp_probe.sh): the ticket -- a device-scope fence + one atomic on ONE address per
+// block -- costs ~0.1 us PER BLOCK, serialised (1.57 M x 8: 58 us on 384 blocks, 91-104 us on 768; the element-wise kernels of the
+// same layer move twice the bytes in 16-24 us), and the merge itself ran in one block after all others (350 of the 430 us of the
+// 256-channel deblock layer).  Now: grid (chunks, 4) -- one QUARTER of a chunk per block, partial slot = 4 chunk + quarter, no fence,
+// no ticket -- and a second small launch that merges the slots in parallel (a block per few channel groups, 16-byte loads, eight
+// slots in flight per thread, float64 sums without a division):
+//   N = sum n_b,  A = sum n_b mean_b,  Q = sum (M2_b + n_b mean_b^2);   mean = A / N,  var = (Q - A mean) / N
+// (float64 over fp32 partials: the cancellation in Q - A mean costs ~(mean / std)^2 x 1e-16 relative).
+// grid (chunks, 4); block 256; G = c / 4 = 1 << L4 channel groups (G <= 64)
 __global__ void __launch_bounds__(256) k_bnseg_stats_v4(const float* __restrict__ x, int ld, int c, int L4, const BnChunk* __restrict__ chunks,
-                                                        float* __restrict__ part, int* __restrict__ counter,
-                                                        const int* __restrict__ seg_first, const int* __restrict__ seg_rows, int S, float eps,
-                                                        float* __restrict__ stats, float momentum, float* __restrict__ rmean,
-                                                        float* __restrict__ rvar) {
+                                                        float* __restrict__ part) {
     __shared__ bn_f4 smv[256];
-    __shared__ double sagg[256][3];
     const BnChunk ch = chunks[blockIdx.x];
+    int qa, qb;
+    bn_quarter(ch, (int)blockIdx.y, qa, qb);
+    const int pslot = (int)blockIdx.x * 4 + (int)blockIdx.y;
     const int G = 1 << L4, t = threadIdx.x;
     const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
     // (a thread's rows are requested BN_U at a time and added in row order: the same sum chain as a one-row loop, with BN_U loads in
-    //  flight per thread instead of one -- at one block per chunk these loops were a chain of memory latencies, 66 us per launch
-    //  for a 16 us byte stream: profiles/r04_rocprof_kernel_stats_cfg5.csv)
+    //  flight per thread instead of one)
     bn_f4 acc[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
     {
-        int r = ch.r0 + rl;
-        for (; r + (BN_U - 1) * RL < ch.r1; r += BN_U * RL) {
+        int r = qa + rl;
+        for (; r + (BN_U - 1) * RL < qb; r += BN_U * RL) {
             bn_f4 v[BN_U];
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) v[u] = *(const bn_f4*)(x + (int64_t)(r + u * RL) * ld + 4 * cg);
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) acc[0] += v[u];
         }
-        for (; r < ch.r1; r += RL) acc[0] += *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg);
+        for (; r < qb; r += RL) acc[0] += *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg);
     }
     bn_reduce_rows<1>(acc, smv, G);
-    const float inv = 1.0f / (float)(ch.r1 - ch.r0);
+    const float inv = qb > qa ? 1.0f / (float)(qb - qa) : 0.f;
     const bn_f4 mean = acc[0] * inv;
     bn_f4 m2[1] = {(bn_f4){0.f, 0.f, 0.f, 0.f}};
     {
-        int r = ch.r0 + rl;
-        for (; r + (BN_U - 1) * RL < ch.r1; r += BN_U * RL) {
+        int r = qa + rl;
+        for (; r + (BN_U - 1) * RL < qb; r += BN_U * RL) {
             bn_f4 v[BN_U];
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) v[u] = *(const bn_f4*)(x + (int64_t)(r + u * RL) * ld + 4 * cg);
@@ -754,62 +774,96 @@ __global__ void __launch_bounds__(256) k_bnseg_stats_v4(const float* __restrict_
                 m2[0] += d * d;
             }
         }
-        for (; r < ch.r1; r += RL) {
+        for (; r < qb; r += RL) {
             const bn_f4 d = *(const bn_f4*)(x + (int64_t)r * ld + 4 * cg) - mean;
             m2[0] += d * d;
         }
     }
     bn_reduce_rows<1>(m2, smv, G);
     if (rl == 0) {
-        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 0) * c + 4 * cg) = mean;
-        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 1) * c + 4 * cg) = m2[0];
+        *(bn_f4*)(part + ((int64_t)pslot * 2 + 0) * c + 4 * cg) = mean;
+        *(bn_f4*)(part + ((int64_t)pslot * 2 + 1) * c + 4 * cg) = m2[0];
     }
-    if (!last_block_done(counter, (int)gridDim.x)) return;
-    // (merge per (segment, channel): the code of k_bnseg_stats)
-    const int pairs = S * c;
+}
+
+// channel groups a merge block owns (all S segments of each: the running statistics / dgamma, dbeta of a channel need every segment)
+__host__ __device__ inline int bn_merge_groups_per_block(int S) { return S >= 8 ? 1 : 8 / S; }   // (few pairs per block: 32+ threads walk one pair's slots)
+
+// grid (ceil(G / GB)); block 256: `tpp` threads share a (channel group, segment) pair, each over a contiguous run of the segment's
+// partial slots (table order), then one of them adds their sums in thread order: the result depends on (S, c, chunk table) only
+__global__ void __launch_bounds__(256) k_bnseg_stats_merge_v4(const float* __restrict__ part, int c, int L4, const BnChunk* __restrict__ chunks,
+                                                              const int* __restrict__ seg_first, const int* __restrict__ seg_rows, int S,
+                                                              float eps, float* __restrict__ stats, float momentum,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar) {
+    __shared__ double sagg[256][9];   // (n, sum n_b mean_b [4], sum M2_b + n_b mean_b^2 [4]) per thread
+    const int G = 1 << L4, GB = bn_merge_groups_per_block(S);
+    const int g_base = (int)blockIdx.x * GB, ng = min(GB, G - g_base);
+    const int pairs = ng * S;   // pair p = (group g_base + p / S, segment p % S)
     int tpp = 1;
     while (tpp * 2 * pairs <= 256) tpp *= 2;
     for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
         const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
-        double n = 0.0, mu = 0.0, mm = 0.0;
+        double n = 0.0, sa[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
         if (pr < pairs) {
-            const int sgi = pr / c, cc = pr % c;
-            const int q0 = seg_first[sgi], q1 = seg_first[sgi + 1];
-            const int per = (q1 - q0 + tpp - 1) / tpp;
-            const int a0 = q0 + sub * per, a1 = min(a0 + per, q1);
-            for (int q = a0; q < a1; ++q) {
-                const double nb = (double)(chunks[q].r1 - chunks[q].r0);
-                const double mb = part[((int64_t)q * 2 + 0) * c + cc], m2b = part[((int64_t)q * 2 + 1) * c + cc];
-                const double d = mb - mu, nt = n + nb;
-                mu += d * nb / nt;
-                mm += m2b + d * d * n * nb / nt;
-                n = nt;
+            const int sgi = pr % S, g4 = g_base + pr / S;
+            const int s0 = 4 * seg_first[sgi], s1 = 4 * seg_first[sgi + 1];
+            const int per = (s1 - s0 + tpp - 1) / tpp;
+            const int a0 = s0 + sub * per, a1 = min(a0 + per, s1);
+            for (int q = a0; q < a1; q += 8) {
+                bn_f4 pm[8], p2[8];
+                int pn[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int qq = min(q + u, a1 - 1);
+                    pn[u] = q + u < a1 ? bn_quarter_rows(chunks[qq >> 2], qq & 3) : 0;
+                    pm[u] = *(const bn_f4*)(part + ((int64_t)qq * 2 + 0) * c + 4 * g4);
+                    p2[u] = *(const bn_f4*)(part + ((int64_t)qq * 2 + 1) * c + 4 * g4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double nb = (double)pn[u];
+                    n += nb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double mb = (double)pm[u][e];
+                        sa[e] += nb * mb;
+                        sq[e] += nb > 0.0 ? (double)p2[u][e] + nb * mb * mb : 0.0;
+                    }
+                }
             }
         }
-        sagg[threadIdx.x][0] = n; sagg[threadIdx.x][1] = mu; sagg[threadIdx.x][2] = mm;
+        sagg[threadIdx.x][0] = n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sagg[threadIdx.x][1 + e] = sa[e]; sagg[threadIdx.x][5 + e] = sq[e]; }
         __syncthreads();
         if (pr < pairs && sub == 0) {
-            double N = 0.0, MU = 0.0, M2 = 0.0;
+            double N = 0.0, A[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
             for (int q = 0; q < tpp; ++q) {
-                const double nb = sagg[threadIdx.x + q][0], mb = sagg[threadIdx.x + q][1], m2b = sagg[threadIdx.x + q][2];
-                if (nb <= 0.0) continue;
-                const double d = mb - MU, nt = N + nb;
-                MU += d * nb / nt;
-                M2 += m2b + d * d * N * nb / nt;
-                N = nt;
+                N += sagg[threadIdx.x + q][0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { A[e] += sagg[threadIdx.x + q][1 + e]; Q[e] += sagg[threadIdx.x + q][5 + e]; }
             }
-            const int sgi = pr / c, cc = pr % c;
-            const float var = N > 0.0 ? (float)(M2 / N) : 0.f;
+            const int sgi = pr % S, g4 = g_base + pr / S;
             float* st = stats + (int64_t)sgi * 3 * c;
-            st[cc] = (float)MU;
-            st[c + cc] = 1.0f / sqrtf(var + eps);
-            st[2 * c + cc] = var;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cc = 4 * g4 + e;
+                const double MU = N > 0.0 ? A[e] / N : 0.0;
+                double V = N > 0.0 ? (Q[e] - A[e] * MU) / N : 0.0;
+                if (V < 0.0) V = 0.0;
+                const float var = (float)V;
+                st[cc] = (float)MU;
+                st[c + cc] = 1.0f / sqrtf(var + eps);
+                st[2 * c + cc] = var;
+            }
         }
         __syncthreads();
     }
-    if (rmean && rvar) {
+    if (rmean && rvar) {   // (this block wrote every segment's statistics of its channels)
         __threadfence_block();
-        for (int cc = threadIdx.x; cc < c; cc += 256) {
+        __syncthreads();
+        for (int cl = threadIdx.x; cl < 4 * ng; cl += 256) {
+            const int cc = 4 * g_base + cl;
             float m = rmean[cc], v = rvar[cc];
             for (int sgi = 0; sgi < S; ++sgi) {
                 const int n = seg_rows[sgi];
@@ -838,7 +892,7 @@ __global__ void __launch_bounds__(256) k_bnseg_apply_v4(const float* __restrict_
     const bn_f4 ga = *(const bn_f4*)(gamma + 4 * cg), be = *(const bn_f4*)(beta + 4 * cg);
     for (int r = ra + rl; r < rb; r += RL) {
         const bn_f4 h = (*(const bn_f4*)(x + (int64_t)r * ld_x + 4 * cg) - mu) * is;
-        *(bn_f4*)(xhat + (int64_t)r * c + 4 * cg) = h;
+        if (xhat) *(bn_f4*)(xhat + (int64_t)r * c + 4 * cg) = h;   // (null: the backward recomputes it from x -- RECOMP below)
         bn_f4 v = h * ga + be;
         if (relu) {
 #pragma unroll
@@ -848,22 +902,58 @@ __global__ void __launch_bounds__(256) k_bnseg_apply_v4(const float* __restrict_
     }
 }
 
+// RECOMP (round 6): the forward kept the layer's INPUT x instead of writing x^ (one store pass less), so `xhat` = x with pitch ld_y here
+// and x^ = (x - mean) * invstd is recomputed -- the apply kernel's expression, the same bits --; the ReLU mask comes from
+// gamma * x^ + beta > 0 (what y > 0 says, y = max(gamma * x^ + beta, 0)) instead of a read of y: 9 instead of 12 passes over the
+// layer's elements per forward + backward.  `y` then carries nothing: RX = {stats, gamma, beta} ride along.
+struct BnRecomp { const float* stats; const float* gamma; const float* beta; };
+template <bool RECOMP>
 __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
                                                            const float* __restrict__ xhat, int c, int L4, int relu,
-                                                           const BnChunk* __restrict__ chunks, float* __restrict__ part,
-                                                           int* __restrict__ counter, const int* __restrict__ seg_first, int S,
-                                                           float* __restrict__ segsum, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           const BnChunk* __restrict__ chunks, float* __restrict__ part, BnRecomp RX) {
+    // grid (chunks, 4): one quarter of a chunk per block, partial slot = 4 chunk + quarter; k_bnseg_sums_merge_v4 folds the slots
     __shared__ bn_f4 smv[512];
     const BnChunk ch = chunks[blockIdx.x];
+    int qa, qb;
+    bn_quarter(ch, (int)blockIdx.y, qa, qb);
+    const int pslot = (int)blockIdx.x * 4 + (int)blockIdx.y;
     const int G = 1 << L4, t = threadIdx.x;
     const int cg = t & (G - 1), rl = t >> L4, RL = 256 >> L4;
     bn_f4 ab[2] = {(bn_f4){0.f, 0.f, 0.f, 0.f}, (bn_f4){0.f, 0.f, 0.f, 0.f}};
-    {
+    if (RECOMP) {
+        const float* st = RX.stats + (int64_t)ch.seg * 3 * c;
+        const bn_f4 mu = *(const bn_f4*)(st + 4 * cg), is = *(const bn_f4*)(st + c + 4 * cg);
+        const bn_f4 ga = *(const bn_f4*)(RX.gamma + 4 * cg), be = *(const bn_f4*)(RX.beta + 4 * cg);
+        constexpr int BN_UB = 8;
+        auto fold = [&](bn_f4 g, bn_f4 xr) {
+            const bn_f4 h = (xr - mu) * is;
+            if (relu) {
+                const bn_f4 v = h * ga + be;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(v[i] > 0.f)) g[i] = 0.f;
+            }
+            ab[0] += g;
+            ab[1] += g * h;
+        };
+        int r = qa + rl;
+        for (; r + (BN_UB - 1) * RL < qb; r += BN_UB * RL) {
+            bn_f4 g[BN_UB], xr[BN_UB];
+#pragma unroll
+            for (int u = 0; u < BN_UB; ++u) {
+                g[u] = *(const bn_f4*)(dy + (int64_t)(r + u * RL) * ld_dy + 4 * cg);
+                xr[u] = *(const bn_f4*)(xhat + (int64_t)(r + u * RL) * ld_y + 4 * cg);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UB; ++u) fold(g[u], xr[u]);
+        }
+        for (; r < qb; r += RL)
+            fold(*(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg), *(const bn_f4*)(xhat + (int64_t)r * ld_y + 4 * cg));
+    } else {
         // (BN_UB rows' (dy, y, x^) requested together, folded in row order: the sums' chains are those of a one-row loop)
         constexpr int BN_UB = 4;
-        int r = ch.r0 + rl;
-        for (; r + (BN_UB - 1) * RL < ch.r1; r += BN_UB * RL) {
+        int r = qa + rl;
+        for (; r + (BN_UB - 1) * RL < qb; r += BN_UB * RL) {
             bn_f4 g[BN_UB], yy[BN_UB], xh[BN_UB];
 #pragma unroll
             for (int u = 0; u < BN_UB; ++u) {
@@ -885,7 +975,7 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restri
                 ab[1] += g[u] * xh[u];
             }
         }
-        for (; r < ch.r1; r += RL) {
+        for (; r < qb; r += RL) {
             bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
             if (relu) {
                 const bn_f4 yy = *(const bn_f4*)(y + (int64_t)r * ld_y + 4 * cg);
@@ -899,46 +989,61 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restri
     }
     bn_reduce_rows<2>(ab, smv, G);
     if (rl == 0) {
-        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 0) * c + 4 * cg) = ab[0];
-        *(bn_f4*)(part + ((int64_t)blockIdx.x * 2 + 1) * c + 4 * cg) = ab[1];
+        *(bn_f4*)(part + ((int64_t)pslot * 2 + 0) * c + 4 * cg) = ab[0];
+        *(bn_f4*)(part + ((int64_t)pslot * 2 + 1) * c + 4 * cg) = ab[1];
     }
-    if (!last_block_done(counter, (int)gridDim.x)) return;
-    // per (segment, channel): `tpp` threads share a pair, each over a contiguous run of the segment's chunk list (table order), then
-    // one of them adds their sums in thread order -- the result does not depend on which block merges, only on (S, c, chunk table)
-    {
-        float* sa2 = (float*)smv;          // (the reduction buffer is free again: 256 + 256 floats)
-        float* sb2 = sa2 + 256;
-        const int pairs = S * c;
-        int tpp = 1;
-        while (tpp * 2 * pairs <= 256) tpp *= 2;
-        for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
-            const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
-            float ta = 0.f, tb = 0.f;
-            if (pr < pairs) {
-                const int sgi = pr / c, cc = pr % c;
-                const int q0 = seg_first[sgi], q1 = seg_first[sgi + 1];
-                const int per = (q1 - q0 + tpp - 1) / tpp;
-                const int a0 = q0 + sub * per, a1 = min(a0 + per, q1);
-                for (int q = a0; q < a1; ++q) {
-                    ta += part[((int64_t)q * 2 + 0) * c + cc];
-                    tb += part[((int64_t)q * 2 + 1) * c + cc];
+}
+
+// grid (ceil(G / GB)); block 256 -- see k_bnseg_stats_merge_v4; per channel the slots' sums are added in table order
+__global__ void __launch_bounds__(256) k_bnseg_sums_merge_v4(const float* __restrict__ part, int c, int L4, const int* __restrict__ seg_first,
+                                                             int S, float* __restrict__ segsum, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    __shared__ bn_f4 sa4[256], sb4[256];
+    const int G = 1 << L4, GB = bn_merge_groups_per_block(S);
+    const int g_base = (int)blockIdx.x * GB, ng = min(GB, G - g_base);
+    const int pairs = ng * S;
+    int tpp = 1;
+    while (tpp * 2 * pairs <= 256) tpp *= 2;
+    for (int p0 = 0; p0 < pairs; p0 += 256 / tpp) {
+        const int pr = p0 + (int)threadIdx.x / tpp, sub = (int)threadIdx.x % tpp;
+        bn_f4 ta = (bn_f4){0.f, 0.f, 0.f, 0.f}, tb = ta;
+        if (pr < pairs) {
+            const int sgi = pr % S, g4 = g_base + pr / S;
+            const int s0 = 4 * seg_first[sgi], s1 = 4 * seg_first[sgi + 1];
+            const int per = (s1 - s0 + tpp - 1) / tpp;
+            const int a0 = s0 + sub * per, a1 = min(a0 + per, s1);
+            int q = a0;
+            for (; q + 8 <= a1; q += 8) {
+                bn_f4 pa[8], pb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    pa[u] = *(const bn_f4*)(part + ((int64_t)(q + u) * 2 + 0) * c + 4 * g4);
+                    pb[u] = *(const bn_f4*)(part + ((int64_t)(q + u) * 2 + 1) * c + 4 * g4);
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ta += pa[u]; tb += pb[u]; }
             }
-            sa2[threadIdx.x] = ta;
-            sb2[threadIdx.x] = tb;
-            __syncthreads();
-            if (pr < pairs && sub == 0) {
-                float xa = 0.f, xb = 0.f;
-                for (int q = 0; q < tpp; ++q) { xa += sa2[threadIdx.x + q]; xb += sb2[threadIdx.x + q]; }
-                const int sgi = pr / c, cc = pr % c;
-                segsum[((int64_t)sgi * 2 + 0) * c + cc] = xa;
-                segsum[((int64_t)sgi * 2 + 1) * c + cc] = xb;
+            for (; q < a1; ++q) {
+                ta += *(const bn_f4*)(part + ((int64_t)q * 2 + 0) * c + 4 * g4);
+                tb += *(const bn_f4*)(part + ((int64_t)q * 2 + 1) * c + 4 * g4);
             }
-            __syncthreads();
         }
+        sa4[threadIdx.x] = ta;
+        sb4[threadIdx.x] = tb;
+        __syncthreads();
+        if (pr < pairs && sub == 0) {
+            bn_f4 xa = (bn_f4){0.f, 0.f, 0.f, 0.f}, xb = xa;
+            for (int q = 0; q < tpp; ++q) { xa += sa4[threadIdx.x + q]; xb += sb4[threadIdx.x + q]; }
+            const int sgi = pr % S, g4 = g_base + pr / S;
+            *(bn_f4*)(segsum + ((int64_t)sgi * 2 + 0) * c + 4 * g4) = xa;
+            *(bn_f4*)(segsum + ((int64_t)sgi * 2 + 1) * c + 4 * g4) = xb;
+        }
+        __syncthreads();
     }
+    __threadfence_block();
     __syncthreads();
-    for (int cc = threadIdx.x; cc < c; cc += 256) {
+    for (int cl = threadIdx.x; cl < 4 * ng; cl += 256) {   // (this block wrote every segment's sums of its channels)
+        const int cc = 4 * g_base + cl;
         float ta = 0.f, tb = 0.f;
         for (int sgi = 0; sgi < S; ++sgi) {
             ta += segsum[((int64_t)sgi * 2 + 0) * c + cc];
@@ -949,11 +1054,13 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_sums_v4(const float* __restri
     }
 }
 
+template <bool RECOMP>
 __global__ void __launch_bounds__(256) k_bnseg_bwd_dx_v4(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
                                                          const float* __restrict__ xhat, int c, int L4, int relu,
                                                          const BnChunk* __restrict__ chunks, const int* __restrict__ seg_rows,
                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                         const float* __restrict__ segsum, float* __restrict__ dx, int ld_dx) {
+                                                         const float* __restrict__ segsum, float* __restrict__ dx, int ld_dx,
+                                                         const float* __restrict__ beta) {
     const BnChunk ch = chunks[blockIdx.x];
     const float* st = stats + (int64_t)ch.seg * 3 * c;
     const float* sg = segsum + (int64_t)ch.seg * 2 * c;
@@ -965,6 +1072,21 @@ __global__ void __launch_bounds__(256) k_bnseg_bwd_dx_v4(const float* __restrict
     const bn_f4 s0 = *(const bn_f4*)(sg + 4 * cg) * inv_n, s1 = *(const bn_f4*)(sg + c + 4 * cg) * inv_n;
     const bn_f4 ga = *(const bn_f4*)(gamma + 4 * cg), is = *(const bn_f4*)(st + c + 4 * cg);
     (void)gi;
+    if (RECOMP) {   // (xhat = the layer's input x, pitch ld_y; see k_bnseg_bwd_sums_v4)
+        const bn_f4 mu = *(const bn_f4*)(st + 4 * cg), be = *(const bn_f4*)(beta + 4 * cg);
+        for (int r = ra + rl; r < rb; r += RL) {
+            bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
+            const bn_f4 xh = (*(const bn_f4*)(xhat + (int64_t)r * ld_y + 4 * cg) - mu) * is;
+            if (relu) {
+                const bn_f4 v = xh * ga + be;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(v[i] > 0.f)) g[i] = 0.f;
+            }
+            *(bn_f4*)(dx + (int64_t)r * ld_dx + 4 * cg) = ga * is * (g - s0 - xh * s1);
+        }
+        return;
+    }
     for (int r = ra + rl; r < rb; r += RL) {
         bn_f4 g = *(const bn_f4*)(dy + (int64_t)r * ld_dy + 4 * cg);
         if (relu) {
@@ -1171,7 +1293,8 @@ static int bn_vec_log2(int c, int ld_a, int ld_b, int ld_c, const void* p0, cons
 }
 
 extern "C" size_t insmos_batchnorm_seg_ws_floats(int n_chunks, int c, int S) {
-    return (size_t)2 * (size_t)(n_chunks > 0 ? n_chunks : 1) * (size_t)c + (size_t)2 * (size_t)(S > 0 ? S : 1) * (size_t)c + 64;
+    // (partials: 2 rows of c floats per chunk QUARTER -- the 16-byte reduction kernels run a block per quarter)
+    return (size_t)8 * (size_t)(n_chunks > 0 ? n_chunks : 1) * (size_t)c + (size_t)2 * (size_t)(S > 0 ? S : 1) * (size_t)c + 64;
 }
 
 extern "C" int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int64_t n, const int32_t* chunks, int n_chunks,
@@ -1180,16 +1303,21 @@ extern "C" int insmos_batchnorm_seg_forward(const float* x, int ld_x, int c, int
                                             float* running_mean, float* running_var, float momentum, int32_t* ticket, float* ws,
                                             void* stream) {
     if (n <= 0 || c <= 0 || n_chunks <= 0) return INSMOS_OK;
-    if (!x || !chunks || !seg_first || !seg_rows || S < 1 || !gamma || !beta || !y || !xhat || !stats || !ws || !ticket || ld_x < c ||
+    if (!x || !chunks || !seg_first || !seg_rows || S < 1 || !gamma || !beta || !y || !stats || !ws || !ticket || ld_x < c ||
         ld_y < c || n >= (1ll << 31))
         return INSMOS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const BnChunk* ch = (const BnChunk*)chunks;
+    const int l4 = bn_vec_log2(c, ld_x, ld_y, c, x, y, xhat ? xhat : y, gamma, beta);
+    // xhat NULL: x^ is not stored -- the caller keeps x and takes insmos_batchnorm_seg_backward_x (16-byte kernels only:
+    // insmos_batchnorm_seg_recompute_ok says whether a shape qualifies)
+    if (!xhat && l4 < 0) return INSMOS_EINVAL;
     ProfScope ps(KK_BATCHNORM, s);
-    const int l4 = bn_vec_log2(c, ld_x, ld_y, c, x, y, xhat, gamma, beta);
     if (l4 >= 0) {
-        INSMOS_LAUNCH(k_bnseg_stats_v4, dim3(n_chunks), dim3(256), 0, s, x, ld_x, c, l4, ch, ws, ticket, seg_first, seg_rows, S, eps, stats,
-                      momentum, running_mean, running_var);
+        const int mg = (int)cdiv((int64_t)(1 << l4), bn_merge_groups_per_block(S));
+        INSMOS_LAUNCH(k_bnseg_stats_v4, dim3(n_chunks, 4), dim3(256), 0, s, x, ld_x, c, l4, ch, ws);
+        INSMOS_LAUNCH(k_bnseg_stats_merge_v4, dim3(mg), dim3(256), 0, s, ws, c, l4, ch, seg_first, seg_rows, S, eps, stats, momentum,
+                      running_mean, running_var);
         INSMOS_LAUNCH(k_bnseg_apply_v4, dim3(n_chunks, 4), dim3(256), 0, s, x, ld_x, c, l4, ch, stats, gamma, beta, relu, xhat, y, ld_y);
         HIP_TRY(hipGetLastError());
         return INSMOS_OK;
@@ -1212,14 +1340,16 @@ extern "C" int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const f
     hipStream_t s = (hipStream_t)stream;
     const BnChunk* ch = (const BnChunk*)chunks;
     float* part = ws;
-    float* segsum = ws + (size_t)2 * n_chunks * c;
+    float* segsum = ws + (size_t)8 * n_chunks * c;
     ProfScope ps(KK_BATCHNORM, s);
     const int l4 = bn_vec_log2(c, ld_dy, relu ? ld_y : c, ld_dx, dy, relu ? y : dy, xhat, gamma, dx);
     if (l4 >= 0) {
-        INSMOS_LAUNCH(k_bnseg_bwd_sums_v4, dim3(n_chunks), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, part, ticket, seg_first,
-                      S, segsum, dgamma, dbeta);
-        INSMOS_LAUNCH(k_bnseg_bwd_dx_v4, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, seg_rows, gamma, stats,
-                      segsum, dx, ld_dx);
+        INSMOS_LAUNCH(k_bnseg_bwd_sums_v4<false>, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, part,
+                      BnRecomp{nullptr, nullptr, nullptr});
+        INSMOS_LAUNCH(k_bnseg_sums_merge_v4, dim3((int)cdiv((int64_t)(1 << l4), bn_merge_groups_per_block(S))), dim3(256), 0, s, part, c, l4,
+                      seg_first, S, segsum, dgamma, dbeta);
+        INSMOS_LAUNCH(k_bnseg_bwd_dx_v4<false>, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, l4, relu, ch, seg_rows, gamma,
+                      stats, segsum, dx, ld_dx, (const float*)nullptr);
         HIP_TRY(hipGetLastError());
         return INSMOS_OK;
     }
@@ -1227,6 +1357,37 @@ extern "C" int insmos_batchnorm_seg_backward(const float* dy, int ld_dy, const f
                   S, segsum, dgamma, dbeta);
     INSMOS_LAUNCH(k_bnseg_bwd_dx, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, y, ld_y, xhat, c, relu, ch, seg_rows, gamma, stats, segsum,
                   dx, ld_dx);
+    HIP_TRY(hipGetLastError());
+    return INSMOS_OK;
+}
+
+// The backward of a forward that did NOT store x^ (insmos_batchnorm_seg_forward with xhat = NULL): x = the layer's input (pitch ld_x),
+// x^ and the ReLU mask are recomputed from it -- the same expressions, the same gradients bit for bit, three passes over the layer's
+// elements fewer per step.  16-byte kernels only: EINVAL for shapes insmos_batchnorm_seg_recompute_ok refuses.
+extern "C" int insmos_batchnorm_seg_recompute_ok(int c, int ld_x, int ld_dy, int ld_dx) {
+    return (c >= 4 && !(c & 3) && !((c / 4) & (c / 4 - 1)) && c / 4 <= 64 && !(ld_x & 3) && !(ld_dy & 3) && !(ld_dx & 3)) ? 1 : 0;
+}
+extern "C" int insmos_batchnorm_seg_backward_x(const float* dy, int ld_dy, const float* x, int ld_x, int c, int64_t n, const int32_t* chunks,
+                                               int n_chunks, const int32_t* seg_first, const int32_t* seg_rows, int S, const float* gamma,
+                                               const float* beta, const float* stats, int relu, float* dx, int ld_dx, float* dgamma,
+                                               float* dbeta, int32_t* ticket, float* ws, void* stream) {
+    if (n <= 0 || c <= 0 || n_chunks <= 0) return INSMOS_OK;
+    if (!dy || !x || !chunks || !seg_first || !seg_rows || S < 1 || !gamma || !beta || !stats || !dx || !dgamma || !dbeta || !ws || !ticket ||
+        ld_dy < c || ld_dx < c || ld_x < c)
+        return INSMOS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const BnChunk* ch = (const BnChunk*)chunks;
+    float* part = ws;
+    float* segsum = ws + (size_t)8 * n_chunks * c;
+    const int l4 = bn_vec_log2(c, ld_dy, ld_x, ld_dx, dy, x, beta, gamma, dx);
+    if (l4 < 0) return INSMOS_EINVAL;
+    ProfScope ps(KK_BATCHNORM, s);
+    INSMOS_LAUNCH(k_bnseg_bwd_sums_v4<true>, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, (const float*)nullptr, ld_x, x, c, l4, relu, ch, part,
+                  BnRecomp{stats, gamma, beta});
+    INSMOS_LAUNCH(k_bnseg_sums_merge_v4, dim3((int)cdiv((int64_t)(1 << l4), bn_merge_groups_per_block(S))), dim3(256), 0, s, part, c, l4,
+                  seg_first, S, segsum, dgamma, dbeta);
+    INSMOS_LAUNCH(k_bnseg_bwd_dx_v4<true>, dim3(n_chunks, 4), dim3(256), 0, s, dy, ld_dy, (const float*)nullptr, ld_x, x, c, l4, relu, ch, seg_rows,
+                  gamma, stats, segsum, dx, ld_dx, beta);
     HIP_TRY(hipGetLastError());
     return INSMOS_OK;
 }

@@ -253,6 +253,56 @@ def test_segmented_batchnorm_vs_torch_per_segment(relu, S, chunk, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c,relu,S", [(8, True, 4), (16, False, 3), (32, True, 1), (128, True, 2), (256, True, 2)])
+def test_segmented_batchnorm_recompute_is_bitwise_the_stored_xhat_path(c, relu, S, monkeypatch):
+    """Round 6: the segmented BatchNorm keeps the layer's input instead of storing x^ (insmos_batchnorm_seg_forward with xhat = NULL,
+    insmos_batchnorm_seg_backward_x recomputes x^ and the ReLU mask): outputs, running statistics and all three gradients are the
+    bits of the stored-x^ path, for every 16-byte width, with and without the fused ReLU, one and several segments -- and the
+    float64 torch yardstick still holds."""
+    import torch
+    import torch.nn.functional as F
+    from insmos_amd import autograd as AG
+    monkeypatch.delenv("INSMOS_BN_CHUNK", raising=False)
+    rng = np.random.default_rng(400 + c + S)
+    run_len = [int(v) for v in rng.integers(1, 1900, size=5 * S)]
+    seg = np.concatenate([np.full(l, i % S, np.int32) for i, l in enumerate(run_len)])
+    n = len(seg)
+    x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 3, c) + rng.normal(size=c) + seg[:, None] * 0.7).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(size=c).astype(np.float32)
+    gy = torch.from_numpy(rng.normal(size=(n, c)).astype(np.float32)).cuda()
+    plan = AG.BnPlan.from_segment_ids(torch.from_numpy(seg).cuda(), S)
+    lib = AG._lib.load()
+    assert lib.insmos_batchnorm_seg_recompute_ok(c, c, c, c) == 1 and lib.insmos_batchnorm_seg_recompute_ok(24, 24, 24, 24) == 0
+
+    def run(recompute):
+        monkeypatch.setattr(AG, "BN_RECOMPUTE", recompute)
+        xt = torch.from_numpy(x).cuda().requires_grad_(True)
+        gt_, bt = torch.from_numpy(gamma).cuda().requires_grad_(True), torch.from_numpy(beta).cuda().requires_grad_(True)
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        y = AG.batch_norm_train_seg(xt, gt_, bt, plan, rm, rv, momentum=0.01, eps=1e-3, relu=relu, force_segmented=True)
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), xt.grad, gt_.grad, bt.grad, rm, rv
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    gr, br = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    yr = torch.zeros((n, c), dtype=torch.float64)
+    segt = torch.from_numpy(seg).long()
+    for sg in range(S):
+        rows = torch.nonzero(segt == sg).flatten()
+        ys = F.batch_norm(xr[rows], None, None, gr, br, training=True, eps=1e-3)
+        yr = yr.index_copy(0, rows, torch.relu(ys) if relu else ys)
+    (yr * gy.cpu().double()).sum().backward()
+    np.testing.assert_allclose(a[0].cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(a[1].cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=3e-4)
+    np.testing.assert_allclose(a[2].cpu().numpy(), gr.grad.numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(a[3].cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.gpu
 def test_conv_bn_relu_conv_loss_graph_vs_torch_reference():
     """One trainable block (SubMConv3d -> BatchNorm1d -> ReLU -> SubMConv3d -> MOSLoss, train mode) on the HIP autograd
     nodes vs the same graph written with torch index ops in float64 on the CPU: loss and every parameter gradient."""

@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CONV_KERNELS = ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_deconv_head", "k_bev_conv3x3", "k_const_conv125")
+CONV_KERNELS = ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_conv_tapc", "k_conv_wide", "k_deconv_head", "k_bev_conv3x3", "k_const_conv125")
 
 
 def workload():

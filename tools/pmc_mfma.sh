@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
 starts = [i for i, r in enumerate(rows) if "k_parent_cubes" in r["Kernel_Name"]]   # the LAST launch set of the trace only
 rows = rows[starts[-1]:] if starts else rows
-conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_deconv_head", "k_bev_conv", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125"))]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_conv_tapc", "k_conv_wide", "k_deconv_head", "k_bev_conv", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125"))]
 tot = {}
 for r in conv:
     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

@@ -16,7 +16,7 @@ import csv
 import json
 
 PEAK = 157.3
-CONV = ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_deconv_head", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125", "k_bev_conv", "k_bev_group_lists")
+CONV = ("k_sparse_conv", "k_conv_rowlane", "k_conv_row32", "k_conv_tapc", "k_conv_wide", "k_deconv_head", "k_resolve_taps<2, 1, 1>", "k_parent_cubes", "k_const_conv125", "k_bev_conv", "k_bev_group_lists")
 
 
 def main():
