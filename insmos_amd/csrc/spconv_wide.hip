@@ -20,7 +20,7 @@
 //
 // STATUS (round 6, measured: profiles/r06_wide_layers_ab.csv, r06_wide_probe_layers.csv): OPT-IN (INSMOS_CONV_WIDE=1), the chunk-split
 // tiles stay the default.  Same bits, but 1.2-1.6x SLOWER on the 64 / 128-channel layers (conv4.1.0: 217 us split, 303 us here).  The
-// probe builds (INSMOS_WIDE_PROBE) say where the time is: without gathers AND without weight loads the kernel still needs 230 us, and
+// probe builds (-DINSMOS_WIDE_PROBE_BUILD, INSMOS_WIDE_PROBE) say where the time is: without gathers AND without weight loads the kernel still needs 230 us, and
 // without MFMAs 16 us -- the load side this kernel improves (half the fragment traffic, whole-line gathers) was not the limit of these
 // layers; what the kernel adds -- one barrier per tap for five waves, 1 296 heavy workgroups (three resident per CU) for 256 CUs
 // where the split tiles have 2 592 light ones -- costs MFMA issue slots.  The split tiles already run these layers at 94 TFLOP/s
@@ -319,6 +319,7 @@ ConvKernelFn conv_wide_pick(const ConvP& P, long* blocks) {
     *blocks = (rows + 31) / 32;
     const bool c2 = P.ntile_co == 8;
     if (P.n16 == 4) return c2 ? k_conv_wide<4, 1, 2> : k_conv_wide<4, 1, 1>;
+#ifdef INSMOS_WIDE_PROBE_BUILD   // (not in the product library: add -DINSMOS_WIDE_PROBE_BUILD to FLAGS of __graft_entry__.py for tools/r06_wide_probe.sh)
     if (P.n16 == 8 && c2) {   // PROBE builds (timing only, wrong results): 1 = no gathers, 2 = no MFMAs, 4 = no weight loads
         const char* e = getenv("INSMOS_WIDE_PROBE");
         switch (e ? atoi(e) : 0) {
@@ -331,6 +332,7 @@ ConvKernelFn conv_wide_pick(const ConvP& P, long* blocks) {
             default: break;
         }
     }
+#endif
     if (P.n16 == 8) return c2 ? k_conv_wide<8, 1, 2> : k_conv_wide<8, 1, 1>;
     return c2 ? k_conv_wide<8, 2, 2> : k_conv_wide<8, 2, 1>;
 }
