@@ -734,3 +734,25 @@ def test_bench_traffic_record_is_tied_to_the_binary(tmp_path):
     assert bench.pmc_traffic(args, 2, "cfg4", profiles_dir=str(tmp_path), lib_hash="abcdef012345")[1] is False
     h = bench.lib_source_hash()
     assert h is None or (len(h) == 12 and all(c in "0123456789abcdef" for c in h))
+
+
+def test_gather_rows_backward_is_a_deterministic_scatter_add():
+    """insmos_amd.autograd.gather_rows (the point -> voxel gathers of both heads, spconv_unet.py:408-410, motionnet.py:42-46): forward is
+    plain row indexing; the backward -- a fixed-point int64 scatter-add, so that repeated rows add in any order to the same bits --
+    equals torch's sort-based indexing backward to 1e-9 and gives identical bits for a permuted index stream (runs on the CPU: torch
+    ops only)."""
+    import torch
+    from insmos_amd.autograd import gather_rows
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 3, generator=g, requires_grad=True)
+    idx = torch.randint(0, 300, (20000,), generator=g)
+    gy = torch.randn(20000, 3, generator=g) * 1e-3
+    y = gather_rows(x, idx)
+    assert torch.equal(y, x[idx])
+    y.backward(gy)
+    ref = torch.zeros(300, 3, dtype=torch.float64).index_add_(0, idx, gy.double())
+    assert float((x.grad.double() - ref).abs().max()) < 1e-9
+    perm = torch.randperm(20000, generator=g)
+    x2 = x.detach().clone().requires_grad_(True)
+    gather_rows(x2, idx[perm]).backward(gy[perm])
+    assert torch.equal(x2.grad, x.grad)
