@@ -373,3 +373,49 @@ def test_native_runner_launch_list_equals_the_step_path(setup):
         tot = sum(w[i][4] for w in wants)
         # (row0 of a set is rounded down to a 16-row group once, not once per window)
         assert abs(grows - tot) <= 16 * 3, (name, grows, tot)
+
+
+def test_degenerate_windows(setup):
+    """Edge inputs the reference's loop can meet on real sequences: windows of a handful of points (tight parity with the oracle), a
+    window whose points all lie outside POINT_CLOUD_RANGE (the 3D branch has no voxel: every current point gets the zero logits of
+    a dropped point, spconv_unet.py:408-410, and there is no box), a single point, a window without a current scan (refused with a
+    ValueError, nothing launched), and a launch set that mixes a normal window with a 50-point one (each gets the bits it gets
+    alone)."""
+    from insmos_amd import params as P
+    from insmos_amd.models import InsMOSNet
+    from insmos_amd.synth import make_window
+    cfg = setup["cfg"]
+    sd = P.random_state_dict(cfg, 1)
+    model = InsMOSNet(cfg, state_dict=sd).cuda().eval()
+    w = make_window(seed=3, n_scans=10, n_az=64)
+    rng = np.random.default_rng(0)
+
+    def fwd(wins):
+        pred, _, logits = model.forward([{"past_point_clouds": torch.from_numpy(x).cuda()} for x in wins], "test")
+        torch.cuda.synchronize()
+        return pred, logits
+
+    for n_pts in (200, 17):
+        sub = w[rng.choice(len(w), n_pts, replace=False)]
+        if not (sub[:, 4] == 0).any():
+            sub[0, 4] = 0.0
+        pred, logits = fwd([sub])
+        ref_logits, ref_pred = M.forward_window(sd, cfg, sub)
+        assert logits[0].shape == ref_logits.shape == (int((sub[:, 4] == 0).sum()), 3)
+        np.testing.assert_allclose(logits[0].cpu().numpy(), ref_logits, atol=1e-5, rtol=0)
+        assert pred[0][0]["pred_boxes"].shape == (0, 7)
+    far = w.copy()
+    far[:, :3] += 1000.0
+    pred, logits = fwd([far])
+    assert logits[0].shape == (int((w[:, 4] == 0).sum()), 3) and float(logits[0].abs().max()) == 0.0
+    assert pred[0][0]["pred_boxes"].shape == (0, 7)
+    pred, logits = fwd([w[w[:, 4] == 0][:1]])
+    assert logits[0].shape == (1, 3) and bool(torch.isfinite(logits[0]).all())
+    with pytest.raises(ValueError):
+        fwd([w[w[:, 4] != 0]])
+    small = w[rng.choice(len(w), 50, replace=False)]
+    small[0, 4] = 0.0
+    _, both = fwd([w, small])
+    _, la = fwd([w])
+    _, lb = fwd([small])
+    assert torch.equal(both[0], la[0]) and torch.equal(both[1], lb[0])
